@@ -1,0 +1,196 @@
+/*
+ * u3d.h -- C ABI of the MI355X (gfx950) kernels behind UniDet3D's detection hot path.
+ *
+ * Every entry point replaces an operator the reference reaches through a third-party
+ * CUDA package (call sites cited per function, file:line relative to the reference repo).
+ * Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *     the name ends in _host;
+ *   - returns 0 on success, a negative U3D_E* code otherwise; never throws;
+ *   - the caller owns every buffer; scratch is passed explicitly (`ws`, sized by the
+ *     matching *_ws_bytes() query); no hidden allocation, no device synchronisation:
+ *     work is enqueued on `stream`; counts the host needs (voxel counts) are read back
+ *     by the caller from the documented device words;
+ *   - thread-safe for distinct streams.
+ * Rows of feature matrices are contiguous fp32 ([N, C] row-major, C % 16 == 0 for the
+ * convolution operands).  Voxel rows are in CANONICAL order: ascending
+ * key = ((b*X + x)*Y + y)*Z + z.  Rulebook pair lists are grouped by kernel offset and
+ * ascending in both columns inside an offset.
+ */
+#ifndef U3D_H_
+#define U3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* u3d_stream_t; /* hipStream_t */
+
+#define U3D_OK 0
+#define U3D_EINVAL (-1)   /* bad argument / unsupported size */
+#define U3D_ELAUNCH (-2)  /* HIP launch error (hipGetLastError != success) */
+#define U3D_EUNSUPPORTED (-3) /* channel combination not instantiated */
+
+int u3d_version(void);
+const char* u3d_last_error(void);
+
+/* ---- kernel timing (HIP events on the launch stream; used by bench.py's roofline) ---- */
+enum { U3D_K_CONV_FWD = 0, U3D_K_CONV_WGRAD = 1, U3D_K_BN = 2, U3D_K_POOL = 3, U3D_K_ATTN_FWD = 4,
+       U3D_K_ATTN_BWD = 5, U3D_K_RULEBOOK = 6, U3D_K_VOXELIZE = 7, U3D_K_COUNT = 8 };
+int u3d_prof_enable(int kernel_class, int on);           /* record start/stop events around each launch of the class */
+int u3d_prof_collect(int kernel_class, double* total_ms, int64_t* launches, double* work); /* syncs the events, then resets */
+
+/* =====================================================================================
+ * R1  voxelisation -- replaces ME.utils.batch_sparse_collate + ME.TensorField(...).sparse()
+ *     + field.inverse_mapping (unidet3d/unidet3d.py:158-174).
+ * ===================================================================================== */
+/* Per-scene min/max of the coordinate source and mean of xyz; also the batch-wide maximum
+ * cell index per axis.  points [n_pts, 6] (xyz rgb); coord_src == NULL -> xyz of `points`
+ * scaled by 1/voxel_size (unidet3d.py:159), else coord_src [n_pts,3] already in voxel units
+ * (elastic path, :164, pass voxel_size = 1).  pt_offsets int64 [B+1].
+ * div_mode 0: IEEE divide (what torch's CPU kernel does -- the oracle); 1: multiply by the
+ * fp32 reciprocal (what torch's CUDA div-by-scalar kernel does).
+ * stats float [B,12] = min[3] max[3] mean_xyz[3] pad[3]; grid_max int32[3]. */
+int u3d_vox_scene_stats(const float* points, const float* coord_src, const int64_t* pt_offsets, int B,
+                        int64_t max_pts_per_scene, float voxel_size, int div_mode, float* stats,
+                        int32_t* grid_max, void* ws, u3d_stream_t stream);
+int64_t u3d_vox_scene_stats_ws_bytes(int B);
+
+/* Occupancy index of one level: bitmap uint64 [B*X*Y*Zw] (Zw = ceil(Z/64); bit z&63 of word
+ * ((b*X+x)*Y+y)*Zw + (z>>6)) and word_rank int32 [n_words+1] = exclusive popcount prefix, so
+ * row(b,x,y,z) = word_rank[w] + popc(bitmap[w] & ((1<<bit)-1)) IS the canonical row. */
+int64_t u3d_index_words(int B, int X, int Y, int Z);
+/* sets the bit of every point's cell; writes pt_cell int64 [n_pts] = word*64 + bit. bitmap must be zeroed. */
+int u3d_vox_mark(const float* points, const float* coord_src, const int64_t* pt_offsets, int B,
+                 int64_t max_pts_per_scene, const float* stats, float voxel_size, int div_mode, int X, int Y,
+                 int Z, uint64_t* bitmap, int64_t* pt_cell, u3d_stream_t stream);
+/* word_rank[0..n_words] ; word_rank[n_words] = number of active voxels (host reads it back). */
+int u3d_index_rank(const uint64_t* bitmap, int64_t n_words, int32_t* word_rank, void* ws, u3d_stream_t stream);
+int64_t u3d_index_rank_ws_bytes(int64_t n_words);
+/* coords int32 [n_vox,4] (b,x,y,z) in canonical order from the index. */
+int u3d_index_coords(const uint64_t* bitmap, const int32_t* word_rank, int B, int X, int Y, int Z,
+                     int32_t* coords, u3d_stream_t stream);
+/* inverse int64 [n_pts] (point -> voxel row); CSR of points per voxel (vox_offsets int32 [n_vox+1],
+ * vox_points int32 [n_pts]); feats [n_vox,6] = unweighted mean of [rgb, xyz - mean_xyz(scene)]. */
+int u3d_vox_finalize(const float* points, const int64_t* pt_offsets, int B, int64_t n_pts, const float* stats,
+                     const int64_t* pt_cell, const uint64_t* bitmap, const int32_t* word_rank, int64_t n_vox,
+                     int64_t* inverse, int32_t* vox_offsets, int32_t* vox_points, float* feats, int feat_ld,
+                     void* ws, u3d_stream_t stream);
+int64_t u3d_vox_finalize_ws_bytes(int64_t n_pts, int64_t n_vox);
+
+/* =====================================================================================
+ * R2  SubMConv3d rulebook (spconv indice pairs, k=3) -- first conv of each indice_key
+ *     subm1..5 (unidet3d/unidet3d.py:97-103, unidet3d/spconv_unet.py:43-56,138).
+ *     pair_in/pair_out int32 [27, n]; counts int32 [27]; offset k=(dx+1)*9+(dy+1)*3+(dz+1),
+ *     input = output + (dx,dy,dz).
+ * ===================================================================================== */
+int u3d_subm_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank,
+                      int B, int X, int Y, int Z, int32_t* pair_in, int32_t* pair_out, int32_t* counts,
+                      void* ws, u3d_stream_t stream);
+int64_t u3d_subm_rulebook_ws_bytes(int64_t n);
+
+/* =====================================================================================
+ * R3  SparseConv3d(k=2,s=2) rulebook, reused by SparseInverseConv3d
+ *     (unidet3d/spconv_unet.py:148-154,178-183).  out = in>>1, k=(x&1)*4+(y&1)*2+(z&1),
+ *     out dims = floor(in/2), inputs whose parent is out of range are dropped.
+ * ===================================================================================== */
+/* sets the bit of (b, x>>shift, y>>shift, z>>shift) for every row whose shifted cell is inside (X,Y,Z);
+ * shift = 1 builds the next (coarser) level, shift = 0 indexes a caller-supplied coordinate list. bitmap must be zeroed. */
+int u3d_index_mark(const int32_t* coords, int64_t n, int shift, int X, int Y, int Z, uint64_t* bitmap,
+                   u3d_stream_t stream);
+int u3d_down_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap2, const int32_t* word_rank2,
+                      int B, int X2, int Y2, int Z2, int32_t* pair_in, int32_t* pair_out, int32_t* counts,
+                      void* ws, u3d_stream_t stream);
+int64_t u3d_down_rulebook_ws_bytes(int64_t n);
+
+/* tile_starts int32 [K, n_tiles+1]: lower bound of t*tile_rows in the (ascending) list rows[k][0..counts[k]). */
+int u3d_tile_starts(const int32_t* rows, const int32_t* counts, int K, int64_t cap, int tile_rows,
+                    int64_t n_tiles, int32_t* tile_starts, u3d_stream_t stream);
+
+/* =====================================================================================
+ * K4-K8  sparse convolution, all variants through one gather-MFMA-scatter kernel:
+ *   dst[scatter[k][p]] (+)= W_k . src[gather[k][p]]      for p < counts[k], k < K
+ * w_rows: weights with the DST channel as the row: w[(n*K + k)*Cs + c]  (n<Cd, c<Cs) --
+ * spconv's native [C_out,k0,k1,k2,C_in] for forward; u3d_weight_transpose() output for dgrad.
+ * scatter lists must be ascending (they are, in both columns); tile_starts from u3d_tile_starts
+ * on the scatter lists.  addend (nullable, [n_dst,Cd]) initialises the accumulator
+ * (fuses the residual add of ResidualBlock.forward, spconv_unet.py:88-89).
+ * Replaces SubMConv3d / SparseConv3d / SparseInverseConv3d forward and their input-gradients.
+ * ===================================================================================== */
+int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
+                   const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst,
+                   int tile_rows, const float* addend, float* dst, double flops_hint, u3d_stream_t stream);
+int u3d_spconv_tile_rows(int Cs, int Cd);   /* the tile height the kernel wants for this shape; <0 unsupported */
+/* dW[(n*K+k)*Cs + c] += sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]   (dW must be zeroed by the caller) */
+int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
+                     const int32_t* counts, int K, int64_t cap, int Cs, int Cd, float* dW,
+                     double flops_hint, u3d_stream_t stream);
+/* wt[(c*K + k)*Cd + n] = w[(n*K + k)*Cs + c] */
+int u3d_weight_transpose(const float* w, float* wt, int Cd, int K, int Cs, u3d_stream_t stream);
+
+/* =====================================================================================
+ * K9  BatchNorm1d / SyncBatchNorm (train) + ReLU over voxel rows
+ *     (unidet3d/spconv_unet.py:42,49,119-124,147,177; unidet3d/unidet3d.py:104-111).
+ *     Split so that the caller can all-reduce the fp64 statistics between the two phases
+ *     (SyncBatchNorm across data-parallel ranks).
+ * ===================================================================================== */
+int u3d_bn_stats(const float* x, int64_t n, int C, double* sums /*[2C]: sum, sum of squares; += */, u3d_stream_t stream);
+/* mean/var from sums/count; scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place
+ * (momentum, unbiased var) when running_mean != NULL. */
+int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, int C, float* mean, float* invstd,
+                    float* scale, float* shift, u3d_stream_t stream);
+int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y,
+                 u3d_stream_t stream);
+/* backward of y = relu(x*scale+shift): sums[0..C) += sum dy', sums[C..2C) += sum dy'*xhat  (dy' = dy*[y>0]) */
+int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd,
+                     const float* scale, const float* shift, int relu, int64_t n, int C, double* sums,
+                     u3d_stream_t stream);
+/* dx = scale*(dy' - sum_dy/count - xhat*sum_dyxhat/count); dgamma = sum_dyxhat, dbeta = sum_dy (fp32 out) */
+int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd,
+                     const float* scale, const float* shift, int relu, const double* sums, double count,
+                     int64_t n, int C, float* dx, float* dgamma, float* dbeta, u3d_stream_t stream);
+
+/* =====================================================================================
+ * K11/K12  superpoint pooling -- replaces x.features[inverse_mapping] + torch_scatter.scatter_mean
+ *     (unidet3d/unidet3d.py:130) and the superpoint centres (:332-333, :446-447).
+ * ===================================================================================== */
+/* CSR of element ids per segment: offsets int32 [S+1], list int32 [L] (order inside a segment unspecified). */
+int u3d_csr_build(const int64_t* seg_ids, int64_t L, int64_t S, int32_t* offsets, int32_t* list, void* ws,
+                  u3d_stream_t stream);
+int64_t u3d_csr_build_ws_bytes(int64_t L, int64_t S);
+/* out[j] = map[list[j]]  (int64 map -> int32) : composes the CSR with inverse_mapping / superpoint ids */
+int u3d_gather_i64_to_i32(const int64_t* map, const int32_t* list, int64_t L, int32_t* out, u3d_stream_t stream);
+/* out[s] = out_scale(s) * sum_{j in [offsets[s],offsets[s+1])} src_scale(rows[j]) * src[rows[j]]
+ * mean_mode 1: out_scale = 1/max(len,1) (scatter_mean semantics: empty segment -> 0).
+ * src_inv_count (nullable, int32 [n_src rows' segment sizes]) : src_scale(r) = 1/max(src_inv_count[r+1]-src_inv_count[r],1)
+ * (backward of the mean: rows are superpoints, scaled by their own 1/count). */
+int u3d_segment_gather_sum(const float* src, const int32_t* rows, const int32_t* offsets, int64_t S, int C,
+                           int mean_mode, const int32_t* src_seg_offsets, float* out, u3d_stream_t stream);
+/* centres[s] = mean over the segment's points of (xyz - sub[scene]) ; points row stride pt_ld floats.
+ * sub (nullable) [B, sub_ld] holds the per-scene shift (the voxelizer's stats rows: min xyz), the scene
+ * of a segment is found from its first point via pt_offsets int64 [B+1]. */
+int u3d_segment_mean_xyz(const float* points, int pt_ld, const int32_t* list, const int32_t* offsets, int64_t S,
+                         const float* sub, int sub_ld, const int64_t* pt_offsets, int B, float* out,
+                         u3d_stream_t stream);
+
+/* =====================================================================================
+ * K13  self-attention core of nn.MultiheadAttention(256, 8, batch_first) per scene
+ *     (unidet3d/encoder.py:19-20,36-37): softmax(Q K^T / sqrt(hd)) V over packed variable
+ *     length scenes.  qkv [n_total, 3*H*hd] (the in_proj output), cu_seqlens int32 [B+1],
+ *     out [n_total, H*hd], lse [H, n_total] (log-sum-exp, saved for backward).  hd == 32.
+ * ===================================================================================== */
+int u3d_attn_varlen_fwd(const float* qkv, const int32_t* cu_seqlens, int B, int max_len, int64_t n_total,
+                        int H, int hd, float scale, float* out, float* lse, double flops_hint,
+                        u3d_stream_t stream);
+int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                        const int32_t* cu_seqlens, int B, int max_len, int64_t n_total, int H, int hd,
+                        float scale, float* dqkv, float* delta_ws /*[H,n_total]*/, double flops_hint,
+                        u3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* U3D_H_ */

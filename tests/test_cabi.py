@@ -1,0 +1,58 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads without a GPU, exports every
+symbol include/u3d.h declares, the ctypes table mirrors the header, and the product path refuses
+to run without the HIP kernels (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'u3d.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(u3d_[a-z0-9_]+)\s*\(', src)) - {'u3d_stream_t'})
+
+
+def test_library_exports_every_declared_symbol():
+    from unidet3d_amd.csrc.build import build
+    path = build(verbose=False)
+    lib = ctypes.CDLL(path)
+    names = _header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/u3d.h but not exported'
+    lib.u3d_version.restype = ctypes.c_int
+    assert lib.u3d_version() >= 100
+
+
+def test_ctypes_table_mirrors_header():
+    from unidet3d_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == _header_symbols()
+    src = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'u3d.h')).read(), flags=re.S)
+    for name, (_, args) in _lib.PROTOTYPES.items():
+        m = re.search(r'\b' + name + r'\s*\((.*?)\)\s*;', src, flags=re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(',') if p.strip() and p.strip() != 'void']
+        assert len(params) == len(args), f'{name}: header has {len(params)} params, ctypes table {len(args)}'
+
+
+def test_pure_size_queries_run_without_gpu():
+    from unidet3d_amd import _lib
+    l = _lib.lib()
+    assert l.u3d_index_words(2, 128, 130, 65) == 2 * 128 * 130 * 2
+    assert l.u3d_spconv_tile_rows(32, 32) in (32, 64, 128, 256)
+    assert l.u3d_spconv_tile_rows(24, 32) < 0            # unsupported channel count is refused
+    assert l.u3d_subm_rulebook_ws_bytes(1000) >= 27 * 1000 * 4
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only check')
+def test_no_cpu_fallback():
+    from unidet3d_amd import _lib, ops
+    with pytest.raises(_lib.U3DError):
+        ops.voxelize([torch.rand(10, 6)], 0.02, 128)
+    with pytest.raises(_lib.U3DError):
+        _lib.ptr(torch.zeros(4))

@@ -1,0 +1,231 @@
+"""GPU parity tests, kernel by kernel, through the C ABI against the CPU oracle.
+
+Integer results (voxel coords, inverse map, rulebook pairs) must be bit-exact; floating
+point within 1e-3 relative (BASELINE.json north_star), most checks far tighter.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ops as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def _scene_points(n_scenes, n_points, seed0=0):
+    from unidet3d_amd.synthetic import make_scene
+    return [make_scene(seed0 + i, n_points=n_points) for i in range(n_scenes)]
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ---------------------------------------------------------------------------- R1
+@pytest.mark.parametrize('n_scenes,n_points,vs', [(1, 10_000, 0.05), (3, 30_000, 0.02)])
+def test_voxelize_bit_exact(n_scenes, n_points, vs):
+    from unidet3d_amd import ops
+    scenes = _scene_points(n_scenes, n_points)
+    pts_cpu = [torch.from_numpy(s.points) for s in scenes]
+    oc, of, oinv, oshape = so.voxelize(pts_cpu, vs, 128)
+    vb = ops.voxelize([p.to(_dev()) for p in pts_cpu], vs, 128)
+    assert vb.spatial_shape == [int(s) for s in oshape]
+    assert torch.equal(vb.coords.cpu(), oc)                      # canonical order, bit exact
+    assert torch.equal(vb.inverse.cpu(), oinv)
+    assert _rel(vb.feats, of) < 1e-5
+    # CSR of points per voxel is consistent with the inverse map
+    offs = vb.vox_offsets.cpu().long(); lst = vb.vox_points.cpu().long()
+    assert int(offs[-1]) == sum(len(p) for p in pts_cpu)
+    rows = torch.repeat_interleave(torch.arange(len(oc)), offs[1:] - offs[:-1])
+    assert torch.equal(oinv[lst], rows)
+
+
+def test_voxelize_ragged_and_tiny():
+    from unidet3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    pts_cpu = [torch.rand(1, 6, generator=g), torch.rand(777, 6, generator=g) * 3, torch.rand(5, 6, generator=g)]
+    oc, of, oinv, oshape = so.voxelize(pts_cpu, 0.05, 16)
+    vb = ops.voxelize([p.to(_dev()) for p in pts_cpu], 0.05, 16)
+    assert torch.equal(vb.coords.cpu(), oc) and torch.equal(vb.inverse.cpu(), oinv)
+    assert vb.spatial_shape == [int(s) for s in oshape]
+    assert _rel(vb.feats, of) < 1e-5
+
+
+# ---------------------------------------------------------------------------- R2 / R3
+def _check_pairs(gpu_lists, oracle_lists):
+    assert len(gpu_lists) == len(oracle_lists)
+    for k, ((gi, go), (oi, oo)) in enumerate(zip(gpu_lists, oracle_lists)):
+        assert np.array_equal(gi, oi) and np.array_equal(go, oo), f'offset {k} differs'
+
+
+@pytest.mark.parametrize('n_points,vs', [(10_000, 0.05), (60_000, 0.02)])
+def test_rulebooks_bit_exact_all_levels(n_points, vs):
+    from unidet3d_amd import ops, sparse
+    scenes = _scene_points(2, n_points, seed0=7)
+    pts_cpu = [torch.from_numpy(s.points) for s in scenes]
+    oc, _, _, oshape = so.voxelize(pts_cpu, vs, 128)
+    vb = ops.voxelize([p.to(_dev()) for p in pts_cpu], vs, 128)
+    coords, shape, index = vb.coords, vb.spatial_shape, vb.index
+    for level in range(5):
+        rb = sparse.build_subm_rulebook(coords, index)
+        _check_pairs(rb.lists(), so.build_subm_rulebook(oc, oshape))
+        if level == 4:
+            break
+        oc2, oshape2, opairs = so.build_down_rulebook(oc, oshape)
+        c2, shape2, ix2, rb2 = sparse.build_down_rulebook(coords, 2, shape)
+        assert torch.equal(c2.cpu(), oc2) and shape2 == [int(s) for s in oshape2]
+        _check_pairs(rb2.lists(), opairs)
+        coords, shape, index, oc, oshape = c2, shape2, ix2, oc2, oshape2
+
+
+def test_index_from_raw_coords_matches_voxelizer_index():
+    from unidet3d_amd import ops, sparse
+    scenes = _scene_points(1, 8000, seed0=11)
+    vb = ops.voxelize([torch.from_numpy(scenes[0].points).to(_dev())], 0.05, 128)
+    ix = sparse.OccupancyIndex.from_coords(vb.coords, 1, vb.spatial_shape)
+    assert torch.equal(ix.bitmap, vb.index.bitmap) and torch.equal(ix.rank, vb.index.rank)
+
+
+# ---------------------------------------------------------------------------- K4-K8
+CONV_SHAPES = [(16, 32), (32, 32), (64, 32), (64, 64), (128, 64), (96, 96), (192, 96), (128, 128), (256, 128), (160, 160)]
+
+
+def _level_geometry(n_points=12_000, vs=0.05):
+    from unidet3d_amd import ops, sparse
+    scenes = _scene_points(2, n_points, seed0=21)
+    pts_cpu = [torch.from_numpy(s.points) for s in scenes]
+    oc, _, _, oshape = so.voxelize(pts_cpu, vs, 128)
+    vb = ops.voxelize([p.to(_dev()) for p in pts_cpu], vs, 128)
+    return vb, oc, oshape
+
+
+@pytest.mark.parametrize('cin,cout', CONV_SHAPES)
+def test_subm_conv_fwd_bwd(cin, cout):
+    from unidet3d_amd import sparse
+    vb, oc, oshape = _level_geometry()
+    n = len(oc)
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1
+    add = torch.randn(n, cout, generator=g)
+    go = torch.randn(n, cout, generator=g)
+    xo, wo, ao = x.clone().requires_grad_(), w.clone().requires_grad_(), add.clone().requires_grad_()
+    pairs = so.build_subm_rulebook(oc, oshape)
+    yo = so.sparse_conv(xo, wo, pairs, n) + ao
+    yo.backward(go)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    xg, wg, ag = [t.clone().to(_dev()).requires_grad_() for t in (x, w, add)]
+    if cin == 16:
+        xg = xg.detach()       # the (zero-padded) network input needs no gradient: dgrad 32->16 is not built
+    yg = sparse.sparse_conv(xg, wg, rb, 'fwd', ag)
+    yg.backward(go.to(_dev()))
+    assert _rel(yg, yo) < 1e-4
+    if cin != 16:
+        assert _rel(xg.grad, xo.grad) < 1e-4
+    assert _rel(wg.grad, wo.grad) < 1e-4
+    assert _rel(ag.grad, ao.grad) < 1e-6
+
+
+@pytest.mark.parametrize('cin,cout', [(32, 64), (64, 96), (96, 128), (128, 160)])
+def test_strided_and_inverse_conv_fwd_bwd(cin, cout):
+    from unidet3d_amd import sparse
+    vb, oc, oshape = _level_geometry()
+    n = len(oc)
+    oc2, oshape2, pairs = so.build_down_rulebook(oc, oshape)
+    c2, shape2, ix2, rb = sparse.build_down_rulebook(vb.coords, 2, vb.spatial_shape)
+    n2 = len(oc2)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, generator=g); w = torch.randn(cout, 2, 2, 2, cin, generator=g) * 0.1
+    go = torch.randn(n2, cout, generator=g)
+    xo, wo = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yo = so.sparse_conv(xo, wo, pairs, n2); yo.backward(go)
+    xg, wg = x.clone().to(_dev()).requires_grad_(), w.clone().to(_dev()).requires_grad_()
+    yg = sparse.sparse_conv(xg, wg, rb, 'fwd'); yg.backward(go.to(_dev()))
+    assert _rel(yg, yo) < 1e-4 and _rel(xg.grad, xo.grad) < 1e-4 and _rel(wg.grad, wo.grad) < 1e-4
+    # inverse conv: cout -> cin on the saved pairs
+    wi = torch.randn(cin, 2, 2, 2, cout, generator=g) * 0.1
+    z = torch.randn(n2, cout, generator=g); gz = torch.randn(n, cin, generator=g)
+    zo, wio = z.clone().requires_grad_(), wi.clone().requires_grad_()
+    uo = so.sparse_conv(zo, wio, pairs, n, inverse=True); uo.backward(gz)
+    zg, wig = z.clone().to(_dev()).requires_grad_(), wi.clone().to(_dev()).requires_grad_()
+    ug = sparse.sparse_conv(zg, wig, rb, 'inv'); ug.backward(gz.to(_dev()))
+    assert _rel(ug, uo) < 1e-4 and _rel(zg.grad, zo.grad) < 1e-4 and _rel(wig.grad, wio.grad) < 1e-4
+
+
+def test_conv_linearity_full_size():
+    """Size-independent property at BASELINE cfg2 scale (one 100k-pt scene, 2 cm):
+    conv(a*x + b*y) == a*conv(x) + b*conv(y), and an all-ones centre-tap kernel is the identity."""
+    from unidet3d_amd import ops, sparse
+    scenes = _scene_points(1, 100_000, seed0=5)
+    vb = ops.voxelize([torch.from_numpy(scenes[0].points).to(_dev())], 0.02, 128)
+    n = vb.coords.shape[0]
+    assert 25_000 < n < 60_000
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    x = torch.randn(n, 32, device=_dev()); y = torch.randn(n, 32, device=_dev())
+    w = torch.randn(32, 3, 3, 3, 32, device=_dev()) * 0.1
+    lhs = sparse.sparse_conv(2.0 * x - 3.0 * y, w, rb)
+    rhs = 2.0 * sparse.sparse_conv(x, w, rb) - 3.0 * sparse.sparse_conv(y, w, rb)
+    assert _rel(lhs, rhs) < 1e-5
+    wid = torch.zeros(32, 27, 32, device=_dev()); wid[:, 13, :] = torch.eye(32, device=_dev())
+    assert torch.equal(sparse.sparse_conv(x, wid.view(32, 3, 3, 3, 32), rb), x)
+    cnt = rb.counts.cpu()
+    assert int(cnt[13]) == n and torch.equal(cnt, cnt.flip(0))       # centre tap hits every voxel; symmetric offsets
+
+
+# ---------------------------------------------------------------------------- K9
+@pytest.mark.parametrize('C', [32, 96, 160, 256])
+@pytest.mark.parametrize('relu', [True, False])
+def test_batchnorm_relu_fwd_bwd(C, relu):
+    from unidet3d_amd import sparse
+    n = 5003
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n, C, generator=g) * 2 + 0.5
+    go = torch.randn(n, C, generator=g)
+    bn_o = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1)
+    bn_o.weight.data = torch.rand(C, generator=g) + 0.5; bn_o.bias.data = torch.randn(C, generator=g) * 0.1
+    bn_g = sparse.SparseBatchNorm(C).to(_dev())
+    bn_g.load_state_dict(bn_o.state_dict())
+    xo = x.clone().requires_grad_()
+    yo = bn_o(xo); yo = torch.relu(yo) if relu else yo
+    yo.backward(go)
+    xg = x.clone().to(_dev()).requires_grad_()
+    yg = bn_g(xg, relu=relu); yg.backward(go.to(_dev()))
+    assert _rel(yg, yo) < 1e-5 and _rel(xg.grad, xo.grad) < 1e-4
+    assert _rel(bn_g.weight.grad, bn_o.weight.grad) < 1e-4 and _rel(bn_g.bias.grad, bn_o.bias.grad) < 1e-4
+    assert _rel(bn_g.running_mean, bn_o.running_mean) < 1e-5 and _rel(bn_g.running_var, bn_o.running_var) < 1e-5
+    bn_o.eval(); bn_g.eval()
+    with torch.no_grad():
+        ye = bn_o(x); ye = torch.relu(ye) if relu else ye
+        assert _rel(bn_g(x.to(_dev()), relu=relu), ye) < 1e-5
+
+
+# ---------------------------------------------------------------------------- K11 / K12
+def test_superpoint_pool_and_centers():
+    from unidet3d_amd import ops
+    scenes = _scene_points(3, 20_000, seed0=31)
+    pts_cpu = [torch.from_numpy(s.points) for s in scenes]
+    sps, bias = [], 0
+    for s in scenes:
+        sp = torch.from_numpy(s.superpoints) + bias
+        bias = int(sp.max()) + 1
+        sps.append(sp)
+    sp_all = torch.cat(sps)
+    oc, of, oinv, oshape = so.voxelize(pts_cpu, 0.02, 128)
+    vb = ops.voxelize([p.to(_dev()) for p in pts_cpu], 0.02, 128)
+    plan = ops.PoolPlan(vb, sp_all.to(_dev()), bias)
+    g = torch.Generator().manual_seed(1)
+    f = torch.randn(len(oc), 32, generator=g); go = torch.randn(bias, 32, generator=g)
+    fo = f.clone().requires_grad_()
+    po = so.scatter_mean(fo[oinv], sp_all, dim_size=bias); po.backward(go)
+    fg = f.clone().to(_dev()).requires_grad_()
+    pg = ops.superpoint_pool(fg, plan); pg.backward(go.to(_dev()))
+    assert _rel(pg, po) < 1e-5 and _rel(fg.grad, fo.grad) < 1e-5
+    cen_o = torch.cat([so.scatter_mean(p[:, :3] - p[:, :3].min(0)[0], torch.from_numpy(s.superpoints))
+                       for p, s in zip(pts_cpu, scenes)])
+    cen_g = ops.superpoint_centers(vb.points, plan.sp_offsets, plan.sp_points, bias, vb.stats, vb.pt_offsets)
+    assert _rel(cen_g, cen_o) < 1e-5

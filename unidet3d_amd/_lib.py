@@ -1,0 +1,117 @@
+"""ctypes binding of the C-ABI kernel library (include/u3d.h).
+
+The product path has NO fallback: if ``libu3d_hip.so`` is missing or a kernel
+returns an error, an exception is raised -- nothing here routes to PyTorch
+ops or to the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libu3d_hip.so')
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> (restype, argtypes)   (mirrors include/u3d.h, checked by tests/test_cabi.py)
+PROTOTYPES = {
+    'u3d_version': (_i32, []),
+    'u3d_last_error': (C.c_char_p, []),
+    'u3d_prof_enable': (_i32, [_i32, _i32]),
+    'u3d_prof_collect': (_i32, [_i32, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64)]),
+    'u3d_vox_scene_stats': (_i32, [_vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp, _vp, _vp]),
+    'u3d_vox_scene_stats_ws_bytes': (_i64, [_i32]),
+    'u3d_index_words': (_i64, [_i32, _i32, _i32, _i32]),
+    'u3d_vox_mark': (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _f32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'u3d_index_rank': (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    'u3d_index_rank_ws_bytes': (_i64, [_i64]),
+    'u3d_index_coords': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'u3d_vox_finalize': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'u3d_vox_finalize_ws_bytes': (_i64, [_i64, _i64]),
+    'u3d_subm_rulebook': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_subm_rulebook_ws_bytes': (_i64, [_i64]),
+    'u3d_index_mark': (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'u3d_down_rulebook': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_down_rulebook_ws_bytes': (_i64, [_i64]),
+    'u3d_tile_starts': (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp]),
+    'u3d_spconv_gmm': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _vp, _vp, _f64, _vp]),
+    'u3d_spconv_tile_rows': (_i32, [_i32, _i32]),
+    'u3d_spconv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _f64, _vp]),
+    'u3d_weight_transpose': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'u3d_bn_finalize': (_i32, [_vp, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_apply': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    'u3d_bn_bwd_stats': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    'u3d_bn_bwd_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'u3d_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    'u3d_csr_build_ws_bytes': (_i64, [_i64, _i64]),
+    'u3d_gather_i64_to_i32': (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    'u3d_segment_gather_sum': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'u3d_segment_mean_xyz': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
+    'u3d_attn_varlen_fwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
+    'u3d_attn_varlen_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
+}
+
+K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE = range(8)
+
+_lib = None
+
+
+class U3DError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the kernel library (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise U3DError(f'{LIB_PATH} not found: build it with `python -m unidet3d_amd.csrc.build` '
+                           '(hipcc --offload-arch=gfx950); there is no fallback path')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point; raise on any non-zero code."""
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise U3DError(f'{name} failed with code {rc}: {l.u3d_last_error().decode()}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Tensors must be contiguous CUDA tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise U3DError('u3d kernels need CUDA (HIP) tensors: the product path has no CPU fallback')
+    if not t.is_contiguous():
+        raise U3DError('non-contiguous tensor passed to a u3d kernel')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def prof_enable(cls: int, on: bool):
+    call('u3d_prof_enable', cls, 1 if on else 0)
+
+
+def prof_collect(cls: int):
+    ms, n, w = _f64(), _i64(), _f64()
+    call('u3d_prof_collect', cls, C.byref(ms), C.byref(n), C.byref(w))
+    return ms.value, n.value, w.value

@@ -1,0 +1,210 @@
+// K9 BatchNorm(+ReLU) over voxel rows, training mode, on gfx950.  HBM-bound: every pass streams
+// [n, C] fp32 with 16-byte coalesced loads; statistics are accumulated in fp64 so that
+// var = E[x^2] - mean^2 is as accurate as torch's two-pass kernel, and so that the per-rank partial
+// sums can be all-reduced across data-parallel ranks (SyncBatchNorm) between stats and apply.
+// Replaces nn.SyncBatchNorm / nn.BatchNorm1d(eps=1e-4, momentum=0.1) + nn.ReLU at
+// unidet3d/spconv_unet.py:42,49,119-124,147,177 and unidet3d/unidet3d.py:104-111.
+#include "u3d_common.h"
+
+namespace u3d {
+
+// mode 0: sums = [sum x, sum x^2]; mode 1: backward sums [sum dy', sum dy'*xhat]
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                   int64_t n, int C, double* sums) {
+    __shared__ double sh[256 * 8];
+    const int lpr = C >> 2;
+    const int rpb = 256 / lpr;
+    const int tid = threadIdx.x;
+    const int c4 = tid % lpr, slot = tid / lpr;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (slot < rpb) {
+        float4 mu = make_float4(0, 0, 0, 0), is = mu, sc = mu, sf = mu;
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const float4*>(mean + c4 * 4);
+            is = *reinterpret_cast<const float4*>(invstd + c4 * 4);
+            sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
+            sf = *reinterpret_cast<const float4*>(shift + c4 * 4);
+        }
+        for (int64_t r = (int64_t)blockIdx.x * rpb + slot; r < n; r += (int64_t)gridDim.x * rpb) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * C + c4 * 4);
+            if (MODE == 0) {
+                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+                b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
+            } else {
+                float4 g = *reinterpret_cast<const float4*>(dy + r * C + c4 * 4);
+                if (relu) {
+                    if (!(v.x * sc.x + sf.x > 0.f)) g.x = 0.f;
+                    if (!(v.y * sc.y + sf.y > 0.f)) g.y = 0.f;
+                    if (!(v.z * sc.z + sf.z > 0.f)) g.z = 0.f;
+                    if (!(v.w * sc.w + sf.w > 0.f)) g.w = 0.f;
+                }
+                a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+                b[0] += (double)g.x * ((v.x - mu.x) * is.x); b[1] += (double)g.y * ((v.y - mu.y) * is.y);
+                b[2] += (double)g.z * ((v.z - mu.z) * is.z); b[3] += (double)g.w * ((v.w - mu.w) * is.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[tid * 8 + j] = a[j]; sh[tid * 8 + 4 + j] = b[j]; }
+    __syncthreads();
+    if (tid < lpr) {
+        double ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
+        for (int s = 0; s < rpb; ++s) {
+            const int o = (s * lpr + tid) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ta[j] += sh[o + j]; tb[j] += sh[o + 4 + j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&sums[tid * 4 + j], ta[j]);
+            atomicAdd(&sums[C + tid * 4 + j], tb[j]);
+        }
+    }
+}
+
+__global__ void bn_finalize_k(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                              float* running_var, int C, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float mf = (float)m;
+    mean[c] = mf;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mf * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, int relu, int64_t n4, int C4, float* y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
+        const float4 sf = reinterpret_cast<const float4*>(shift)[c4];
+        float4 o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                      const double* __restrict__ sums, double inv_count, int64_t n4, int C,
+                                                      float* dx, float* dgamma, float* dbeta) {
+    const int C4 = C >> 2;
+    if (blockIdx.x == 0 && dgamma) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dbeta[c] = (float)sums[c];
+            dgamma[c] = (float)sums[C + c];
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        const float4 mu = reinterpret_cast<const float4*>(mean)[c4];
+        const float4 is = reinterpret_cast<const float4*>(invstd)[c4];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
+        const float4 sf = reinterpret_cast<const float4*>(shift)[c4];
+        if (relu) {
+            if (!(v.x * sc.x + sf.x > 0.f)) g.x = 0.f;
+            if (!(v.y * sc.y + sf.y > 0.f)) g.y = 0.f;
+            if (!(v.z * sc.z + sf.z > 0.f)) g.z = 0.f;
+            if (!(v.w * sc.w + sf.w > 0.f)) g.w = 0.f;
+        }
+        const int c = c4 * 4;
+        const float m1x = (float)(sums[c] * inv_count), m1y = (float)(sums[c + 1] * inv_count);
+        const float m1z = (float)(sums[c + 2] * inv_count), m1w = (float)(sums[c + 3] * inv_count);
+        const float m2x = (float)(sums[C + c] * inv_count), m2y = (float)(sums[C + c + 1] * inv_count);
+        const float m2z = (float)(sums[C + c + 2] * inv_count), m2w = (float)(sums[C + c + 3] * inv_count);
+        float4 o;
+        o.x = sc.x * (g.x - m1x - (v.x - mu.x) * is.x * m2x);
+        o.y = sc.y * (g.y - m1y - (v.y - mu.y) * is.y * m2y);
+        o.z = sc.z * (g.z - m1z - (v.z - mu.z) * is.z * m2z);
+        o.w = sc.w * (g.w - m1w - (v.w - mu.w) * is.w * m2w);
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+static bool bn_ok(int64_t n, int C) { return n > 0 && C >= 4 && C <= 256 && C % 4 == 0; }
+static unsigned ew_grid(int64_t n4) {
+    int64_t g = ceil_div(n4, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace u3d
+
+using namespace u3d;
+
+extern "C" {
+
+int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, u3d_stream_t stream) {
+    if (!x || !sums || !bn_ok(n, C)) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
+    const int rpb = 256 / (C / 4);
+    int64_t g = ceil_div(n, (int64_t)rpb * 8);
+    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    hipLaunchKernelGGL(bn_reduce_k<0>, dim3((unsigned)g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, sums);
+    return check_launch("bn_stats");
+}
+
+int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int C, float* mean, float* invstd, float* scale,
+                    float* shift, u3d_stream_t stream) {
+    if (!sums || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0) return U3D_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_k, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, gamma, beta, eps,
+                       momentum, running_mean, running_var, C, mean, invstd, scale, shift);
+    return check_launch("bn_finalize");
+}
+
+int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y,
+                 u3d_stream_t stream) {
+    if (!x || !scale || !shift || !y || !bn_ok(n, C)) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
+    const int64_t n4 = n * (C / 4);
+    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, scale, shift, relu, n4, C / 4, y);
+    return check_launch("bn_apply");
+}
+
+int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
+                     const float* shift, int relu, int64_t n, int C, double* sums, u3d_stream_t stream) {
+    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !bn_ok(n, C)) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
+    const int rpb = 256 / (C / 4);
+    int64_t g = ceil_div(n, (int64_t)rpb * 8);
+    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    hipLaunchKernelGGL(bn_reduce_k<1>, dim3((unsigned)g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, sums);
+    return check_launch("bn_bwd_stats");
+}
+
+int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
+                     const float* shift, int relu, const double* sums, double count, int64_t n, int C, float* dx,
+                     float* dgamma, float* dbeta, u3d_stream_t stream) {
+    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !dx || !bn_ok(n, C) || count <= 0) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
+    const int64_t n4 = n * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, sums,
+                       1.0 / count, n4, C, dx, dgamma, dbeta);
+    return check_launch("bn_bwd_apply");
+}
+
+}  // extern "C"

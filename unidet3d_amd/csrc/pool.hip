@@ -1,0 +1,169 @@
+// K11 / K12 superpoint pooling on gfx950.  Replaces
+//   scatter_mean(x.features[inverse_mapping], superpoints, dim=0)      unidet3d/unidet3d.py:130
+//   scatter_mean(points, sp_pts_mask, dim=0)                            unidet3d/unidet3d.py:332-333,446-447
+// Instead of materialising the [n_points, 32] gather (102 MB at cfg2) and scattering it back with
+// float atomics, a CSR of point ids per segment is built once per batch (integer atomics only) and
+// each segment is reduced by one wave (or one 8-lane group) with coalesced 128-byte row reads.
+// The same kernel with the CSR of points per voxel gives the backward pass.
+#include "u3d_common.h"
+
+namespace u3d {
+
+__global__ __launch_bounds__(256) void seg_count_k(const int64_t* __restrict__ seg, int64_t L, int32_t* cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) atomicAdd(&cnt[seg[i]], 1);
+}
+__global__ __launch_bounds__(256) void seg_fill_k(const int64_t* __restrict__ seg, const int32_t* __restrict__ offsets, int64_t L,
+                                                  int32_t* cursor, int32_t* list) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const int64_t s = seg[i];
+    list[offsets[s] + atomicAdd(&cursor[s], 1)] = (int)i;
+}
+__global__ __launch_bounds__(256) void gather_i64_i32_k(const int64_t* __restrict__ map, const int32_t* __restrict__ list, int64_t L,
+                                                        int32_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) out[i] = (int)map[list[i]];
+}
+
+// LPR = lanes per row (C/4, power of two); WAVE_PER_SEG: 64/LPR rows in flight per segment, else one
+// LPR-lane group per segment.
+template <int LPR, bool WAVE_PER_SEG>
+__global__ __launch_bounds__(256) void seg_gather_sum_k(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                        const int32_t* __restrict__ offsets, int64_t S, int mean_mode,
+                                                        const int32_t* __restrict__ src_seg, float* out) {
+    constexpr int C = LPR * 4;
+    constexpr int SLOTS = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int c4 = lane % LPR, slot = lane / LPR;
+    int64_t s;
+    int step, first;
+    if (WAVE_PER_SEG) { s = wave_id; step = SLOTS; first = slot; }
+    else { s = wave_id * SLOTS + slot; step = 1; first = 0; }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int lo = 0, hi = 0;
+    if (s < S) { lo = offsets[s]; hi = offsets[s + 1]; }
+    for (int j = lo + first; j < hi; j += step) {
+        const int r = rows[j];
+        float4 v = *reinterpret_cast<const float4*>(src + (int64_t)r * C + c4 * 4);
+        if (src_seg) {
+            const int n = src_seg[r + 1] - src_seg[r];
+            const float sc = 1.0f / (float)(n > 1 ? n : 1);
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (WAVE_PER_SEG) {
+#pragma unroll
+        for (int d = LPR; d < 64; d <<= 1) {
+            acc.x += __shfl_xor(acc.x, d, 64); acc.y += __shfl_xor(acc.y, d, 64);
+            acc.z += __shfl_xor(acc.z, d, 64); acc.w += __shfl_xor(acc.w, d, 64);
+        }
+    }
+    if (s < S && (!WAVE_PER_SEG || slot == 0)) {
+        if (mean_mode) {
+            const int n = hi - lo;
+            const float sc = 1.0f / (float)(n > 1 ? n : 1);
+            acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+        }
+        *reinterpret_cast<float4*>(out + s * C + c4 * 4) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_mean_xyz_k(const float* __restrict__ points, int ld, const int32_t* __restrict__ list,
+                                                      const int32_t* __restrict__ offsets, int64_t S, const float* __restrict__ sub,
+                                                      int sub_ld, const int64_t* __restrict__ pt_offsets, int B, float* out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int lo = offsets[s], hi = offsets[s + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (sub && lo < hi) {
+        int b = 0;
+        const int64_t p0 = list[lo];
+        while (b + 1 < B && pt_offsets[b + 1] <= p0) ++b;
+        sx = sub[b * sub_ld]; sy = sub[b * sub_ld + 1]; sz = sub[b * sub_ld + 2];
+    }
+    double a = 0, b = 0, c = 0;
+    for (int j = lo; j < hi; ++j) {
+        const float* q = points + (int64_t)list[j] * ld;
+        a += q[0] - sx; b += q[1] - sy; c += q[2] - sz;
+    }
+    const double inv = 1.0 / (double)(hi - lo > 1 ? hi - lo : 1);
+    out[s * 3 + 0] = (float)(a * inv);
+    out[s * 3 + 1] = (float)(b * inv);
+    out[s * 3 + 2] = (float)(c * inv);
+}
+
+template <int LPR>
+static int launch_seg(const float* src, const int32_t* rows, const int32_t* offsets, int64_t S, int mean_mode,
+                      const int32_t* src_seg, float* out, bool wave_per_seg, hipStream_t s) {
+    if (wave_per_seg) {
+        hipLaunchKernelGGL((seg_gather_sum_k<LPR, true>), dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, s, src, rows, offsets, S,
+                           mean_mode, src_seg, out);
+    } else {
+        constexpr int SLOTS = 64 / LPR;
+        hipLaunchKernelGGL((seg_gather_sum_k<LPR, false>), dim3((unsigned)ceil_div(S, 4 * SLOTS)), dim3(256), 0, s, src, rows,
+                           offsets, S, mean_mode, src_seg, out);
+    }
+    return check_launch("segment_gather_sum");
+}
+
+}  // namespace u3d
+
+using namespace u3d;
+
+extern "C" {
+
+int64_t u3d_csr_build_ws_bytes(int64_t L, int64_t S) { return (S + 1) * 8 + 256 + scan_ws_bytes(S); }
+
+int u3d_csr_build(const int64_t* seg_ids, int64_t L, int64_t S, int32_t* offsets, int32_t* list, void* ws,
+                  u3d_stream_t stream) {
+    if (!seg_ids || !offsets || !list || !ws || L <= 0 || S <= 0) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_POOL, s, 0.0);
+    int32_t* cnt = (int32_t*)ws;
+    int32_t* cursor = cnt + (S + 1);
+    void* sws = (void*)(((uintptr_t)(cursor + S + 1) + 63) & ~(uintptr_t)63);
+    hipMemsetAsync(cnt, 0, (size_t)(2 * (S + 1)) * 4, s);
+    const unsigned g = (unsigned)ceil_div(L, 256);
+    hipLaunchKernelGGL(seg_count_k, dim3(g), dim3(256), 0, s, seg_ids, L, cnt);
+    int rc = exclusive_scan_i32(cnt, S, offsets, sws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(seg_fill_k, dim3(g), dim3(256), 0, s, seg_ids, (const int32_t*)offsets, L, cursor, list);
+    return check_launch("csr_build");
+}
+
+int u3d_gather_i64_to_i32(const int64_t* map, const int32_t* list, int64_t L, int32_t* out, u3d_stream_t stream) {
+    if (!map || !list || !out || L <= 0) return U3D_EINVAL;
+    hipLaunchKernelGGL(gather_i64_i32_k, dim3((unsigned)ceil_div(L, 256)), dim3(256), 0, (hipStream_t)stream, map, list, L, out);
+    return check_launch("gather_i64_to_i32");
+}
+
+int u3d_segment_gather_sum(const float* src, const int32_t* rows, const int32_t* offsets, int64_t S, int C, int mean_mode,
+                           const int32_t* src_seg_offsets, float* out, u3d_stream_t stream) {
+    if (!src || !rows || !offsets || !out || S <= 0) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_POOL, s, 0.0);
+    // segments of the forward pass (points per superpoint) are long, those of the backward pass
+    // (points per voxel) hold a handful of rows: mean_mode picks the decomposition.
+    const bool wave_per_seg = mean_mode != 0;
+    switch (C) {
+        case 16: return launch_seg<4>(src, rows, offsets, S, mean_mode, src_seg_offsets, out, wave_per_seg, s);
+        case 32: return launch_seg<8>(src, rows, offsets, S, mean_mode, src_seg_offsets, out, wave_per_seg, s);
+        case 64: return launch_seg<16>(src, rows, offsets, S, mean_mode, src_seg_offsets, out, wave_per_seg, s);
+        case 128: return launch_seg<32>(src, rows, offsets, S, mean_mode, src_seg_offsets, out, wave_per_seg, s);
+        case 256: return launch_seg<64>(src, rows, offsets, S, mean_mode, src_seg_offsets, out, wave_per_seg, s);
+        default: set_error("segment_gather_sum: C=%d unsupported", C); return U3D_EUNSUPPORTED;
+    }
+}
+
+int u3d_segment_mean_xyz(const float* points, int pt_ld, const int32_t* list, const int32_t* offsets, int64_t S,
+                         const float* sub, int sub_ld, const int64_t* pt_offsets, int B, float* out, u3d_stream_t stream) {
+    if (!points || !list || !offsets || !out || S <= 0 || pt_ld < 3 || (sub && (!pt_offsets || B <= 0 || sub_ld < 3))) return U3D_EINVAL;
+    hipLaunchKernelGGL(seg_mean_xyz_k, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, (hipStream_t)stream, points, pt_ld, list,
+                       offsets, S, sub, sub_ld, pt_offsets, B, out);
+    return check_launch("segment_mean_xyz");
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Internal helpers shared by the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "u3d.h"
+
+namespace u3d {
+
+void set_error(const char* fmt, ...);
+
+// ---- per-class kernel timing with HIP events on the launch stream --------------------
+struct ProfScope {
+    int cls;
+    hipStream_t stream;
+    bool on;
+    hipEvent_t e0, e1;
+    double work;
+    ProfScope(int cls, hipStream_t s, double work);
+    ~ProfScope();
+};
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return U3D_ELAUNCH;
+    }
+    return U3D_OK;
+}
+
+__host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// exclusive scan of n int32 values produced by a functor; out has n+1 entries (out[n] = total)
+int exclusive_scan_popc64(const uint64_t* words, int64_t n, int32_t* out, void* ws, hipStream_t s);
+int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hipStream_t s);
+int64_t scan_ws_bytes(int64_t n);
+
+// ---- occupancy index (bitmap + popcount rank) ------------------------------------------
+struct Index {
+    const uint64_t* bitmap;
+    const int32_t* rank;
+    int B, X, Y, Z, Zw;
+};
+
+__device__ __forceinline__ int index_lookup(const Index& ix, int b, int x, int y, int z) {
+    if ((unsigned)x >= (unsigned)ix.X || (unsigned)y >= (unsigned)ix.Y || (unsigned)z >= (unsigned)ix.Z) return -1;
+    const int64_t w = ((int64_t)(b * ix.X + x) * ix.Y + y) * ix.Zw + (z >> 6);
+    const uint64_t word = ix.bitmap[w];
+    const int bit = z & 63;
+    if (!((word >> bit) & 1ull)) return -1;
+    return ix.rank[w] + __popcll(word & ((1ull << bit) - 1ull));
+}
+
+}  // namespace u3d

@@ -1,0 +1,137 @@
+"""Voxelisation and superpoint pooling through the C ABI (host side).
+
+``voxelize``     replaces ME.utils.batch_sparse_collate + ME.TensorField(...).sparse()
+                 + inverse_mapping                       (unidet3d/unidet3d.py:158-174)
+``PoolPlan`` / ``superpoint_pool``   replace  scatter_mean(x.features[inverse_mapping], superpoints)
+                                                          (unidet3d/unidet3d.py:130)
+``superpoint_centers``               replaces scatter_mean(points, sp_pts_mask)   (:332-333, :446-447)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+from .sparse import OccupancyIndex
+
+
+@dataclass
+class VoxelBatch:
+    coords: torch.Tensor          # int32 [Nv, 4]  (b, x, y, z), canonical order
+    feats: torch.Tensor           # f32   [Nv, 6]
+    inverse: torch.Tensor         # int64 [Np]     point -> voxel row
+    spatial_shape: List[int]
+    index: OccupancyIndex
+    vox_offsets: torch.Tensor     # int32 [Nv+1]   CSR of points per voxel
+    vox_points: torch.Tensor      # int32 [Np]
+    pt_offsets: torch.Tensor      # int64 [B+1] (device)
+    stats: torch.Tensor           # f32 [B, 12] min, max, mean_xyz, pad
+    points: torch.Tensor          # f32 [Np, 6] concatenated
+
+
+def voxelize(points: List[torch.Tensor], voxel_size: float, min_spatial_shape: int,
+             elastic_points: Optional[List[torch.Tensor]] = None, div_mode: int = 0) -> VoxelBatch:
+    dev = points[0].device
+    B = len(points)
+    sizes = [int(p.shape[0]) for p in points]
+    pts = torch.cat([p.to(torch.float32) for p in points]).contiguous() if B > 1 else points[0].to(torch.float32).contiguous()
+    n_pts = pts.shape[0]
+    offs_h = [0]
+    for s in sizes:
+        offs_h.append(offs_h[-1] + s)
+    offs = torch.tensor(offs_h, dtype=torch.int64, device=dev)
+    csrc = None
+    vs = float(voxel_size)
+    if elastic_points is not None:
+        csrc = torch.cat([e.to(torch.float32) for e in elastic_points]).contiguous()
+        vs = 1.0
+    stats = torch.empty(B, 12, dtype=torch.float32, device=dev)
+    gmax = torch.empty(3, dtype=torch.int32, device=dev)
+    w = L.ws(L.lib().u3d_vox_scene_stats_ws_bytes(B), dev)
+    L.call('u3d_vox_scene_stats', L.ptr(pts), L.ptr(csrc), L.ptr(offs), B, max(sizes), vs, div_mode,
+           L.ptr(stats), L.ptr(gmax), L.ptr(w), L.stream())
+    shape = [max(int(v) + 1, int(min_spatial_shape)) for v in gmax.tolist()]       # read-back #1
+    index = OccupancyIndex.alloc(B, shape, dev)
+    pt_cell = torch.empty(n_pts, dtype=torch.int64, device=dev)
+    L.call('u3d_vox_mark', L.ptr(pts), L.ptr(csrc), L.ptr(offs), B, max(sizes), L.ptr(stats), vs, div_mode,
+           *shape, L.ptr(index.bitmap), L.ptr(pt_cell), L.stream())
+    index.build_rank()
+    n_vox = index.count()                                                          # read-back #2
+    coords = index.coords(n_vox)
+    inverse = torch.empty(n_pts, dtype=torch.int64, device=dev)
+    vox_offsets = torch.empty(n_vox + 1, dtype=torch.int32, device=dev)
+    vox_points = torch.empty(n_pts, dtype=torch.int32, device=dev)
+    feats = torch.empty(n_vox, 6, dtype=torch.float32, device=dev)
+    w2 = L.ws(L.lib().u3d_vox_finalize_ws_bytes(n_pts, n_vox), dev)
+    L.call('u3d_vox_finalize', L.ptr(pts), L.ptr(offs), B, n_pts, L.ptr(stats), L.ptr(pt_cell), L.ptr(index.bitmap),
+           L.ptr(index.rank), n_vox, L.ptr(inverse), L.ptr(vox_offsets), L.ptr(vox_points), L.ptr(feats), 6,
+           L.ptr(w2), L.stream())
+    return VoxelBatch(coords, feats, inverse, shape, index, vox_offsets, vox_points, offs, stats, pts)
+
+
+def csr_build(seg_ids: torch.Tensor, S: int):
+    """offsets int32 [S+1], list int32 [L] of element ids grouped by segment."""
+    Ln = seg_ids.shape[0]
+    dev = seg_ids.device
+    offsets = torch.empty(S + 1, dtype=torch.int32, device=dev)
+    lst = torch.empty(Ln, dtype=torch.int32, device=dev)
+    w = L.ws(L.lib().u3d_csr_build_ws_bytes(Ln, S), dev)
+    L.call('u3d_csr_build', L.ptr(seg_ids.contiguous()), Ln, S, L.ptr(offsets), L.ptr(lst), L.ptr(w), L.stream())
+    return offsets, lst
+
+
+class PoolPlan:
+    """Index structures of one batch for pooling voxel features into superpoints (built once,
+    integer work only): CSR of points per superpoint composed with inverse_mapping (forward) and
+    the voxelizer's CSR of points per voxel composed with the superpoint ids (backward)."""
+
+    def __init__(self, vb: VoxelBatch, superpoints: torch.Tensor, n_superpoints: int):
+        self.S = int(n_superpoints)
+        self.n_vox = vb.coords.shape[0]
+        sp = superpoints.contiguous()
+        self.sp_offsets, self.sp_points = csr_build(sp, self.S)
+        n = sp.shape[0]
+        self.sp_vox = torch.empty(n, dtype=torch.int32, device=sp.device)
+        L.call('u3d_gather_i64_to_i32', L.ptr(vb.inverse), L.ptr(self.sp_points), n, L.ptr(self.sp_vox), L.stream())
+        self.vox_sp = torch.empty(n, dtype=torch.int32, device=sp.device)
+        L.call('u3d_gather_i64_to_i32', L.ptr(sp), L.ptr(vb.vox_points), n, L.ptr(self.vox_sp), L.stream())
+        self.vox_offsets = vb.vox_offsets
+
+
+class _PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, plan: PoolPlan):
+        feats = feats.contiguous()
+        C = feats.shape[1]
+        out = torch.empty(plan.S, C, dtype=torch.float32, device=feats.device)
+        L.call('u3d_segment_gather_sum', L.ptr(feats), L.ptr(plan.sp_vox), L.ptr(plan.sp_offsets), plan.S, C, 1,
+               None, L.ptr(out), L.stream())
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan = ctx.plan
+        dout = dout.contiguous()
+        C = dout.shape[1]
+        df = torch.empty(plan.n_vox, C, dtype=torch.float32, device=dout.device)
+        L.call('u3d_segment_gather_sum', L.ptr(dout), L.ptr(plan.vox_sp), L.ptr(plan.vox_offsets), plan.n_vox, C, 0,
+               L.ptr(plan.sp_offsets), L.ptr(df), L.stream())
+        return df, None
+
+
+def superpoint_pool(feats: torch.Tensor, plan: PoolPlan) -> torch.Tensor:
+    return _PoolFn.apply(feats, plan)
+
+
+def superpoint_centers(points: torch.Tensor, sp_offsets: torch.Tensor, sp_points: torch.Tensor, S: int,
+                       stats: Optional[torch.Tensor] = None, pt_offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mean over each superpoint's points of (xyz - scene_min); ``stats`` = VoxelBatch.stats
+    (row b starts with the scene's min xyz) or None for raw coordinates (predict path)."""
+    out = torch.empty(S, 3, dtype=torch.float32, device=points.device)
+    B = 0 if stats is None else stats.shape[0]
+    L.call('u3d_segment_mean_xyz', L.ptr(points), points.stride(0), L.ptr(sp_points), L.ptr(sp_offsets), S,
+           L.ptr(stats), 12, L.ptr(pt_offsets), B, L.ptr(out), L.stream())
+    return out

@@ -1,0 +1,436 @@
+"""Sparse-voxel tensor + layers over the gfx950 kernels (host side of the boundary).
+
+Mirrors the subset of ``spconv.pytorch`` the reference uses
+(unidet3d/spconv_unet.py:5-7,34-72,146-192; unidet3d/unidet3d.py:96-111,353-354):
+``SparseConvTensor`` (features / indices / spatial_shape / batch_size /
+replace_feature / per-forward ``indice_dict`` rulebook cache keyed by
+``indice_key``), ``SparseSequential``, ``SubMConv3d``, ``SparseConv3d``,
+``SparseInverseConv3d``; plus the BatchNorm the reference takes from torch
+(``nn.SyncBatchNorm`` / ``nn.BatchNorm1d``).  Same constructor arguments,
+same parameter names and weight layout ``[C_out, k, k, k, C_in]``.
+
+Every compute step is a call through the C ABI (include/u3d.h); there is no
+PyTorch fallback.  Rows must be in canonical order (ascending
+((b*X+x)*Y+y)*Z+z) -- which is what ``ops.voxelize`` / ``UniDet3D.collate``
+produce.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib as L
+
+
+# ----------------------------------------------------------------------------------------
+# geometry: occupancy index + rulebooks
+# ----------------------------------------------------------------------------------------
+class OccupancyIndex:
+    """Bitmap + popcount rank of one level (key -> canonical row)."""
+
+    def __init__(self, bitmap, rank, B, shape):
+        self.bitmap, self.rank, self.B = bitmap, rank, B
+        self.shape = [int(s) for s in shape]
+
+    @staticmethod
+    def alloc(B, shape, device):
+        nw = L.lib().u3d_index_words(B, *[int(s) for s in shape])
+        bitmap = torch.zeros(nw, dtype=torch.int64, device=device)
+        rank = torch.empty(nw + 1, dtype=torch.int32, device=device)
+        return OccupancyIndex(bitmap, rank, B, shape)
+
+    def build_rank(self):
+        nw = self.bitmap.numel()
+        w = L.ws(L.lib().u3d_index_rank_ws_bytes(nw), self.bitmap.device)
+        L.call('u3d_index_rank', L.ptr(self.bitmap), nw, L.ptr(self.rank), L.ptr(w), L.stream())
+
+    def count(self) -> int:
+        return int(self.rank[-1].item())       # documented read-back (one host sync)
+
+    def coords(self, n: int) -> torch.Tensor:
+        c = torch.empty(n, 4, dtype=torch.int32, device=self.bitmap.device)
+        if n:
+            L.call('u3d_index_coords', L.ptr(self.bitmap), L.ptr(self.rank), self.B, *self.shape, L.ptr(c), L.stream())
+        return c
+
+    @staticmethod
+    def from_coords(coords: torch.Tensor, B: int, shape, shift: int = 0) -> 'OccupancyIndex':
+        ix = OccupancyIndex.alloc(B, shape, coords.device)
+        L.call('u3d_index_mark', L.ptr(coords), coords.shape[0], shift, *ix.shape, L.ptr(ix.bitmap), L.stream())
+        ix.build_rank()
+        return ix
+
+
+class Rulebook:
+    """pair_in / pair_out int32 [K, cap] grouped by offset, ascending inside an offset."""
+
+    def __init__(self, pair_in, pair_out, counts, K, n_in, n_out):
+        self.pair_in, self.pair_out, self.counts = pair_in, pair_out, counts
+        self.K, self.cap, self.n_in, self.n_out = K, pair_in.shape[1], n_in, n_out
+        self._tiles: Dict = {}
+        self._total = None
+
+    def tile_starts(self, role: str, T: int) -> torch.Tensor:
+        key = (role, T)
+        if key not in self._tiles:
+            rows = self.pair_out if role == 'out' else self.pair_in
+            n_dst = self.n_out if role == 'out' else self.n_in
+            nt = (n_dst + T - 1) // T
+            ts = torch.empty(self.K, nt + 1, dtype=torch.int32, device=rows.device)
+            L.call('u3d_tile_starts', L.ptr(rows), L.ptr(self.counts), self.K, self.cap, T, nt, L.ptr(ts), L.stream())
+            self._tiles[key] = ts
+        return self._tiles[key]
+
+    @property
+    def total_pairs(self) -> int:
+        if self._total is None:
+            self._total = int(self.counts.sum().item())
+        return self._total
+
+    def lists(self):
+        """Host copy as 27/8 (in_rows, out_rows) arrays -- the canonical rulebook (tests)."""
+        c = self.counts.cpu().tolist()
+        pi, po = self.pair_in.cpu(), self.pair_out.cpu()
+        return [(pi[k, :c[k]].numpy(), po[k, :c[k]].numpy()) for k in range(self.K)]
+
+
+def build_subm_rulebook(coords: torch.Tensor, index: OccupancyIndex) -> Rulebook:
+    n = coords.shape[0]
+    dev = coords.device
+    pin = torch.empty(27, n, dtype=torch.int32, device=dev)
+    pout = torch.empty(27, n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(27, dtype=torch.int32, device=dev)
+    w = L.ws(L.lib().u3d_subm_rulebook_ws_bytes(n), dev)
+    L.call('u3d_subm_rulebook', L.ptr(coords), n, L.ptr(index.bitmap), L.ptr(index.rank), index.B, *index.shape,
+           L.ptr(pin), L.ptr(pout), L.ptr(cnt), L.ptr(w), L.stream())
+    return Rulebook(pin, pout, cnt, 27, n, n)
+
+
+def build_down_rulebook(coords: torch.Tensor, B: int, shape):
+    """Returns (out_coords, out_shape, out_index, Rulebook)."""
+    n = coords.shape[0]
+    dev = coords.device
+    oshape = [int(s) // 2 for s in shape]
+    ix2 = OccupancyIndex.from_coords(coords, B, oshape, shift=1)
+    n2 = ix2.count()
+    oc = ix2.coords(n2)
+    pin = torch.empty(8, n, dtype=torch.int32, device=dev)
+    pout = torch.empty(8, n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(8, dtype=torch.int32, device=dev)
+    w = L.ws(L.lib().u3d_down_rulebook_ws_bytes(n), dev)
+    L.call('u3d_down_rulebook', L.ptr(coords), n, L.ptr(ix2.bitmap), L.ptr(ix2.rank), B, *oshape,
+           L.ptr(pin), L.ptr(pout), L.ptr(cnt), L.ptr(w), L.stream())
+    return oc, oshape, ix2, Rulebook(pin, pout, cnt, 8, n, n2)
+
+
+# ----------------------------------------------------------------------------------------
+# convolution (forward / dgrad / wgrad through the C ABI)
+# ----------------------------------------------------------------------------------------
+def _gmm(src, w_rows, gather, scatter, ts, K, cap, n_dst, T, addend, flops):
+    Cs, Cd = src.shape[1], w_rows.shape[0]
+    dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
+    if n_dst:
+        L.call('u3d_spconv_gmm', L.ptr(src), L.ptr(w_rows), L.ptr(gather), L.ptr(scatter), L.ptr(ts), K, cap, Cs, Cd,
+               n_dst, T, L.ptr(addend), L.ptr(dst), float(flops), L.stream())
+    return dst
+
+
+def _tile(Cs, Cd):
+    T = L.lib().u3d_spconv_tile_rows(Cs, Cd)
+    if T <= 0:
+        raise L.U3DError(f'sparse conv: channel combination {Cs}->{Cd} unsupported by the gfx950 kernels')
+    return T
+
+
+_PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops
+
+
+def set_profile_flops(on: bool):
+    global _PROFILE_FLOPS
+    _PROFILE_FLOPS = bool(on)
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """mode: 'fwd' (src rows = pair_in, dst rows = pair_out; SubM and strided conv) or
+    'inv' (roles swapped; SparseInverseConv3d)."""
+
+    @staticmethod
+    def forward(ctx, src, weight, rb: Rulebook, mode: str, addend):
+        cout, cin = weight.shape[0], weight.shape[-1]
+        w = weight.reshape(cout, rb.K, cin)
+        src = src.contiguous()
+        if mode == 'fwd':
+            g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
+        else:
+            g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
+        T = _tile(cin, cout)
+        flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
+        dst = _gmm(src, w, g, s, rb.tile_starts(role, T), rb.K, rb.cap, n_dst, T,
+                   None if addend is None else addend.contiguous(), flops)
+        ctx.save_for_backward(src, weight)
+        ctx.rb, ctx.mode, ctx.has_addend = rb, mode, addend is not None
+        return dst
+
+    @staticmethod
+    def backward(ctx, dout):
+        src, weight = ctx.saved_tensors
+        rb, mode = ctx.rb, ctx.mode
+        cout, cin = weight.shape[0], weight.shape[-1]
+        dout = dout.contiguous()
+        dsrc = dw = None
+        flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty(cin, rb.K, cout, dtype=torch.float32, device=weight.device)
+            L.call('u3d_weight_transpose', L.ptr(weight), L.ptr(wt), cout, rb.K, cin, L.stream())
+            if mode == 'fwd':
+                g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
+            else:
+                g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
+            T = _tile(cout, cin)
+            dsrc = _gmm(dout, wt, g, s, rb.tile_starts(role, T), rb.K, rb.cap, n_dst, T, None, flops)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(weight)
+            rx, rg = (rb.pair_in, rb.pair_out) if mode == 'fwd' else (rb.pair_out, rb.pair_in)
+            L.call('u3d_spconv_wgrad', L.ptr(src), L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(rb.counts), rb.K, rb.cap,
+                   cin, cout, L.ptr(dw), float(flops), L.stream())
+        return dsrc, dw, None, None, (dout if ctx.has_addend else None)
+
+
+def sparse_conv(src, weight, rb, mode='fwd', addend=None):
+    return _SparseConvFn.apply(src, weight, rb, mode, addend)
+
+
+# ----------------------------------------------------------------------------------------
+# batch norm (+ReLU)
+# ----------------------------------------------------------------------------------------
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_bn_sums(sums: torch.Tensor, group=None):
+    """SyncBatchNorm exchange: one all-reduce of the fp64 [.., count] vector (RCCL over xGMI
+    on the GPU box, gloo in the CPU tests)."""
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+class _BNReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync):
+        x = x.contiguous()
+        n, C = x.shape
+        dev = x.device
+        st = torch.empty(4, C, dtype=torch.float32, device=dev)     # mean, invstd, scale, shift
+        y = torch.empty_like(x)
+        count = float(n)
+        if training:
+            sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
+            if n:
+                L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(sums), L.stream())
+            if sync and _dist_on():
+                sums[2 * C] = float(n)
+                allreduce_bn_sums(sums)
+                count = float(sums[2 * C].item())
+            L.call('u3d_bn_finalize', L.ptr(sums), count, L.ptr(gamma), L.ptr(beta), eps, momentum,
+                   L.ptr(running_mean), L.ptr(running_var), C, L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
+                   L.stream())
+        else:
+            st[0] = running_mean
+            st[1] = torch.rsqrt(running_var + eps)
+            st[2] = gamma * st[1]
+            st[3] = beta - running_mean * st[2]
+        if n:
+            L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
+        ctx.save_for_backward(x, st)
+        ctx.relu, ctx.training, ctx.sync, ctx.count = relu, training, sync, count
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, C = x.shape
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=x.device)
+        dx = torch.empty_like(x)
+        if n:
+            L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
+                   int(ctx.relu), n, C, L.ptr(sums), L.stream())
+        dbeta = sums[:C].to(torch.float32)          # local sums: DDP averages parameter grads afterwards
+        dgamma = sums[C:].to(torch.float32)
+        if ctx.training:
+            if ctx.sync and _dist_on():
+                allreduce_bn_sums(sums)
+        else:
+            sums = torch.zeros_like(sums)           # eval: statistics are constants
+        if n:
+            L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
+                   int(ctx.relu), L.ptr(sums), ctx.count, n, C, L.ptr(dx), None, None, L.stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class SparseBatchNorm(nn.Module):
+    """BatchNorm over voxel rows with the parameter/buffer names of nn.BatchNorm1d /
+    nn.SyncBatchNorm (weight, bias, running_mean, running_var, num_batches_tracked).
+    ``sync=True`` all-reduces the statistics across ranks when a process group exists
+    (nn.SyncBatchNorm degenerates to plain batch norm without one -- SURVEY.md 2.3)."""
+
+    def __init__(self, num_features, eps=1e-4, momentum=0.1, sync=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.sync = num_features, eps, momentum, sync
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+        if self.training:
+            self.num_batches_tracked += 1
+        return _BNReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                               self.momentum, relu, self.training, self.sync)
+
+
+# ----------------------------------------------------------------------------------------
+# SparseConvTensor + layers
+# ----------------------------------------------------------------------------------------
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, indice_dict=None, index=None):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {} if indice_dict is None else indice_dict
+        self._index = index
+
+    def replace_feature(self, new_features):
+        return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size,
+                                self.indice_dict, self._index)
+
+    @property
+    def index(self) -> OccupancyIndex:
+        if self._index is None:
+            key = ('__index__', tuple(self.spatial_shape), self.indices.data_ptr())
+            if key not in self.indice_dict:
+                self.indice_dict[key] = OccupancyIndex.from_coords(self.indices, self.batch_size, self.spatial_shape)
+            self._index = self.indice_dict[key]
+        return self._index
+
+
+class SparseModule(nn.Module):
+    pass
+
+
+class SparseSequential(SparseModule):
+    """spconv.SparseSequential: sparse layers see the tensor, dense layers its features;
+    a BatchNorm directly followed by ReLU runs as one fused kernel."""
+
+    def __init__(self, *args):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for k, m in args[0].items():
+                self.add_module(k, m)
+        else:
+            for i, m in enumerate(args):
+                self.add_module(str(i), m)
+
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, SparseModule):
+                x = m(x)
+            elif isinstance(m, SparseBatchNorm):
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = x.replace_feature(m(x.features, relu=fuse))
+                i += 1 if fuse else 0
+            elif isinstance(m, nn.Identity):
+                pass
+            elif isinstance(m, nn.ReLU):
+                x = x.replace_feature(_relu(x.features))
+            else:
+                raise L.U3DError(f'SparseSequential: no gfx950 kernel for dense layer {type(m).__name__}')
+            i += 1
+        return x
+
+
+def _relu(f):
+    # stand-alone ReLU (not preceded by BN) does not occur on the hot path; identity-BN kernel reuse
+    C = f.shape[1]
+    one = torch.ones(C, device=f.device)
+    zero = torch.zeros(C, device=f.device)
+    y = torch.empty_like(f)
+    L.call('u3d_bn_apply', L.ptr(f.contiguous()), L.ptr(one), L.ptr(zero), 1, f.shape[0], C, L.ptr(y), L.stream())
+    return y
+
+
+def _pad16(f):
+    c = f.shape[1]
+    return f if c % 16 == 0 else F.pad(f, (0, 16 - c % 16))
+
+
+class _ConvBase(SparseModule):
+    def __init__(self, in_channels, out_channels, kernel_size, bias=False, indice_key=None):
+        super().__init__()
+        if bias:
+            raise L.U3DError('bias=True is not used by the reference configs and not built')
+        k = kernel_size
+        self.in_channels, self.out_channels, self.kernel_size, self.indice_key = in_channels, out_channels, k, indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, k, k, k, in_channels))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+    def _w16(self):
+        c = self.in_channels
+        return self.weight if c % 16 == 0 else F.pad(self.weight, (0, 16 - c % 16))
+
+
+class SubMConv3d(_ConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, bias, indice_key)
+        assert kernel_size in (1, 3)
+
+    def forward(self, x: SparseConvTensor, addend: Optional[torch.Tensor] = None) -> SparseConvTensor:
+        if self.kernel_size == 1:
+            # plain [N, Cin] x [Cin, Cout] library GEMM (hipBLASLt), no rulebook (K5)
+            y = F.linear(x.features, self.weight.view(self.out_channels, self.in_channels))
+            return x.replace_feature(y if addend is None else y + addend)
+        key = self.indice_key if self.indice_key is not None else ('__subm__', id(self))
+        rb = x.indice_dict.get(key)
+        if rb is None:
+            rb = build_subm_rulebook(x.indices, x.index)
+            x.indice_dict[key] = rb
+        return x.replace_feature(sparse_conv(_pad16(x.features), self._w16(), rb, 'fwd', addend))
+
+
+class SparseConv3d(_ConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, bias, indice_key)
+        assert kernel_size == 2 and stride == 2 and padding == 0, 'only k=2,s=2 is on the hot path'
+
+    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+        oc, oshape, ix2, rb = build_down_rulebook(x.indices, x.batch_size, x.spatial_shape)
+        x.indice_dict[self.indice_key] = (rb, x.indices, x.spatial_shape, x._index)
+        f = sparse_conv(_pad16(x.features), self._w16(), rb, 'fwd')
+        return SparseConvTensor(f, oc, oshape, x.batch_size, x.indice_dict, ix2)
+
+
+class SparseInverseConv3d(_ConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=False):
+        super().__init__(in_channels, out_channels, kernel_size, bias, indice_key)
+
+    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+        if self.indice_key not in x.indice_dict:
+            raise L.U3DError(f'SparseInverseConv3d: no rulebook saved under {self.indice_key!r}')
+        rb, idx, shape, index = x.indice_dict[self.indice_key]
+        f = sparse_conv(_pad16(x.features), self._w16(), rb, 'inv')
+        return SparseConvTensor(f, idx, shape, x.batch_size, x.indice_dict, index)

@@ -1,0 +1,120 @@
+"""Sparse-voxel residual U-Net backbone over the gfx950 kernels.
+
+Drop-in for the reference's ``SpConvUNet`` (unidet3d/spconv_unet.py:94-240): same registry
+name, constructor arguments (:108-115), forward signature / return types (:205-240) and
+``state_dict`` keys (blocks.block{i}.conv_branch.{0,2,3,5}, .i_branch.0, conv.{0,2}, u.*,
+deconv.{0,2}, blocks_tail.*), so OneFormer3D / UniDet3D checkpoints load unchanged.
+
+Differences are all below the module surface: convolutions, rulebooks and batch-norm run as
+HIP kernels through include/u3d.h, BN+ReLU is one fused kernel, and the residual add of
+``ResidualBlock.forward`` (:88-89) is folded into the accumulator init of the block's last
+convolution.
+"""
+from __future__ import annotations
+
+import functools
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .registry import MODELS
+from .sparse import (SparseBatchNorm, SparseConv3d, SparseConvTensor, SparseInverseConv3d, SparseModule,
+                     SparseSequential, SubMConv3d)
+
+
+def _norm_factory(sync: bool):
+    return functools.partial(SparseBatchNorm, eps=1e-4, momentum=0.1, sync=sync)
+
+
+class ResidualBlock(SparseModule):
+    """(BN, ReLU, SubM3) x 2 + identity / SubM1 skip  (spconv_unet.py:13-91)."""
+
+    def __init__(self, in_channels, out_channels, norm_fn=None, indice_key=None, normalize_before=True):
+        super().__init__()
+        norm_fn = norm_fn or _norm_factory(False)
+        self.normalize_before = normalize_before
+        if in_channels == out_channels:
+            self.i_branch = SparseSequential(nn.Identity())
+        else:
+            self.i_branch = SparseSequential(SubMConv3d(in_channels, out_channels, kernel_size=1, bias=False))
+        conv1 = SubMConv3d(in_channels, out_channels, kernel_size=3, padding=1, bias=False, indice_key=indice_key)
+        conv2 = SubMConv3d(out_channels, out_channels, kernel_size=3, padding=1, bias=False, indice_key=indice_key)
+        if normalize_before:
+            self.conv_branch = SparseSequential(norm_fn(in_channels), nn.ReLU(), conv1,
+                                                norm_fn(out_channels), nn.ReLU(), conv2)
+        else:
+            self.conv_branch = SparseSequential(conv1, norm_fn(out_channels), nn.ReLU(),
+                                                conv2, norm_fn(out_channels), nn.ReLU())
+
+    def forward(self, input: SparseConvTensor) -> SparseConvTensor:
+        skip = self.i_branch(input).features
+        if not self.normalize_before:
+            out = self.conv_branch(input)
+            return out.replace_feature(out.features + skip)
+        mods = list(self.conv_branch._modules.values())
+        x = input
+        x = x.replace_feature(mods[0](x.features, relu=True))
+        x = mods[2](x)
+        x = x.replace_feature(mods[3](x.features, relu=True))
+        return mods[5](x, addend=skip)          # conv + residual in one kernel
+
+
+@MODELS.register_module()
+class SpConvUNet(nn.Module):
+    def __init__(self, num_planes, use_sync_bn=True, block_reps=2, block=ResidualBlock, indice_key_id=1,
+                 normalize_before=True, return_blocks=False):
+        super().__init__()
+        self.return_blocks = return_blocks
+        self.num_planes = list(num_planes)
+        # The reference's recursion passes its norm_fn partial in the ``use_sync_bn`` slot
+        # (spconv_unet.py:166-168), which is truthy: every inner level is SyncBatchNorm even when
+        # the top level asked for BatchNorm1d.  Reproduced: inner levels always sync.
+        norm_fn = _norm_factory(bool(use_sync_bn))
+        if isinstance(block, str):
+            area = ['residual', 'vgg', 'asym']
+            assert block in area, f'block must be in {area}, but got {block}'
+            if block != 'residual':
+                raise NotImplementedError(f'block {block!r} is not defined by the reference either')
+            block = ResidualBlock
+        c0 = self.num_planes[0]
+        self.blocks = SparseSequential(OrderedDict(
+            (f'block{i}', block(c0, c0, norm_fn, normalize_before=normalize_before, indice_key=f'subm{indice_key_id}'))
+            for i in range(block_reps)))
+        if len(self.num_planes) > 1:
+            c1 = self.num_planes[1]
+            down = SparseConv3d(c0, c1, kernel_size=2, stride=2, bias=False, indice_key=f'spconv{indice_key_id}')
+            up = SparseInverseConv3d(c1, c0, kernel_size=2, bias=False, indice_key=f'spconv{indice_key_id}')
+            if normalize_before:
+                self.conv = SparseSequential(norm_fn(c0), nn.ReLU(), down)
+            else:
+                self.conv = SparseSequential(down, norm_fn(c1), nn.ReLU())
+            self.u = SpConvUNet(self.num_planes[1:], True, block_reps, block, indice_key_id=indice_key_id + 1,
+                                normalize_before=normalize_before, return_blocks=return_blocks)
+            if normalize_before:
+                self.deconv = SparseSequential(norm_fn(c1), nn.ReLU(), up)
+            else:
+                self.deconv = SparseSequential(up, norm_fn(c0), nn.ReLU())
+            self.blocks_tail = SparseSequential(OrderedDict(
+                (f'block{i}', block(c0 * (2 - i), c0, norm_fn, indice_key=f'subm{indice_key_id}',
+                                    normalize_before=normalize_before))
+                for i in range(block_reps)))
+
+    def forward(self, input: SparseConvTensor, previous_outputs=None):
+        output = self.blocks(input)
+        identity = output
+        if len(self.num_planes) > 1:
+            dec = self.conv(output)
+            if self.return_blocks:
+                dec, previous_outputs = self.u(dec, previous_outputs)
+            else:
+                dec = self.u(dec)
+            dec = self.deconv(dec)
+            output = output.replace_feature(torch.cat((identity.features, dec.features), dim=1))
+            output = self.blocks_tail(output)
+        if self.return_blocks:
+            if previous_outputs is None:
+                previous_outputs = []
+            previous_outputs.append(output)
+            return output, previous_outputs
+        return output

@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Headline benchmark: scenes/sec forward+backward of UniDet3D's detection hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): 8 synthetic ScanNet-shape scenes per GPU, 100k points each,
+0.02 m voxels, fp32, the ScanNet model config (5-level sparse U-Net 32..160 ch, 6-layer 256-d decoder).
+One step = one pass of the hot path over the batch with the points already resident in HBM:
+voxelise -> rulebooks -> backbone -> superpoint pooling -> decoder -> matcher/loss -> backward ->
+(gradient all-reduce when N > 1) -> grad clip + AdamW.  Weak scaling: every rank runs its own 8 scenes.
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='scenes per GPU (cfg2: 8)')
+    ap.add_argument('--points', type=int, default=100_000)
+    ap.add_argument('--voxel-size', type=float, default=0.02)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (diagnostic, not the reported config)')
+    return ap.parse_args()
+
+
+def cpu_baseline(points: int, voxel_size: float):
+    """The oracle (a PyTorch-CPU restatement of the algorithm spconv's CPU path uses) timed on this
+    box's host cores on a bounded sample: ONE scene of the same workload, forward + loss + backward."""
+    from oracle import criterion as oc
+    from oracle import model as om
+    from unidet3d_amd.config import scannet_model_cfg
+    from unidet3d_amd.synthetic import make_scene
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = scannet_model_cfg(voxel_size=voxel_size)
+    torch.manual_seed(0)
+    det = om.ODetector(backbone=cfg['backbone'], decoder=cfg['decoder'], voxel_size=voxel_size)
+    det.train()
+
+    def run(sc):
+        p = [torch.from_numpy(sc.points)]
+        s = [torch.from_numpy(sc.superpoints)]
+        feats, _ = det.extract_feat(p, s)
+        out = det.decoder(feats, det.sp_centers(p, s), ['scannet'])
+        inst = oc.gt_from_scene(p[0][:, :3] - p[0][:, :3].min(0)[0], torch.from_numpy(sc.instance_mask),
+                                torch.from_numpy(sc.labels), s[0])
+        loss = oc.criterion(out, [inst])
+        det.zero_grad()
+        loss.backward()
+        return float(loss)
+
+    run(make_scene(900, n_points=max(points // 20, 2000)))      # warm the thread pool / allocator
+    sc = make_scene(0, n_points=points)
+    t0 = time.perf_counter()
+    run(sc)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit='scenes/s', cores=cores, kind='port',
+                sample=f'1 scene of the bench workload ({points} pts, {voxel_size} m voxels), fwd+loss+bwd, fp32, '
+                       f'{dt:.1f} s on torch CPU threads={cores}; GPU value is the whole {"8-scene"} batch rate')
+
+
+def main():
+    args = parse()
+    from unidet3d_amd import _lib as L
+    from unidet3d_amd import sparse
+    from unidet3d_amd.config import build_model, scannet_model_cfg
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.dist import FlatGradBucket, broadcast_params, init_from_env
+    from unidet3d_amd.synthetic import make_scene
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    L.lib()                                           # fail loudly if the HIP library is missing
+    rank, world, local = init_from_env('nccl')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    torch.manual_seed(0)
+    model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)
+    model.train()
+    broadcast_params(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    bucket = FlatGradBucket(params)
+    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)      # configs/unidet3d_1xb8_scannet.py:712
+
+    scenes = [make_scene(rank * args.batch + i, n_points=args.points) for i in range(args.batch)]
+    inputs, samples = make_batch_inputs(scenes, dev)                              # resident in HBM before timing
+
+    def step():
+        bucket.zero()
+        loss = model.loss(inputs, samples)['det_loss']
+        loss.backward()
+        bucket.allreduce_mean()
+        if not args.no_optimizer:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=10, norm_type=2, foreach=True)   # configs :713
+            opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sparse.set_profile_flops(True)      # launches carry their algorithmic flops (pair counts cached during warm-up)
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    assert bucket.check_views(), 'p.grad no longer aliases the flat gradient buffer'
+    for c in (L.K_CONV_FWD, L.K_CONV_WGRAD, L.K_ATTN_FWD, L.K_ATTN_BWD):
+        L.prof_enable(c, True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = {}
+    for name, c in (('conv_gmm', L.K_CONV_FWD), ('conv_wgrad', L.K_CONV_WGRAD), ('attn_fwd', L.K_ATTN_FWD),
+                    ('attn_bwd', L.K_ATTN_BWD)):
+        ms, n, work = L.prof_collect(c)
+        L.prof_enable(c, False)
+        prof[name] = dict(ms=ms, launches=n, flops=work)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        g = prof['conv_gmm']
+        ach = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
+        w = prof['conv_wgrad']
+        n_vox = int(model._vb.coords.shape[0])
+        out = {
+            'metric': 'scenes/sec fwd+bwd, 100k-pt ScanNet voxel grid',
+            'value': args.batch * world * args.steps / dt,
+            'unit': 'scenes/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'cfg2: {args.batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
+                                   f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, fp32; '
+                                   'step = voxelise+rulebook+fwd+loss+bwd' +
+                                   ('' if args.no_optimizer else '+clip+AdamW'),
+                       'global_batch': args.batch * world, 'points_per_scene': args.points,
+                       'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val},
+            'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
+                         'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'launches': g['launches'], 'avg_launch_us': g['ms'] * 1e3 / max(g['launches'], 1),
+                         'algorithmic_gflop_per_launch': g['flops'] / max(g['launches'], 1) / 1e9,
+                         'share_of_step': g['ms'] / (dt * 1e3)},
+            'kernels': {k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
+                            'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] > 0 and v['flops'] > 0 else None)}
+                        for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.points, args.voxel_size)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

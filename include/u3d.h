@@ -138,7 +138,8 @@ int u3d_weight_transpose(const float* w, float* wt, int Cd, int K, int Cs, u3d_s
  * ===================================================================================== */
 int u3d_bn_stats(const float* x, int64_t n, int C, double* sums /*[2C]: sum, sum of squares; += */, u3d_stream_t stream);
 /* mean/var from sums/count; scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place
- * (momentum, unbiased var) when running_mean != NULL. */
+ * (momentum, unbiased var) when running_mean != NULL.  count <= 0: the row count is read from sums[2C]
+ * (it then travels through the SyncBatchNorm all-reduce with the sums: no host read-back). */
 int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, int C, float* mean, float* invstd,
                     float* scale, float* shift, u3d_stream_t stream);
@@ -148,7 +149,8 @@ int u3d_bn_apply(const float* x, const float* scale, const float* shift, int rel
 int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd,
                      const float* scale, const float* shift, int relu, int64_t n, int C, double* sums,
                      u3d_stream_t stream);
-/* dx = scale*(dy' - sum_dy/count - xhat*sum_dyxhat/count); dgamma = sum_dyxhat, dbeta = sum_dy (fp32 out) */
+/* dx = scale*(dy' - sum_dy/count - xhat*sum_dyxhat/count); dgamma = sum_dyxhat, dbeta = sum_dy (fp32 out);
+ * count <= 0: read from sums[2C]. */
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd,
                      const float* scale, const float* shift, int relu, const double* sums, double count,
                      int64_t n, int C, float* dx, float* dgamma, float* dbeta, u3d_stream_t stream);

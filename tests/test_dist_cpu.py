@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the flat-gradient all-reduce and the
+SyncBatchNorm statistic exchange (the collective layer is device agnostic; the kernels feeding it
+are covered by the -m gpu tests)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from unidet3d_amd.dist import FlatGradBucket, broadcast_params, init_from_env
+    from unidet3d_amd.sparse import allreduce_bn_sums
+    r, w, _ = init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                     # ranks start different, broadcast must align them
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    broadcast_params(net)
+    bucket = FlatGradBucket(net.parameters())
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8, 6, generator=g); Y = torch.randn(8, 3, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    bucket.zero()
+    ((net(xs) - ys) ** 2).mean().backward()
+    assert bucket.check_views()
+    bucket.allreduce_mean()
+    # SyncBN statistics: per-rank partial sums of different row counts -> global mean / var
+    C = 4
+    xr = torch.randn(10 + 7 * rank, C, generator=torch.Generator().manual_seed(rank)).double()
+    sums = torch.cat([xr.sum(0), (xr * xr).sum(0), torch.tensor([float(len(xr))], dtype=torch.float64)])
+    allreduce_bn_sums(sums)
+    q.put((rank, bucket.flat.clone().numpy(), [p.detach().clone().numpy() for p in net.parameters()], sums.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_and_syncbn_stats_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # identical averaged gradients on both ranks == gradient of the full-batch mean loss
+    assert np.allclose(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)                   # broadcast aligned the replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    with torch.no_grad():
+        for p, a in zip(net.parameters(), res[0][2]):
+            p.copy_(torch.from_numpy(a))
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8, 6, generator=g); Y = torch.randn(8, 3, generator=g)
+    ((net(X) - Y) ** 2).mean().backward()
+    full = torch.cat([p.grad.view(-1) for p in net.parameters()]).numpy()
+    assert np.allclose(res[0][1], full, atol=1e-6)
+    # statistics equal those of the concatenated batch
+    xs = [torch.randn(10 + 7 * r, 4, generator=torch.Generator().manual_seed(r)).double() for r in range(world)]
+    allx = torch.cat(xs)
+    s = res[0][3]
+    n = s[8]
+    assert n == len(allx)
+    assert np.allclose(s[:4] / n, allx.mean(0).numpy()) and np.allclose(s[4:8] / n - (s[:4] / n) ** 2, allx.var(0, unbiased=False).numpy())

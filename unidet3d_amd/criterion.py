@@ -1,0 +1,178 @@
+"""Loss driver of the hot path (drives backward): matcher + per-layer CE + DIoU.
+
+Same registry names, constructor arguments and call signatures as the reference
+(unidet3d/criterion.py:7-178 ``UniDet3DCriterion``; :200-320 ``QueryClassificationCost``,
+``BboxCostJointTraining``, ``UniMatcher``; unidet3d/axis_aligned_iou_loss.py:14-116
+``UniDet3DAxisAlignedIoULoss``).  The tensors here are [n_queries, n_gt] -- tiny next to the
+backbone -- so this stays on torch ops on the device; the rotated
+DIoU (ARKitScenes only) is not built and raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import MODELS, TASK_UTILS
+from .structures import InstanceData_
+
+
+def _aligned_iou_3d(b1, b2, eps=1e-6):
+    """mmdet3d AxisAlignedBboxOverlaps3D(is_aligned=True) on (x1,y1,z1,x2,y2,z2)."""
+    vol1 = (b1[..., 3:] - b1[..., :3]).prod(-1)
+    vol2 = (b2[..., 3:] - b2[..., :3]).prod(-1)
+    inter = (torch.min(b1[..., 3:], b2[..., 3:]) - torch.max(b1[..., :3], b2[..., :3])).clamp(min=0).prod(-1)
+    union = torch.max(vol1 + vol2 - inter, inter.new_tensor([eps]))
+    return inter / union
+
+
+def axis_aligned_diou_loss(pred, target):
+    """1 - IoU + centre_dist^2 / enclosing_diag^2 (axis_aligned_iou_loss.py:14-53), including
+    the reference's ``[:, 0]`` indexing of the distance term (:51)."""
+    iou_loss = 1 - _aligned_iou_3d(pred, target)
+    pc = (pred[..., :3] + pred[..., 3:]) / 2
+    tc = (target[..., :3] + target[..., 3:]) / 2
+    r2 = ((pc - tc) ** 2).sum(-1, keepdim=True)
+    lo = torch.minimum(pred[..., :3], target[..., :3])
+    hi = torch.maximum(pred[..., 3:], target[..., 3:])
+    c2 = ((lo - hi) ** 2).sum(-1, keepdim=True)
+    return iou_loss + (r2 / c2)[:, 0]
+
+
+@MODELS.register_module()
+class UniDet3DAxisAlignedIoULoss(nn.Module):
+    def __init__(self, mode='iou', reduction='mean', loss_weight=1.0):
+        super().__init__()
+        assert mode in ['iou', 'diou'] and reduction in ['none', 'sum', 'mean']
+        self.mode, self.reduction, self.loss_weight = mode, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        reduction = reduction_override if reduction_override else self.reduction
+        loss = axis_aligned_diou_loss(pred, target) if self.mode == 'diou' else 1 - _aligned_iou_3d(pred, target)
+        if weight is not None:
+            loss = loss * weight
+        if reduction == 'mean':
+            loss = loss.mean() if avg_factor is None else loss.sum() / avg_factor
+        elif reduction == 'sum':
+            loss = loss.sum()
+        return loss * self.loss_weight
+
+
+@MODELS.register_module()
+class UniDet3DRotatedIoU3DLoss(nn.Module):
+    """Placeholder with the reference's name (rotated_iou_loss.py): only ARKitScenes
+    (angles=True) reaches it; not built in this round -> fails loudly."""
+
+    def __init__(self, mode='iou', reduction='mean', loss_weight=1.0):
+        super().__init__()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('rotated DIoU (ARKitScenes, 7-dof boxes) is outside the built hot path')
+
+
+def _bbox_to_loss(bbox):                       # criterion.py:180-198
+    if bbox.shape[-1] != 6:
+        return bbox
+    half = bbox[..., 3:] / 2
+    return torch.cat((bbox[..., :3] - half, bbox[..., :3] + half), dim=-1)
+
+
+@TASK_UTILS.register_module()
+class QueryClassificationCost:
+    def __init__(self, weight):
+        self.weight = weight
+
+    def __call__(self, pred_instances, gt_instances, **kwargs):
+        return -pred_instances.scores.softmax(-1)[:, gt_instances.labels] * self.weight
+
+
+@TASK_UTILS.register_module()
+class BboxCostJointTraining:
+    def __init__(self, weight, loss_simple, loss_rotated):
+        self.weight = weight
+        self.loss_simple = MODELS.build(loss_simple)
+        self.loss_rotated = MODELS.build(loss_rotated)
+
+    def __call__(self, pred_instances, gt_instances, **kwargs):
+        n, g = pred_instances.bboxes.shape[0], gt_instances.bboxes.shape[0]
+        assert gt_instances.bboxes.shape[1] == pred_instances.bboxes.shape[1]
+        pb = pred_instances.bboxes.unsqueeze(1).expand(n, g, -1)
+        gb = gt_instances.bboxes.unsqueeze(0).expand(n, g, -1)
+        loss = self.loss_rotated if gt_instances.bboxes.shape[1] == 7 else self.loss_simple
+        return loss(_bbox_to_loss(pb), _bbox_to_loss(gb)) * self.weight
+
+
+@TASK_UTILS.register_module()
+class UniMatcher:
+    """Each GT keeps its ``topk`` cheapest queries among those its mask allows (criterion.py:272-320)."""
+
+    def __init__(self, costs):
+        self.costs = [TASK_UTILS.build(c) for c in costs]
+        self.inf = 1e8
+
+    @torch.no_grad()
+    def __call__(self, pred_instances, gt_instances, topk, **kwargs):
+        labels = gt_instances.labels
+        if len(labels) == 0:
+            return labels.new_empty((0,)), labels.new_empty((0,))
+        cost = torch.stack([c(pred_instances, gt_instances) for c in self.costs]).sum(dim=0)
+        cost = torch.where(gt_instances.query_masks.T, cost, cost.new_tensor(self.inf))
+        kth = torch.topk(cost, topk + 1, dim=0, sorted=True, largest=False).values[-1:, :]
+        ids = torch.argwhere(cost < kth)
+        return ids[:, 0], ids[:, 1]
+
+
+def _gt_boxes(b):
+    return torch.cat((b.gravity_center, b.tensor[:, 3:] if b.with_yaw else b.tensor[:, 3:6]), dim=1)
+
+
+@MODELS.register_module()
+class UniDet3DCriterion:
+    def __init__(self, matcher, loss_weight, non_object_weight, iter_matcher, bbox_loss_simple, bbox_loss_rotated,
+                 datasets, datasets_weights, topk):
+        self.bbox_loss_simple = MODELS.build(bbox_loss_simple)
+        self.bbox_loss_rotated = MODELS.build(bbox_loss_rotated)
+        self.matcher = TASK_UTILS.build(matcher)
+        self.non_object_weight = non_object_weight
+        self.loss_weight = loss_weight
+        self.iter_matcher = iter_matcher
+        self.datasets = datasets
+        self.datasets_weights = datasets_weights
+        self.topk = topk
+
+    def get_layer_loss(self, aux_outputs, insts, datasets_names, indices=None):
+        cls_preds, pred_bboxes = aux_outputs['cls_preds'], aux_outputs['bboxes']
+        if indices is None:
+            indices = []
+            for i, inst in enumerate(insts):
+                idx = self.datasets.index(datasets_names[i])
+                pred = InstanceData_(scores=cls_preds[i], bboxes=pred_bboxes[i])
+                gt = InstanceData_(labels=inst.labels_3d, query_masks=inst.query_masks, bboxes=_gt_boxes(inst.bboxes_3d))
+                indices.append(self.matcher(pred, gt, self.topk[idx]))
+        cls_losses, bbox_losses = [], []
+        for name, cls_pred, bbox, inst, (idx_q, idx_gt) in zip(datasets_names, cls_preds, pred_bboxes, insts, indices):
+            weight = self.datasets_weights[self.datasets.index(name)]
+            n_cls = cls_pred.shape[1] - 1
+            target = cls_pred.new_full((len(cls_pred),), n_cls, dtype=torch.long)
+            target[idx_q] = inst.labels_3d[idx_gt]
+            cw = cls_pred.new_ones(n_cls + 1)
+            cw[-1] = self.non_object_weight
+            cls_losses.append(weight * F.cross_entropy(cls_pred, target, cw))
+            if len(inst) == 0 or len(idx_q) == 0:
+                continue
+            tgt = _gt_boxes(inst.bboxes_3d[idx_gt])
+            loss_fn = self.bbox_loss_rotated if tgt.shape[1] == 7 else self.bbox_loss_simple
+            bbox_losses.append(weight * loss_fn(_bbox_to_loss(bbox[idx_q]), _bbox_to_loss(tgt)).mean())
+        cls_loss = torch.mean(torch.stack(cls_losses))
+        bbox_loss = torch.stack(bbox_losses).mean() if bbox_losses else 0
+        return self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss
+
+    def __call__(self, pred, insts, datasets_names):
+        loss = self.get_layer_loss(pred, insts, datasets_names)
+        if 'aux_outputs' in pred:
+            indices = None        # iter_matcher=True re-matches per layer; the reference leaves `indices`
+            if not self.iter_matcher:   # undefined otherwise (criterion.py:171-176) -- same requirement here
+                raise NotImplementedError('iter_matcher=False is not exercised by the reference configs')
+            for aux in pred['aux_outputs']:
+                loss = loss + self.get_layer_loss(aux, insts, datasets_names, indices)
+        return {'det_loss': loss}

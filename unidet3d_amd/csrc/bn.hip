@@ -70,6 +70,7 @@ __global__ void bn_finalize_k(const double* __restrict__ sums, double count, con
                               float* running_var, int C, float* mean, float* invstd, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (!(count > 0.0)) count = sums[2 * C];      // count travels with the (all-reduced) sums
     const double m = sums[c] / count;
     double var = sums[C + c] / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
                                                       const double* __restrict__ sums, double inv_count, int64_t n4, int C,
                                                       float* dx, float* dgamma, float* dbeta) {
     const int C4 = C >> 2;
+    if (!(inv_count > 0.0)) inv_count = 1.0 / sums[2 * C];
     if (blockIdx.x == 0 && dgamma) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             dbeta[c] = (float)sums[c];
@@ -167,7 +169,7 @@ int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, u3d_stream_t st
 int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, int C, float* mean, float* invstd, float* scale,
                     float* shift, u3d_stream_t stream) {
-    if (!sums || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0) return U3D_EINVAL;
+    if (!sums || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0) return U3D_EINVAL;
     hipLaunchKernelGGL(bn_finalize_k, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, gamma, beta, eps,
                        momentum, running_mean, running_var, C, mean, invstd, scale, shift);
     return check_launch("bn_finalize");
@@ -198,7 +200,7 @@ int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const f
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
                      const float* shift, int relu, const double* sums, double count, int64_t n, int C, float* dx,
                      float* dgamma, float* dbeta, u3d_stream_t stream) {
-    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !dx || !bn_ok(n, C) || count <= 0) return U3D_EINVAL;
+    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !dx || !bn_ok(n, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
     const int64_t n4 = n * (C / 4);

@@ -42,14 +42,25 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(points: int, voxel_size: float):
-    """The oracle (a PyTorch-CPU restatement of the algorithm spconv's CPU path uses) timed on this
-    box's host cores on a bounded sample: ONE scene of the same workload, forward + loss + backward."""
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count()
+    reports the host's cores inside a container and oversubscribes the OpenMP pool)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, 64))
+
+
+def _cpu_baseline_child(points: int, voxel_size: float, cores: int):
+    """Runs in a child process (bounded by a timeout in the parent)."""
     from oracle import criterion as oc
     from oracle import model as om
     from unidet3d_amd.config import scannet_model_cfg
     from unidet3d_amd.synthetic import make_scene
-    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     cfg = scannet_model_cfg(voxel_size=voxel_size)
     torch.manual_seed(0)
@@ -66,16 +77,38 @@ def cpu_baseline(points: int, voxel_size: float):
         loss = oc.criterion(out, [inst])
         det.zero_grad()
         loss.backward()
-        return float(loss)
+        return float(loss.detach())
 
     run(make_scene(900, n_points=max(points // 20, 2000)))      # warm the thread pool / allocator
     sc = make_scene(0, n_points=points)
     t0 = time.perf_counter()
     run(sc)
-    dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit='scenes/s', cores=cores, kind='port',
-                sample=f'1 scene of the bench workload ({points} pts, {voxel_size} m voxels), fwd+loss+bwd, fp32, '
-                       f'{dt:.1f} s on torch CPU threads={cores}; GPU value is the whole {"8-scene"} batch rate')
+    print(json.dumps({'seconds': time.perf_counter() - t0}))
+
+
+def cpu_baseline(points: int, voxel_size: float):
+    """The oracle (a PyTorch-CPU restatement of the algorithm spconv's CPU path uses) timed on this
+    box's host cores on a bounded sample: ONE scene of the same workload, forward + loss + backward."""
+    import subprocess
+    cores = usable_cores()
+    for pts, limit in ((points, 150), (max(points // 5, 2000), 90)):
+        code = f'import sys; sys.path.insert(0, {ROOT!r}); import bench; bench._cpu_baseline_child({pts}, {voxel_size}, {cores})'
+        try:
+            res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=limit,
+                                 env=dict(os.environ, OMP_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES=''))
+            dt = json.loads(res.stdout.strip().splitlines()[-1])['seconds']
+        except Exception as e:  # noqa: BLE001  (timeout / parse error -> try the smaller sample)
+            log(f'cpu_baseline sample of {pts} pts failed: {type(e).__name__}')
+            continue
+        return dict(value=1.0 / dt, unit='scenes/s', cores=cores, kind='port',
+                    sample=f'1 scene ({pts} pts, {voxel_size} m voxels) of the bench workload, fwd+loss+bwd, fp32, '
+                           f'{dt:.1f} s with torch CPU threads={cores}' +
+                           ('' if pts == points else f' (reduced from {points} pts to stay inside the time bound)'))
+    return dict(value=None, unit='scenes/s', cores=cores, kind='port', sample='timed out')
+
+
+def log(msg: str):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
 def main():
@@ -101,17 +134,20 @@ def main():
     model.train()
     broadcast_params(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    bucket = FlatGradBucket(params)
+    bucket = FlatGradBucket(params, attach=False)
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)      # configs/unidet3d_1xb8_scannet.py:712
 
+    log(f'rank {rank}/{world}: model built, generating {args.batch} scenes')
     scenes = [make_scene(rank * args.batch + i, n_points=args.points) for i in range(args.batch)]
     inputs, samples = make_batch_inputs(scenes, dev)                              # resident in HBM before timing
 
     def step():
-        bucket.zero()
+        bucket.clear_grads()                 # backward writes fresh grads: no accumulate kernels
         loss = model.loss(inputs, samples)['det_loss']
         loss.backward()
-        bucket.allreduce_mean()
+        if world > 1:
+            bucket.pack()                    # one multi-tensor copy into the flat buffer ...
+            bucket.allreduce_mean()          # ... one RCCL all-reduce of all gradients
         if not args.no_optimizer:
             torch.nn.utils.clip_grad_norm_(params, max_norm=10, norm_type=2, foreach=True)   # configs :713
             opt.step()
@@ -123,9 +159,12 @@ def main():
         torch.cuda.synchronize()
 
     sparse.set_profile_flops(True)      # launches carry their algorithmic flops (pair counts cached during warm-up)
-    for _ in range(max(args.warmup, 1)):
+    log('inputs resident, warm-up')
+    for i in range(max(args.warmup, 1)):
         loss = step()
-    assert bucket.check_views(), 'p.grad no longer aliases the flat gradient buffer'
+        torch.cuda.synchronize()
+        log(f'warm-up step {i} done, loss {float(loss.detach()):.4f}')
+    assert world == 1 or bucket.check_views(), 'p.grad does not alias the flat gradient buffer'
     for c in (L.K_CONV_FWD, L.K_CONV_WGRAD, L.K_ATTN_FWD, L.K_ATTN_BWD):
         L.prof_enable(c, True)
     fence()
@@ -134,6 +173,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step')
     prof = {}
     for name, c in (('conv_gmm', L.K_CONV_FWD), ('conv_wgrad', L.K_CONV_WGRAD), ('attn_fwd', L.K_ATTN_FWD),
                     ('attn_bwd', L.K_ATTN_BWD)):

@@ -167,7 +167,91 @@ class UniDet3DCriterion:
         bbox_loss = torch.stack(bbox_losses).mean() if bbox_losses else 0
         return self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss
 
+    # ---- packed fast path ---------------------------------------------------------------------
+    # Same arithmetic as get_layer_loss, but every scene of the batch goes through ONE set of
+    # [B, n_max, g_max] tensor ops instead of a Python loop of ~70 small kernels per (layer, scene):
+    # the reference's loop (criterion.py:79-134) costs thousands of launches per step on a GPU.
+    def _can_pack(self, pred, insts, datasets_names):
+        if '_packed' not in pred or len(set(datasets_names)) != 1 or not self.iter_matcher:
+            return False
+        if not (isinstance(self.matcher, UniMatcher) and len(self.matcher.costs) == 2 and
+                isinstance(self.matcher.costs[0], QueryClassificationCost) and
+                isinstance(self.matcher.costs[1], BboxCostJointTraining)):
+            return False
+        return all((not i.bboxes_3d.with_yaw) for i in insts) and pred['_packed']['box'][0].shape[-1] == 6
+
+    def _pack_gt(self, insts, sizes, device):
+        B, g_max, n_max = len(insts), max(max(len(i) for i in insts), 1), max(sizes)
+        labels = torch.zeros(B, g_max, dtype=torch.long, device=device)
+        boxes = torch.zeros(B, g_max, 6, device=device)
+        boxes[..., 3:] = 1.0                                   # harmless unit boxes for the padding slots
+        qmask = torch.zeros(B, g_max, n_max, dtype=torch.bool, device=device)
+        for b, inst in enumerate(insts):
+            g = len(inst)
+            if g:
+                labels[b, :g] = inst.labels_3d
+                boxes[b, :g] = _gt_boxes(inst.bboxes_3d)
+                qmask[b, :g, :sizes[b]] = inst.query_masks
+        rows = torch.zeros(B, n_max, dtype=torch.long, device=device)
+        valid = torch.zeros(B, n_max, dtype=torch.bool, device=device)
+        o = 0
+        for b, n in enumerate(sizes):
+            rows[b, :n] = torch.arange(o, o + n, device=device)
+            valid[b, :n] = True
+            o += n
+        has_gt = torch.tensor([len(i) > 0 for i in insts], device=device)
+        return dict(labels=labels, boxes=boxes, qmask=qmask.transpose(1, 2), rows=rows, valid=valid, has_gt=has_gt,
+                    uniform=len(set(sizes)) == 1)
+
+    def _layer_loss_packed(self, cls, box, gt, name):
+        idx = self.datasets.index(name)
+        weight, topk = self.datasets_weights[idx], self.topk[idx]
+        B, n = gt['rows'].shape
+        if gt['uniform']:
+            cls_b, box_b = cls.view(B, n, -1), box.view(B, n, 6)
+        else:
+            cls_b, box_b = cls[gt['rows']], box[gt['rows']]
+        n_cls = cls_b.shape[-1] - 1
+        gtb = _bbox_to_loss(gt['boxes'])[:, None]                                  # [B,1,g,6]
+        with torch.no_grad():                                                      # UniMatcher (criterion.py:286-320)
+            prob = cls_b.softmax(-1)
+            c_cls = -prob.gather(2, gt['labels'][:, None, :].expand(-1, n, -1)) * self.matcher.costs[0].weight
+            pb = _bbox_to_loss(box_b)[:, :, None]                                  # [B,n,1,6]
+            iou_loss = 1 - _aligned_iou_3d(pb, gtb)                                # [B,n,g]
+            pc, tc = (pb[..., :3] + pb[..., 3:]) / 2, (gtb[..., :3] + gtb[..., 3:]) / 2
+            r2 = ((pc - tc) ** 2).sum(-1)
+            c2 = ((torch.minimum(pb[..., :3], gtb[..., :3]) - torch.maximum(pb[..., 3:], gtb[..., 3:])) ** 2).sum(-1)
+            c_box = (iou_loss + (r2 / c2)[:, :, :1]) * self.matcher.costs[1].weight    # the reference's [:, 0] term
+            cost = torch.where(gt['qmask'], c_cls + c_box, cls_b.new_tensor(self.matcher.inf))
+            kth = torch.topk(cost, topk + 1, dim=1, sorted=True, largest=False).values[:, -1:, :]
+            matched = cost < kth                                                   # [B,n,g]
+            g = matched.shape[2]
+            last = (matched * torch.arange(1, g + 1, device=cls.device)).amax(2) - 1   # highest matched gt wins
+            target = torch.where(last >= 0, gt['labels'].gather(1, last.clamp(min=0)), n_cls)
+            cw = cls_b.new_ones(n_cls + 1)
+            cw[-1] = self.non_object_weight
+            w = cw[target] * gt['valid']
+        nll = -torch.log_softmax(cls_b, -1).gather(2, target[..., None])[..., 0]
+        cls_loss = (weight * (nll * w).sum(1) / w.sum(1)).mean()
+        pbx, gbx = _bbox_to_loss(box_b)[:, :, None], gtb
+        diou = 1 - _aligned_iou_3d(pbx, gbx)
+        pc, tc = (pbx[..., :3] + pbx[..., 3:]) / 2, (gbx[..., :3] + gbx[..., 3:]) / 2
+        diou = diou + ((pc - tc) ** 2).sum(-1) / \
+            ((torch.minimum(pbx[..., :3], gbx[..., :3]) - torch.maximum(pbx[..., 3:], gbx[..., 3:])) ** 2).sum(-1)
+        cnt = matched.sum((1, 2))
+        per_scene = (torch.where(matched, diou, diou.new_zeros(())).sum((1, 2)) / cnt.clamp(min=1)) * weight
+        has = (cnt > 0) & gt['has_gt']
+        bbox_loss = (per_scene * has).sum() / has.sum().clamp(min=1)
+        return self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss
+
     def __call__(self, pred, insts, datasets_names):
+        if self._can_pack(pred, insts, datasets_names):
+            pk = pred['_packed']
+            gt = self._pack_gt(insts, pk['sizes'], pk['cls'][0].device)
+            loss = 0
+            for cls, box in zip(pk['cls'], pk['box']):       # final layer + the aux layers, re-matched each
+                loss = loss + self._layer_loss_packed(cls, box, gt, datasets_names[0])
+            return {'det_loss': loss}
         loss = self.get_layer_loss(pred, insts, datasets_names)
         if 'aux_outputs' in pred:
             indices = None        # iter_matcher=True re-matches per layer; the reference leaves `indices`

@@ -16,18 +16,49 @@ import torch.distributed as dist
 
 
 class FlatGradBucket:
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    """One flat fp32 buffer for all parameter gradients.
+
+    ``attach()`` makes every ``p.grad`` a view of the buffer (autograd then accumulates in place);
+    ``pack()`` is the cheaper per-step form: gradients are produced by backward as fresh tensors
+    (``p.grad = None`` beforehand, so no accumulate kernels), copied into the flat buffer with one
+    multi-tensor copy, and ``p.grad`` is re-pointed at the views so the optimizer reads the reduced
+    values."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], attach: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.views = []
         o = 0
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
+        if attach:
+            self.attach()
+
+    def attach(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def zero(self):
         self.flat.zero_()
+
+    def clear_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        self.attach()
 
     def allreduce_mean(self, group=None):
         """Sum over ranks / world size (DDP semantics).  No-op without a process group."""

@@ -52,11 +52,11 @@ def make_scene(scene_idx: int, n_points: int = 100_000, area_scale: float = 1.0,
     """One room. ``area_scale`` multiplies the total surface (cfg5 uses 10)."""
     rng = np.random.default_rng(SEED_BASE + scene_idx)
     s = float(np.sqrt(area_scale))
-    # room ~ 2.2 x 1.8 x 1.2 m at scale 1: floor 3.96 + walls 9.6 -> with
-    # furniture ~14.5 m^2, which gives ~40k occupied 2 cm voxels per 100k pts
-    lx = (2.0 + 0.4 * rng.random()) * s
-    ly = (1.6 + 0.4 * rng.random()) * s
-    lz = 1.1 + 0.2 * rng.random()
+    # room ~ 1.9 x 1.6 x 1.1 m at scale 1: with the furniture shells ~12 m^2 of surface,
+    # which gives ~40k occupied 2 cm voxels per 100k pts (SURVEY.md 8d)
+    lx = (1.75 + 0.35 * rng.random()) * s
+    ly = (1.4 + 0.35 * rng.random()) * s
+    lz = 1.0 + 0.15 * rng.random()
     ex, ey, ez = np.eye(3)
     rects = []   # (origin, e1, e2, instance_id)
     rects.append((np.zeros(3), ex * lx, ey * ly, -1))                    # floor
@@ -65,8 +65,8 @@ def make_scene(scene_idx: int, n_points: int = 100_000, area_scale: float = 1.0,
     rects.append((np.zeros(3), ey * ly, ez * lz, -1))                    # x = 0
     rects.append((ex * lx, ey * ly, ez * lz, -1))                        # x = lx
     for f in range(n_furniture):
-        size = np.array([0.15 + 0.35 * rng.random(), 0.15 + 0.35 * rng.random(),
-                         0.15 + 0.45 * rng.random()]) * np.array([s ** 0.5, s ** 0.5, 1.0])
+        size = np.array([0.15 + 0.3 * rng.random(), 0.15 + 0.3 * rng.random(),
+                         0.15 + 0.4 * rng.random()]) * np.array([s ** 0.5, s ** 0.5, 1.0])
         lo = np.array([rng.random() * (lx - size[0]), rng.random() * (ly - size[1]), 0.0])
         hi = lo + size
         # 5 faces of the shell (no bottom)

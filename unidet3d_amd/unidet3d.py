@@ -108,11 +108,10 @@ class UniDet3D(nn.Module):
         ``instance_ids`` int64 [N] in [-1, n_inst)."""
         if n_inst == 0:
             return DepthInstance3DBoxes(points.new_zeros(0, 6), with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5))
-        m = instance_ids >= 0
-        idx = instance_ids[m].unsqueeze(1).expand(-1, 3)
-        p = points[m]
-        lo = p.new_full((n_inst, 3), float('inf')).scatter_reduce_(0, idx, p, 'amin', include_self=True)
-        hi = p.new_full((n_inst, 3), float('-inf')).scatter_reduce_(0, idx, p, 'amax', include_self=True)
+        # one masked min / max pass per instance set (no atomics: scatter_reduce serialises on ~10 addresses)
+        m = (instance_ids[None, :] == torch.arange(n_inst, device=points.device)[:, None])[:, :, None]
+        lo = torch.where(m, points[None], points.new_tensor(float('inf'))).amin(1)
+        hi = torch.where(m, points[None], points.new_tensor(float('-inf'))).amax(1)
         return DepthInstance3DBoxes(torch.cat(((hi + lo) / 2, hi - lo), 1), with_yaw=False, box_dim=6,
                                     origin=(0.5, 0.5, 0.5))
 

@@ -115,14 +115,19 @@ int u3d_tile_starts(const int32_t* rows, const int32_t* counts, int K, int64_t c
  * w_rows: weights with the DST channel as the row: w[(n*K + k)*Cs + c]  (n<Cd, c<Cs) --
  * spconv's native [C_out,k0,k1,k2,C_in] for forward; u3d_weight_transpose() output for dgrad.
  * scatter lists must be ascending (they are, in both columns); tile_starts from u3d_tile_starts
- * on the scatter lists.  addend (nullable, [n_dst,Cd]) initialises the accumulator
+ * on the scatter lists with the tile height u3d_spconv_plan() returns.  addend (nullable, [n_dst,Cd]) initialises the accumulator
  * (fuses the residual add of ResidualBlock.forward, spconv_unet.py:88-89).
  * Replaces SubMConv3d / SparseConv3d / SparseInverseConv3d forward and their input-gradients.
  * ===================================================================================== */
 int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst,
-                   int tile_rows, const float* addend, float* dst, double flops_hint, u3d_stream_t stream);
-int u3d_spconv_tile_rows(int Cs, int Cd);   /* the tile height the kernel wants for this shape; <0 unsupported */
+                   int tile_rows, int k_groups, const float* addend, float* dst, void* ws, double flops_hint,
+                   u3d_stream_t stream);
+/* Launch plan for a shape: tile_rows (rows per wave-tile = the tile height to pass to u3d_tile_starts) and
+ * k_groups (kernel offsets are split into that many groups when the level has too few rows to fill the chip;
+ * the groups' partial sums go through ws = k_groups*n_dst*Cd*4 bytes and a fixed-order reduce).
+ * Returns U3D_EUNSUPPORTED for channel counts that are not instantiated. */
+int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups);
 /* dW[(n*K+k)*Cs + c] += sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]   (dW must be zeroed by the caller) */
 int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
                      const int32_t* counts, int K, int64_t cap, int Cs, int Cd, float* dW,

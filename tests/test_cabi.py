@@ -44,8 +44,10 @@ def test_pure_size_queries_run_without_gpu():
     from unidet3d_amd import _lib
     l = _lib.lib()
     assert l.u3d_index_words(2, 128, 130, 65) == 2 * 128 * 130 * 2
-    assert l.u3d_spconv_tile_rows(32, 32) in (32, 64, 128, 256)
-    assert l.u3d_spconv_tile_rows(24, 32) < 0            # unsupported channel count is refused
+    R, G = ctypes.c_int(0), ctypes.c_int(0)
+    assert l.u3d_spconv_plan(32, 32, 27, 400000, ctypes.byref(R), ctypes.byref(G)) == 0 and (R.value, G.value) == (64, 1)
+    assert l.u3d_spconv_plan(160, 160, 27, 1400, ctypes.byref(R), ctypes.byref(G)) == 0 and R.value == 32 and G.value > 1
+    assert l.u3d_spconv_plan(24, 32, 27, 1000, ctypes.byref(R), ctypes.byref(G)) < 0     # unsupported channel count is refused
     assert l.u3d_subm_rulebook_ws_bytes(1000) >= 27 * 1000 * 4
 
 

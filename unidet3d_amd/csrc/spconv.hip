@@ -3,18 +3,22 @@
 // MFMA kernel for the weight gradient.  Replaces spconv's implicit-GEMM kernels behind
 // unidet3d/spconv_unet.py:34-72,146-192 and unidet3d/unidet3d.py:96-103.
 //
-// Forward / dgrad (spconv_gmm_k):
-//   * a workgroup (4 wave64) owns a tile of T consecutive DST rows; its fp32 accumulator tile
-//     lives in LDS ([T][Cd+4]), so dst is written exactly once (no global atomics, no per-pair
-//     feature round trip through HBM: algorithmic traffic N*(Cs+Cd)*4 + pair indices + weights).
-//   * the canonical rulebook is the working structure: for offset k the tile's pairs are the
-//     contiguous range tile_starts[k][t] .. tile_starts[k][t+1] of the (ascending) scatter list;
-//     offsets with no pair in the tile are skipped, no padding work on absent neighbours.
-//   * per (offset, channel block): W_k block staged in LDS (double buffered, global loads issued
-//     before the MFMA phase and written to LDS after it); each wave takes 16-pair chunks: gathers
-//     src rows straight into MFMA A fragments (float4 per lane, K-permuted so one 16-byte load
-//     feeds 4 v_mfma_f32_16x16x4_f32), reads B fragments with ds_read_b128 and scatters the
-//     16x16 results into the LDS accumulator with ds_add_f32.
+// Forward / dgrad (spconv_gmm_k), wave-independent design (no workgroup barriers at all):
+//   * every wave64 owns R (32 or 64) consecutive DST rows x a 32-column slice of the output and,
+//     optionally, one of G groups of kernel offsets; its fp32 accumulator tile [R][36] is private
+//     LDS, so dst is written exactly once per (row, column) -- no global atomics, no per-pair
+//     feature round trip through HBM (algorithmic traffic N*(Cs+Cd)*4 + pair indices + weights).
+//   * the canonical rulebook is the working structure: for offset k the wave's pairs are the
+//     contiguous range tile_starts[k][t] .. tile_starts[k][t+1] of the ascending scatter list;
+//     offsets without a pair in the tile cost two scalar loads, absent neighbours cost nothing.
+//   * per offset the wave takes 16-pair chunks two at a time: gathers the src rows straight into
+//     MFMA A fragments (one float4 per lane, K-permuted so a 16-byte load feeds four
+//     v_mfma_f32_16x16x4_f32), reads the B fragments W_k[n][c..c+3] with one float4 per lane from
+//     L2 (weights are [n][k][c], so the fragment is contiguous) shared by both chunks, accumulates
+//     over all source channels in registers and adds the 16x32 results into LDS with ds_add_f32.
+//   * 4 independent waves per workgroup, 16-18 KB LDS per wave-tile -> up to 16 waves per CU hide the
+//     gather latency; deep U-Net levels (a few thousand rows) get their parallelism from column
+//     slices and offset groups (partials summed by a small deterministic reduce kernel).
 //   * fp32 in / fp32 accumulate MFMA (exact fp32, 157 TF peak) -- BASELINE config 2 is fp32.
 #include "u3d_common.h"
 
@@ -29,177 +33,146 @@ struct GmmParams {
     const int32_t* scatter;
     const int32_t* ts;
     const float* addend;
-    float* dst;
+    float* out;          // dst, or the partial buffer [G][n_dst][Cd] when G > 1
     int K;
     int64_t cap;
-    int Cs;
+    int Cs, Cd;
     int64_t n_dst;
-    int T;
-    int64_t n_tiles;
-    int ncb;
+    int64_t n_sub;
+    int n_slices;
+    int G;
+    int kper;
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int CB, int CD16>
-__device__ __forceinline__ void gmm_gload(float4 (&pf)[(CD16 * 16 * CB * 4 + 255) / 256], const GmmParams& p, int k, int cb, int tid) {
-    constexpr int W4 = CD16 * 16 * CB * 4, NPF = (W4 + 255) / 256;
-#pragma unroll
-    for (int j = 0; j < NPF; ++j) {
-        const int idx = (NPF * 256 == W4) ? tid + j * 256 : min(tid + j * 256, W4 - 1);   // clamped: always defined
-        const int n = idx / (CB * 4), c4 = idx % (CB * 4);
-        pf[j] = *reinterpret_cast<const float4*>(p.w + ((int64_t)n * p.K + k) * p.Cs + cb * (CB * 16) + c4 * 4);
-    }
-}
-template <int CB, int CD16>
-__device__ __forceinline__ void gmm_lstore(const float4 (&pf)[(CD16 * 16 * CB * 4 + 255) / 256], float* wb, int tid) {
-    constexpr int W4 = CD16 * 16 * CB * 4, NPF = (W4 + 255) / 256, WLD = CB * 16 + 4;
-#pragma unroll
-    for (int j = 0; j < NPF; ++j) {
-        const int idx = tid + j * 256;
-        if (NPF * 256 == W4 || idx < W4) {
-            const int n = idx / (CB * 4), c4 = idx % (CB * 4);
-            *reinterpret_cast<float4*>(wb + n * WLD + c4 * 4) = pf[j];
-        }
-    }
-}
+constexpr int GMM_CDS = 32;            // output columns per wave
+constexpr int GMM_ALD = GMM_CDS + 4;   // padded accumulator row
 
-template <int CB, int CD16>
+template <int CS16, int R>
 __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
-    constexpr int CD = CD16 * 16, CBW = CB * 16, WLD = CBW + 4, ALD = CD + 4;
-    constexpr int W4 = CD * CB * 4;                  // float4 per staged weight block
-    constexpr int NPF = (W4 + 255) / 256;            // float4 per thread
+    constexpr int JB = CS16 <= 8 ? CS16 : CS16 / 2;     // 16-channel groups held in registers at a time
+    constexpr int NJB = CS16 / JB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* acc = smem;
-    float* wbuf = smem + (size_t)p.T * ALD;
-    int* s_act = reinterpret_cast<int*>(wbuf + 2 * CD * WLD);   // [32] active offsets, [32] = count
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
-    const int64_t t = blockIdx.x;
-    const int64_t tile_base = t * p.T;
-    const int rows = (int)min((int64_t)p.T, p.n_dst - tile_base);
-    const int64_t tsld = p.n_tiles + 1;
+    float* acc = smem + wave * (R * GMM_ALD);
 
-    // ---- accumulator init (zeros or the fused residual addend) ----
-    for (int idx = tid; idx < rows * (CD / 4); idx += 256) {
-        const int r = idx / (CD / 4), c4 = idx % (CD / 4);
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int per_sub = p.n_slices * p.G;
+    const int64_t sub = wid / per_sub;
+    if (sub >= p.n_sub) return;                      // wave-uniform; there are no barriers in this kernel
+    const int rem = (int)(wid % per_sub);
+    const int slice = rem / p.G, g = rem % p.G;
+    const int n0 = slice * GMM_CDS;
+    const int64_t row0 = sub * R;
+    const int rows = (int)min((int64_t)R, p.n_dst - row0);
+    const int64_t tsld = p.n_sub + 1;
+
+    // ---- accumulator init: zeros, or the fused residual addend (single offset group only) ----
+    for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
+        const int r = idx >> 3, c4 = idx & 7;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.addend) v = *reinterpret_cast<const float4*>(p.addend + (tile_base + r) * CD + c4 * 4);
-        *reinterpret_cast<float4*>(acc + r * ALD + c4 * 4) = v;
+        if (p.addend && p.G == 1) v = *reinterpret_cast<const float4*>(p.addend + (row0 + r) * p.Cd + n0 + c4 * 4);
+        *reinterpret_cast<float4*>(acc + r * GMM_ALD + c4 * 4) = v;
     }
-    // ---- offsets that have at least one pair in this tile ----
-    if (wave == 0) {
-        bool act = false;
-        if (lane < p.K) act = p.ts[lane * tsld + t + 1] > p.ts[lane * tsld + t];
-        const unsigned long long m = __ballot(act);
-        if (act) s_act[__popcll(m & ((1ull << lane) - 1ull))] = lane;
-        if (lane == 0) s_act[32] = __popcll(m);
-    }
-    __syncthreads();
-    const int n_units = s_act[32] * p.ncb;
 
-    float4 pf[NPF];
-    if (n_units > 0) {
-        gmm_gload<CB, CD16>(pf, p, s_act[0], 0, tid);
-        gmm_lstore<CB, CD16>(pf, wbuf, tid);
-    }
-    for (int u = 0; u < n_units; ++u) {
-        __syncthreads();
-        {   // unconditional prefetch of the next block (the last iteration re-reads its own: harmless)
-            const int un = min(u + 1, n_units - 1);
-            gmm_gload<CB, CD16>(pf, p, s_act[un / p.ncb], un % p.ncb, tid);
-        }
-        {
-            const int k = s_act[u / p.ncb], cb = u % p.ncb;
-            const float* wb = wbuf + (u & 1) * (CD * WLD);
-            const int s = p.ts[k * tsld + t], e = p.ts[k * tsld + t + 1];
-            const int32_t* gl = p.gather + (int64_t)k * p.cap;
-            const int32_t* sl = p.scatter + (int64_t)k * p.cap;
-            const int nchunk = (e - s + 15) >> 4;
-            for (int c = wave; c < nchunk; c += 4) {
-                const int base = s + c * 16;
-                const int g = (base + i16 < e) ? gl[base + i16] : -1;
-                float4 a[CB];
+    const int k_lo = g * p.kper, k_hi = min(p.K, k_lo + p.kper);
+    for (int k = k_lo; k < k_hi; ++k) {
+        const int s = p.ts[k * tsld + sub], e = p.ts[k * tsld + sub + 1];
+        if (s == e) continue;
+        const int32_t* gl = p.gather + (int64_t)k * p.cap;
+        const int32_t* sl = p.scatter + (int64_t)k * p.cap;
+        const float* wk = p.w + ((int64_t)(n0 + i16) * p.K + k) * p.Cs + q * 4;     // this lane's B row, 16 cols apart per nb
+        for (int base = s; base < e; base += 32) {
+            const bool two = base + 16 < e;
+            const int g0 = (base + i16 < e) ? gl[base + i16] : -1;
+            const int g1 = (two && base + 16 + i16 < e) ? gl[base + 16 + i16] : -1;
+            int srow0[4], srow1[4];
 #pragma unroll
-                for (int j = 0; j < CB; ++j) {
-                    a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g >= 0) a[j] = *reinterpret_cast<const float4*>(p.src + (int64_t)g * p.Cs + cb * CBW + j * 16 + q * 4);
-                }
-                int srow[4];
+            for (int r = 0; r < 4; ++r) {
+                const int i0 = base + q * 4 + r, i1 = i0 + 16;
+                srow0[r] = i0 < e ? (int)(sl[i0] - row0) : -1;
+                srow1[r] = (two && i1 < e) ? (int)(sl[i1] - row0) : -1;
+            }
+            f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = base + q * 4 + r;
-                    srow[r] = idx < e ? (int)(sl[idx] - tile_base) : -1;
+            for (int jb = 0; jb < NJB; ++jb) {
+                float4 a0[JB], a1[JB];
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    a0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    a1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g0 >= 0) a0[j] = *reinterpret_cast<const float4*>(p.src + (int64_t)g0 * p.Cs + (jb * JB + j) * 16 + q * 4);
+                    if (g1 >= 0) a1[j] = *reinterpret_cast<const float4*>(p.src + (int64_t)g1 * p.Cs + (jb * JB + j) * 16 + q * 4);
                 }
 #pragma unroll
-                for (int nb = 0; nb < CD16; nb += 2) {
-                    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+                for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
-                    for (int j = 0; j < CB; ++j) {
-                        const float4 b0 = *reinterpret_cast<const float4*>(wb + (nb * 16 + i16) * WLD + j * 16 + q * 4);
-                        const float4 b1 = *reinterpret_cast<const float4*>(wb + ((nb + 1) * 16 + i16) * WLD + j * 16 + q * 4);
-                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0.x, d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1.x, d1, 0, 0, 0);
-                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0.y, d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b1.y, d1, 0, 0, 0);
-                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0.z, d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1.z, d1, 0, 0, 0);
-                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, d1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (srow[r] >= 0) {
-                            lds_add(acc + srow[r] * ALD + nb * 16 + i16, d0[r]);
-                            lds_add(acc + srow[r] * ALD + (nb + 1) * 16 + i16, d1[r]);
+                    for (int j = 0; j < JB; ++j) {
+                        const float4 b = *reinterpret_cast<const float4*>(wk + (int64_t)nb * 16 * p.K * p.Cs + (jb * JB + j) * 16);
+                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].x, b.x, d0[nb], 0, 0, 0);
+                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].y, b.y, d0[nb], 0, 0, 0);
+                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].z, b.z, d0[nb], 0, 0, 0);
+                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].w, b.w, d0[nb], 0, 0, 0);
+                        if (two) {
+                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].x, b.x, d1[nb], 0, 0, 0);
+                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].y, b.y, d1[nb], 0, 0, 0);
+                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].z, b.z, d1[nb], 0, 0, 0);
+                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].w, b.w, d1[nb], 0, 0, 0);
                         }
                     }
                 }
             }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (srow0[r] >= 0) lds_add(acc + srow0[r] * GMM_ALD + nb * 16 + i16, d0[nb][r]);
+                    if (srow1[r] >= 0) lds_add(acc + srow1[r] * GMM_ALD + nb * 16 + i16, d1[nb][r]);
+                }
         }
-        gmm_lstore<CB, CD16>(pf, wbuf + ((u + 1) & 1) * (CD * WLD), tid);
     }
-    __syncthreads();
-    for (int idx = tid; idx < rows * (CD / 4); idx += 256) {
-        const int r = idx / (CD / 4), c4 = idx % (CD / 4);
-        *reinterpret_cast<float4*>(p.dst + (tile_base + r) * CD + c4 * 4) =
-            *reinterpret_cast<const float4*>(acc + r * ALD + c4 * 4);
+    float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
+    for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
+        const int r = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<float4*>(out + (row0 + r) * p.Cd + n0 + c4 * 4) = *reinterpret_cast<const float4*>(acc + r * GMM_ALD + c4 * 4);
     }
 }
 
-// channel blocking: CB 16-column groups of the source per staged weight block
-static int pick_cb(int Cs, int Cd) {
-    const int cs16 = Cs / 16;
-    const int cands[4] = {8, 4, 2, 1};
-    for (int c : cands) {
-        if (cs16 % c) continue;
-        if ((int64_t)Cd * (16 * c + 4) <= 6000) return c;
+// dst = sum_g partial[g] (+ addend), fixed summation order
+__global__ __launch_bounds__(256) void gmm_reduce_k(const float* __restrict__ partial, int G, int64_t n4, const float* __restrict__ addend,
+                                                    float* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = addend ? reinterpret_cast<const float4*>(addend)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < G; ++g) {
+            const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)g * n4 + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        reinterpret_cast<float4*>(dst)[i] = v;
     }
-    return 1;
-}
-static int64_t gmm_lds_bytes(int CB, int Cd, int T) {
-    return ((int64_t)T * (Cd + 4) + 2 * (int64_t)Cd * (CB * 16 + 4)) * 4 + 33 * 4 + 16;
-}
-static int pick_tile(int Cs, int Cd) {
-    const int CB = pick_cb(Cs, Cd);
-    const int cands[4] = {256, 128, 64, 32};
-    for (int T : cands)
-        if (gmm_lds_bytes(CB, Cd, T) <= 80 * 1024) return T;
-    return gmm_lds_bytes(CB, Cd, 32) <= 160 * 1024 ? 32 : -1;
 }
 
-template <int CB, int CD16>
+// rows per wave-tile and offset groups: aim at >= 2 waves per SIMD on 256 CUs x 4 SIMDs
+static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
+    const int slices = Cd / GMM_CDS;
+    const int64_t want = 2048;
+    int r = 64, g = 1;
+    if (ceil_div(n_dst, 64) * slices < want) r = 32;
+    const int64_t waves = ceil_div(n_dst, r) * slices;
+    if (waves < want && K >= 27) g = waves * 3 >= want ? 3 : 9;
+    *R = r;
+    *G = g;
+}
+
+template <int CS16, int R>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
-    const size_t lds = (size_t)gmm_lds_bytes(CB, CD16 * 16, p.T);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_gmm_k<CB, CD16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((spconv_gmm_k<CB, CD16>), dim3((unsigned)p.n_tiles), dim3(256), lds, s, p);
+    const size_t lds = (size_t)4 * R * GMM_ALD * sizeof(float);
+    const int64_t waves = p.n_sub * p.n_slices * p.G;
+    hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");
 }
 
@@ -328,37 +301,45 @@ using namespace u3d;
 
 extern "C" {
 
-int u3d_spconv_tile_rows(int Cs, int Cd) {
-    if (Cs % 16 || Cd % 32 || Cs <= 0 || Cd <= 0 || Cd > 256 || Cs > 256) return U3D_EUNSUPPORTED;
-    return pick_tile(Cs, Cd);
+int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups) {
+    if (Cs % 16 || Cd % 32 || Cs <= 0 || Cd <= 0 || Cd > 256 || Cs > 256 || K <= 0 || K > 32 || n_dst <= 0 || !tile_rows || !k_groups)
+        return U3D_EUNSUPPORTED;
+    const int cs16 = Cs / 16;
+    if (!(cs16 == 1 || cs16 == 2 || cs16 == 4 || cs16 == 6 || cs16 == 8 || cs16 == 10 || cs16 == 12 || cs16 == 16)) return U3D_EUNSUPPORTED;
+    plan_gmm(Cs, Cd, K, n_dst, tile_rows, k_groups);
+    return U3D_OK;
 }
 
 int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
-                   const float* addend, float* dst, double flops_hint, u3d_stream_t stream) {
+                   int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
     if (!src || !w_rows || !gather || !scatter || !tile_starts || !dst || K <= 0 || K > 32 || n_dst <= 0) return U3D_EINVAL;
-    if (Cs % 16 || Cd % 32 || tile_rows != pick_tile(Cs, Cd)) {
-        set_error("spconv_gmm: unsupported Cs=%d Cd=%d tile=%d", Cs, Cd, tile_rows);
+    int R = 0, G = 0;
+    if (u3d_spconv_plan(Cs, Cd, K, n_dst, &R, &G) != U3D_OK || R != tile_rows || G != k_groups || (G > 1 && !ws)) {
+        set_error("spconv_gmm: unsupported Cs=%d Cd=%d or plan mismatch (tile %d/%d groups %d/%d)", Cs, Cd, tile_rows, R, k_groups, G);
         return U3D_EUNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_CONV_FWD, s, flops_hint);
     GmmParams p;
-    p.src = src; p.w = w_rows; p.gather = gather; p.scatter = scatter; p.ts = tile_starts; p.addend = addend; p.dst = dst;
-    p.K = K; p.cap = cap; p.Cs = Cs; p.n_dst = n_dst; p.T = tile_rows; p.n_tiles = ceil_div(n_dst, tile_rows);
-    const int CB = pick_cb(Cs, Cd);
-    p.ncb = Cs / (CB * 16);
-    const int cd16 = Cd / 16;
-#define U3D_GMM_CASE(cb, cd) if (CB == cb && cd16 == cd) return launch_gmm<cb, cd>(p, s);
-    U3D_GMM_CASE(1, 2) U3D_GMM_CASE(2, 2) U3D_GMM_CASE(4, 2) U3D_GMM_CASE(8, 2)
-    U3D_GMM_CASE(1, 4) U3D_GMM_CASE(2, 4) U3D_GMM_CASE(4, 4)
-    U3D_GMM_CASE(1, 6) U3D_GMM_CASE(2, 6)
-    U3D_GMM_CASE(1, 8) U3D_GMM_CASE(2, 8)
-    U3D_GMM_CASE(1, 10) U3D_GMM_CASE(2, 10)
-    U3D_GMM_CASE(1, 12) U3D_GMM_CASE(1, 16)
+    p.src = src; p.w = w_rows; p.gather = gather; p.scatter = scatter; p.ts = tile_starts; p.addend = addend;
+    p.out = G > 1 ? (float*)ws : dst;
+    p.K = K; p.cap = cap; p.Cs = Cs; p.Cd = Cd; p.n_dst = n_dst; p.n_sub = ceil_div(n_dst, R);
+    p.n_slices = Cd / GMM_CDS; p.G = G; p.kper = (int)ceil_div(K, G);
+    const int cs16 = Cs / 16;
+    int rc = U3D_EUNSUPPORTED;
+#define U3D_GMM_CASE(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64>(p, s) : launch_gmm<cs, 32>(p, s);
+    U3D_GMM_CASE(1) U3D_GMM_CASE(2) U3D_GMM_CASE(4) U3D_GMM_CASE(6) U3D_GMM_CASE(8) U3D_GMM_CASE(10) U3D_GMM_CASE(12) U3D_GMM_CASE(16)
 #undef U3D_GMM_CASE
-    set_error("spconv_gmm: no instantiation for CB=%d Cd=%d", CB, Cd);
-    return U3D_EUNSUPPORTED;
+    if (rc != U3D_OK) return rc;
+    if (G > 1) {
+        const int64_t n4 = n_dst * Cd / 4;
+        int64_t grid = ceil_div(n4, 256);
+        grid = grid > 2048 ? 2048 : grid;
+        hipLaunchKernelGGL(gmm_reduce_k, dim3((unsigned)grid), dim3(256), 0, s, (const float*)ws, G, n4, addend, dst);
+        rc = check_launch("gmm_reduce");
+    }
+    return rc;
 }
 
 int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,

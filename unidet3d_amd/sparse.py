@@ -138,20 +138,24 @@ def build_down_rulebook(coords: torch.Tensor, B: int, shape):
 # ----------------------------------------------------------------------------------------
 # convolution (forward / dgrad / wgrad through the C ABI)
 # ----------------------------------------------------------------------------------------
-def _gmm(src, w_rows, gather, scatter, ts, K, cap, n_dst, T, addend, flops):
+def _plan(Cs, Cd, K, n_dst):
+    """(rows per wave-tile, offset groups) the kernel wants for this shape."""
+    import ctypes
+    R, G = ctypes.c_int(0), ctypes.c_int(0)
+    if n_dst <= 0 or L.lib().u3d_spconv_plan(Cs, Cd, K, n_dst, ctypes.byref(R), ctypes.byref(G)) != 0:
+        raise L.U3DError(f'sparse conv: channel combination {Cs}->{Cd} unsupported by the gfx950 kernels')
+    return R.value, G.value
+
+
+def _gmm(src, w_rows, rb, gather, scatter, role, n_dst, addend, flops):
     Cs, Cd = src.shape[1], w_rows.shape[0]
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     if n_dst:
-        L.call('u3d_spconv_gmm', L.ptr(src), L.ptr(w_rows), L.ptr(gather), L.ptr(scatter), L.ptr(ts), K, cap, Cs, Cd,
-               n_dst, T, L.ptr(addend), L.ptr(dst), float(flops), L.stream())
+        R, G = _plan(Cs, Cd, rb.K, n_dst)
+        ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
+        L.call('u3d_spconv_gmm', L.ptr(src), L.ptr(w_rows), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
+               rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
     return dst
-
-
-def _tile(Cs, Cd):
-    T = L.lib().u3d_spconv_tile_rows(Cs, Cd)
-    if T <= 0:
-        raise L.U3DError(f'sparse conv: channel combination {Cs}->{Cd} unsupported by the gfx950 kernels')
-    return T
 
 
 _PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops
@@ -175,10 +179,8 @@ class _SparseConvFn(torch.autograd.Function):
             g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
         else:
             g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
-        T = _tile(cin, cout)
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
-        dst = _gmm(src, w, g, s, rb.tile_starts(role, T), rb.K, rb.cap, n_dst, T,
-                   None if addend is None else addend.contiguous(), flops)
+        dst = _gmm(src, w, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops)
         ctx.save_for_backward(src, weight)
         ctx.rb, ctx.mode, ctx.has_addend = rb, mode, addend is not None
         return dst
@@ -198,8 +200,7 @@ class _SparseConvFn(torch.autograd.Function):
                 g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
             else:
                 g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
-            T = _tile(cout, cin)
-            dsrc = _gmm(dout, wt, g, s, rb.tile_starts(role, T), rb.K, rb.cap, n_dst, T, None, flops)
+            dsrc = _gmm(dout, wt, rb, g, s, role, n_dst, None, flops)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight)
             rx, rg = (rb.pair_in, rb.pair_out) if mode == 'fwd' else (rb.pair_out, rb.pair_in)

@@ -51,14 +51,89 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 constexpr int GMM_CDS = 32;            // output columns per wave
 constexpr int GMM_ALD = GMM_CDS + 4;   // padded accumulator row
 
-template <int CS16, int R>
-__global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
+// one or two 16-pair chunks of offset k: gather -> MFMA over all source channels -> scatter-add into LDS
+template <int CS16, bool TWO, int TRASH>
+__device__ __forceinline__ void gmm_chunks(const GmmParams& p, const int32_t* __restrict__ gl, const int32_t* __restrict__ sl,
+                                           const float* __restrict__ wk, int base, int e, int64_t row0, float* acc, int i16, int q) {
     constexpr int JB = CS16 <= 8 ? CS16 : CS16 / 2;     // 16-channel groups held in registers at a time
     constexpr int NJB = CS16 / JB;
+    // every load is unconditional (indices clamped into the range): lanes past the end compute garbage
+    // rows that are simply never scattered, and no load waits on a branch.
+    const int last = e - 1;
+    const int g0 = gl[min(base + i16, last)];
+    const int g1 = TWO ? gl[min(base + 16 + i16, last)] : 0;
+    int srow0[4], srow1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i0 = base + q * 4 + r, i1 = i0 + 16;
+        srow0[r] = sl[min(i0, last)];
+        srow1[r] = TWO ? sl[min(i1, last)] : 0;
+    }
+    // keep the compiler from sinking the index loads into the validity branches below (it would then
+    // wait for each of them separately): the asm makes every loaded value live here.
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(srow0[r]), "+v"(srow1[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i0 = base + q * 4 + r, i1 = i0 + 16;
+        srow0[r] = i0 < e ? (int)(srow0[r] - row0) : TRASH;        // lanes past the end add into a scratch row
+        srow1[r] = (TWO && i1 < e) ? (int)(srow1[r] - row0) : TRASH;
+    }
+    f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float* a0p = p.src + (int64_t)g0 * p.Cs + q * 4;
+    const float* a1p = p.src + (int64_t)g1 * p.Cs + q * 4;
+    const int64_t nbs = (int64_t)16 * p.K * p.Cs;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+        float4 a0[JB], a1[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            a0[j] = *reinterpret_cast<const float4*>(a0p + (jb * JB + j) * 16);
+            if (TWO) a1[j] = *reinterpret_cast<const float4*>(a1p + (jb * JB + j) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const float4 b0 = *reinterpret_cast<const float4*>(wk + (jb * JB + j) * 16);
+            const float4 b1 = *reinterpret_cast<const float4*>(wk + nbs + (jb * JB + j) * 16);
+            // independent accumulator chains interleaved (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
+#define U3D_STEP(c)                                                                          \
+    d0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].c, b0.c, d0[0], 0, 0, 0);             \
+    d0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].c, b1.c, d0[1], 0, 0, 0);             \
+    if (TWO) {                                                                               \
+        d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].c, b0.c, d1[0], 0, 0, 0);         \
+        d1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].c, b1.c, d1[1], 0, 0, 0);         \
+    }
+            U3D_STEP(x) U3D_STEP(y) U3D_STEP(z) U3D_STEP(w)
+#undef U3D_STEP
+        }
+    }
+    // scatter: the accumulator tile is private to this wave and, inside one offset, every destination row
+    // occurs at most once -> a plain LDS read-modify-write is exact (ds_add_f32 atomics measured ~10x slower:
+    // SQ_WAIT_INST_LDS was 83 % of all wave cycles with them).
+    float o0[2][4], o1[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[nb][r] = acc[srow0[r] * GMM_ALD + nb * 16 + i16];
+            if (TWO) o1[nb][r] = acc[srow1[r] * GMM_ALD + nb * 16 + i16];
+        }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[srow0[r] * GMM_ALD + nb * 16 + i16] = o0[nb][r] + d0[nb][r];
+            if (TWO) acc[srow1[r] * GMM_ALD + nb * 16 + i16] = o1[nb][r] + d1[nb][r];
+        }
+}
+
+template <int CS16, int R>
+__global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
-    float* acc = smem + wave * (R * GMM_ALD);
+    float* acc = smem + wave * ((R + 1) * GMM_ALD);      // R rows + one scratch row
 
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const int per_sub = p.n_slices * p.G;
@@ -80,61 +155,22 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     }
 
     const int k_lo = g * p.kper, k_hi = min(p.K, k_lo + p.kper);
+    // all (start, end) ranges of this wave's offsets in one round trip: lane k holds offset k's range
+    int ts_s = 0, ts_e = 0;
+    if (lane < p.K) {
+        ts_s = p.ts[lane * tsld + sub];
+        ts_e = p.ts[lane * tsld + sub + 1];
+    }
     for (int k = k_lo; k < k_hi; ++k) {
-        const int s = p.ts[k * tsld + sub], e = p.ts[k * tsld + sub + 1];
+        const int s = __builtin_amdgcn_readfirstlane(__shfl(ts_s, k, 64));     // wave-uniform -> scalar control flow
+        const int e = __builtin_amdgcn_readfirstlane(__shfl(ts_e, k, 64));
         if (s == e) continue;
         const int32_t* gl = p.gather + (int64_t)k * p.cap;
         const int32_t* sl = p.scatter + (int64_t)k * p.cap;
-        const float* wk = p.w + ((int64_t)(n0 + i16) * p.K + k) * p.Cs + q * 4;     // this lane's B row, 16 cols apart per nb
-        for (int base = s; base < e; base += 32) {
-            const bool two = base + 16 < e;
-            const int g0 = (base + i16 < e) ? gl[base + i16] : -1;
-            const int g1 = (two && base + 16 + i16 < e) ? gl[base + 16 + i16] : -1;
-            int srow0[4], srow1[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i0 = base + q * 4 + r, i1 = i0 + 16;
-                srow0[r] = i0 < e ? (int)(sl[i0] - row0) : -1;
-                srow1[r] = (two && i1 < e) ? (int)(sl[i1] - row0) : -1;
-            }
-            f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int jb = 0; jb < NJB; ++jb) {
-                float4 a0[JB], a1[JB];
-#pragma unroll
-                for (int j = 0; j < JB; ++j) {
-                    a0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    a1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g0 >= 0) a0[j] = *reinterpret_cast<const float4*>(p.src + (int64_t)g0 * p.Cs + (jb * JB + j) * 16 + q * 4);
-                    if (g1 >= 0) a1[j] = *reinterpret_cast<const float4*>(p.src + (int64_t)g1 * p.Cs + (jb * JB + j) * 16 + q * 4);
-                }
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-                    for (int j = 0; j < JB; ++j) {
-                        const float4 b = *reinterpret_cast<const float4*>(wk + (int64_t)nb * 16 * p.K * p.Cs + (jb * JB + j) * 16);
-                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].x, b.x, d0[nb], 0, 0, 0);
-                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].y, b.y, d0[nb], 0, 0, 0);
-                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].z, b.z, d0[nb], 0, 0, 0);
-                        d0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].w, b.w, d0[nb], 0, 0, 0);
-                        if (two) {
-                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].x, b.x, d1[nb], 0, 0, 0);
-                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].y, b.y, d1[nb], 0, 0, 0);
-                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].z, b.z, d1[nb], 0, 0, 0);
-                            d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].w, b.w, d1[nb], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (srow0[r] >= 0) lds_add(acc + srow0[r] * GMM_ALD + nb * 16 + i16, d0[nb][r]);
-                    if (srow1[r] >= 0) lds_add(acc + srow1[r] * GMM_ALD + nb * 16 + i16, d1[nb][r]);
-                }
-        }
+        const float* wk = p.w + ((int64_t)(n0 + i16) * p.K + k) * p.Cs + q * 4;     // this lane's B row; +16 rows for the 2nd column block
+        int base = s;
+        for (; base + 16 < e; base += 32) gmm_chunks<CS16, true, R>(p, gl, sl, wk, base, e, row0, acc, i16, q);
+        if (base < e) gmm_chunks<CS16, false, R>(p, gl, sl, wk, base, e, row0, acc, i16, q);
     }
     float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
     for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
@@ -170,7 +206,7 @@ static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
 
 template <int CS16, int R>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
-    const size_t lds = (size_t)4 * R * GMM_ALD * sizeof(float);
+    const size_t lds = (size_t)4 * (R + 1) * GMM_ALD * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
     hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");

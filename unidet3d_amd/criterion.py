@@ -19,9 +19,12 @@ from .structures import InstanceData_
 
 def _aligned_iou_3d(b1, b2, eps=1e-6):
     """mmdet3d AxisAlignedBboxOverlaps3D(is_aligned=True) on (x1,y1,z1,x2,y2,z2)."""
-    vol1 = (b1[..., 3:] - b1[..., :3]).prod(-1)
-    vol2 = (b2[..., 3:] - b2[..., :3]).prod(-1)
-    inter = (torch.min(b1[..., 3:], b2[..., 3:]) - torch.max(b1[..., :3], b2[..., :3])).clamp(min=0).prod(-1)
+    d1 = b1[..., 3:] - b1[..., :3]
+    d2 = b2[..., 3:] - b2[..., :3]
+    wh = (torch.min(b1[..., 3:], b2[..., 3:]) - torch.max(b1[..., :3], b2[..., :3])).clamp(min=0)
+    vol1 = d1[..., 0] * d1[..., 1] * d1[..., 2]          # explicit products: .prod()'s backward is a scan kernel
+    vol2 = d2[..., 0] * d2[..., 1] * d2[..., 2]
+    inter = wh[..., 0] * wh[..., 1] * wh[..., 2]
     union = torch.max(vol1 + vol2 - inter, inter.new_tensor([eps]))
     return inter / union
 
@@ -192,13 +195,12 @@ class UniDet3DCriterion:
                 labels[b, :g] = inst.labels_3d
                 boxes[b, :g] = _gt_boxes(inst.bboxes_3d)
                 qmask[b, :g, :sizes[b]] = inst.query_masks
-        rows = torch.zeros(B, n_max, dtype=torch.long, device=device)
         valid = torch.zeros(B, n_max, dtype=torch.bool, device=device)
-        o = 0
+        dest = []
         for b, n in enumerate(sizes):
-            rows[b, :n] = torch.arange(o, o + n, device=device)
             valid[b, :n] = True
-            o += n
+            dest.append(torch.arange(b * n_max, b * n_max + n, device=device))
+        rows = torch.cat(dest)                                  # packed row -> slot in the padded batch
         has_gt = torch.tensor([len(i) > 0 for i in insts], device=device)
         return dict(labels=labels, boxes=boxes, qmask=qmask.transpose(1, 2), rows=rows, valid=valid, has_gt=has_gt,
                     uniform=len(set(sizes)) == 1)
@@ -206,11 +208,14 @@ class UniDet3DCriterion:
     def _layer_loss_packed(self, cls, box, gt, name):
         idx = self.datasets.index(name)
         weight, topk = self.datasets_weights[idx], self.topk[idx]
-        B, n = gt['rows'].shape
+        B, n = gt['valid'].shape
         if gt['uniform']:
             cls_b, box_b = cls.view(B, n, -1), box.view(B, n, 6)
-        else:
-            cls_b, box_b = cls[gt['rows']], box[gt['rows']]
+        else:       # index_copy into the padded layout: its backward is an index_select (no scatter-add kernel)
+            cls_b = cls.new_zeros(B * n, cls.shape[1]).index_copy(0, gt['rows'], cls).view(B, n, -1)
+            pad_box = box.new_zeros(B * n, 6)
+            pad_box[:, 3:] = 1.0
+            box_b = pad_box.index_copy(0, gt['rows'], box).view(B, n, 6)
         n_cls = cls_b.shape[-1] - 1
         gtb = _bbox_to_loss(gt['boxes'])[:, None]                                  # [B,1,g,6]
         with torch.no_grad():                                                      # UniMatcher (criterion.py:286-320)

@@ -28,22 +28,39 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
             sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
             sf = *reinterpret_cast<const float4*>(shift + c4 * 4);
         }
-        for (int64_t r = (int64_t)blockIdx.x * rpb + slot; r < n; r += (int64_t)gridDim.x * rpb) {
-            const float4 v = *reinterpret_cast<const float4*>(x + r * C + c4 * 4);
-            if (MODE == 0) {
-                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-                b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
-            } else {
-                float4 g = *reinterpret_cast<const float4*>(dy + r * C + c4 * 4);
-                if (relu) {
-                    if (!(v.x * sc.x + sf.x > 0.f)) g.x = 0.f;
-                    if (!(v.y * sc.y + sf.y > 0.f)) g.y = 0.f;
-                    if (!(v.z * sc.z + sf.z > 0.f)) g.z = 0.f;
-                    if (!(v.w * sc.w + sf.w > 0.f)) g.w = 0.f;
+        // 4 rows per trip: four independent 16-byte loads in flight per lane hide the HBM latency
+        const int64_t stride = (int64_t)gridDim.x * rpb;
+        for (int64_t r0 = (int64_t)blockIdx.x * rpb + slot; r0 < n; r0 += 4 * stride) {
+            float4 v4[4], g4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t r = r0 + u * stride;
+                v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                g4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < n) {
+                    v4[u] = *reinterpret_cast<const float4*>(x + r * C + c4 * 4);
+                    if (MODE == 1) g4[u] = *reinterpret_cast<const float4*>(dy + r * C + c4 * 4);
                 }
-                a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
-                b[0] += (double)g.x * ((v.x - mu.x) * is.x); b[1] += (double)g.y * ((v.y - mu.y) * is.y);
-                b[2] += (double)g.z * ((v.z - mu.z) * is.z); b[3] += (double)g.w * ((v.w - mu.w) * is.w);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = v4[u];
+                if (MODE == 0) {
+                    // rows past the end contribute exact zeros
+                    a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+                    b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
+                } else {
+                    float4 g = g4[u];
+                    if (relu) {
+                        if (!(v.x * sc.x + sf.x > 0.f)) g.x = 0.f;
+                        if (!(v.y * sc.y + sf.y > 0.f)) g.y = 0.f;
+                        if (!(v.z * sc.z + sf.z > 0.f)) g.z = 0.f;
+                        if (!(v.w * sc.w + sf.w > 0.f)) g.w = 0.f;
+                    }
+                    a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+                    b[0] += (double)g.x * ((v.x - mu.x) * is.x); b[1] += (double)g.y * ((v.y - mu.y) * is.y);
+                    b[2] += (double)g.z * ((v.z - mu.z) * is.z); b[3] += (double)g.w * ((v.w - mu.w) * is.w);
+                }
             }
         }
     }

@@ -141,7 +141,10 @@ int u3d_weight_transpose(const float* w, float* wt, int Cd, int K, int Cs, u3d_s
  *     Split so that the caller can all-reduce the fp64 statistics between the two phases
  *     (SyncBatchNorm across data-parallel ranks).
  * ===================================================================================== */
-int u3d_bn_stats(const float* x, int64_t n, int C, double* sums /*[2C]: sum, sum of squares; += */, u3d_stream_t stream);
+/* sums[0..C) = sum x, sums[C..2C) = sum x^2, sums[2C] = n (fp64; per-block partials in ws are combined in a fixed
+ * order -> deterministic).  ws: u3d_bn_ws_bytes(C). */
+int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, void* ws, u3d_stream_t stream);
+int64_t u3d_bn_ws_bytes(int C);
 /* mean/var from sums/count; scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place
  * (momentum, unbiased var) when running_mean != NULL.  count <= 0: the row count is read from sums[2C]
  * (it then travels through the SyncBatchNorm all-reduce with the sums: no host read-back). */
@@ -150,15 +153,24 @@ int u3d_bn_finalize(const double* sums, double count, const float* gamma, const 
                     float* scale, float* shift, u3d_stream_t stream);
 int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y,
                  u3d_stream_t stream);
-/* backward of y = relu(x*scale+shift): sums[0..C) += sum dy', sums[C..2C) += sum dy'*xhat  (dy' = dy*[y>0]) */
+/* backward of y = relu(x*scale+shift): sums[0..C) = sum dy', sums[C..2C) = sum dy'*xhat  (dy' = dy*[y>0]);
+ * sums[2C] is left untouched (the caller keeps the forward row count there). */
 int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd,
-                     const float* scale, const float* shift, int relu, int64_t n, int C, double* sums,
+                     const float* scale, const float* shift, int relu, int64_t n, int C, double* sums, void* ws,
                      u3d_stream_t stream);
 /* dx = scale*(dy' - sum_dy/count - xhat*sum_dyxhat/count); dgamma = sum_dyxhat, dbeta = sum_dy (fp32 out);
  * count <= 0: read from sums[2C]. */
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd,
                      const float* scale, const float* shift, int relu, const double* sums, double count,
                      int64_t n, int C, float* dx, float* dgamma, float* dbeta, u3d_stream_t stream);
+
+/* Single-call forms for the non-distributed case (stats -> finalize -> apply; bwd_stats -> bwd_apply).
+ * st float [4C] = mean, invstd, scale, shift (saved for backward); sums double [2C+1]. */
+int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, int relu, float* y, float* st, double* sums, void* ws,
+                   u3d_stream_t stream);
+int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, double* sums, int64_t n, int C,
+                    float* dx, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
 
 /* =====================================================================================
  * K11/K12  superpoint pooling -- replaces x.features[inverse_mapping] + torch_scatter.scatter_mean

@@ -1,0 +1,32 @@
+"""Summarise a rocprofv3 --stats kernel_stats.csv: python tools/stats_summary.py file.csv n_steps"""
+import collections
+import csv
+import re
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+tot = sum(int(r['TotalDurationNs']) for r in rows)
+print(f'GPU busy {tot / steps / 1e6:.2f} ms/step, {sum(int(r["Calls"]) for r in rows) / steps:.0f} kernels/step')
+
+
+def grp(n):
+    if 'spconv_gmm' in n or 'gmm_reduce' in n: return 'u3d conv fwd+dgrad (spconv_gmm_k)'
+    if 'spconv_wgrad' in n: return 'u3d conv wgrad'
+    if 'attn_' in n: return 'u3d attention'
+    if 'bn_' in n: return 'u3d batch norm'
+    if n.startswith('Cijk'): return 'hipBLASLt GEMM (decoder Linear, 1x1 conv)'
+    if 'u3d::' in n: return 'u3d voxelise/rulebook/pool/other'
+    if 'rocclr' in n: return 'copy/memset'
+    return 'torch elementwise/reduce/optimizer'
+
+
+g = collections.Counter(); c = collections.Counter()
+for r in rows:
+    g[grp(r['Name'])] += int(r['TotalDurationNs']); c[grp(r['Name'])] += int(r['Calls'])
+for k, v in g.most_common():
+    print(f'{k:44s} {v / steps / 1e6:8.2f} ms/step {c[k] / steps:8.0f} calls/step {100.0 * v / tot:5.1f}%')
+print()
+for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
+    n = re.sub(r'at::native::', '', r['Name'])[:110]
+    print(f"{int(r['TotalDurationNs']) / steps / 1e6:7.2f} ms/step {int(r['Calls']) / steps:7.0f} {float(r['AverageNs']) / 1e3:9.1f} us  {n}")

@@ -41,10 +41,13 @@ PROTOTYPES = {
     'u3d_spconv_plan': (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
     'u3d_spconv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _f64, _vp]),
     'u3d_weight_transpose': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
-    'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    'u3d_bn_ws_bytes': (_i64, [_i32]),
+    'u3d_bn_forward': (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_backward': (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_bn_finalize': (_i32, [_vp, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_bn_apply': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
-    'u3d_bn_bwd_stats': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    'u3d_bn_bwd_stats': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'u3d_bn_bwd_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _i32, _vp, _vp, _vp, _vp]),
     'u3d_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     'u3d_csr_build_ws_bytes': (_i64, [_i64, _i64]),
@@ -105,6 +108,18 @@ def stream():
 
 def ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_SCRATCH = {}
+
+
+def scratch(nbytes: int, device) -> torch.Tensor:
+    """Persistent per-device workspace (stream-ordered reuse on the current stream)."""
+    t = _SCRATCH.get(device)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 21), dtype=torch.uint8, device=device)
+        _SCRATCH[device] = t
+    return t
 
 
 def prof_enable(cls: int, on: bool):

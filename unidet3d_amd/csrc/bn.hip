@@ -13,7 +13,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                   int64_t n, int C, double* sums) {
+                                                   int64_t n, int C, double* sums /* partials [gridDim.x][2C] */) {
     __shared__ double sh[256 * 8];
     const int lpr = C >> 2;
     const int rpb = 256 / lpr;
@@ -74,12 +74,26 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ta[j] += sh[o + j]; tb[j] += sh[o + 4 + j]; }
         }
+        // per-block partial row (1024-way same-address fp64 atomics cost ~100 us on the big levels)
+        double* out = sums + (int64_t)blockIdx.x * 2 * C;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            atomicAdd(&sums[tid * 4 + j], ta[j]);
-            atomicAdd(&sums[C + tid * 4 + j], tb[j]);
+            out[tid * 4 + j] = ta[j];
+            out[C + tid * 4 + j] = tb[j];
         }
     }
+}
+
+// sums[c] = sum_b partial[b][c] in fixed order (deterministic); optionally sums[2C] = rows
+__global__ void bn_sum_partials_k(const double* __restrict__ partial, int nblk, int C2, double rows, int set_rows,
+                                  double* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C2) {
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * C2 + c];
+        sums[c] = t;
+    }
+    if (c == 0 && set_rows) sums[C2] = rows;
 }
 
 __global__ void bn_finalize_k(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
@@ -171,15 +185,22 @@ using namespace u3d;
 
 extern "C" {
 
-int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, u3d_stream_t stream) {
-    if (!x || !sums || !bn_ok(n, C)) return U3D_EINVAL;
+static int bn_grid(int64_t n, int C) {
+    const int rpb = 256 / (C / 4);
+    int64_t g = ceil_div(n, (int64_t)rpb * 16);
+    return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+
+int64_t u3d_bn_ws_bytes(int C) { return (int64_t)256 * 2 * C * sizeof(double) + 64; }
+
+int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, void* ws, u3d_stream_t stream) {
+    if (!x || !sums || !ws || !bn_ok(n, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
-    const int rpb = 256 / (C / 4);
-    int64_t g = ceil_div(n, (int64_t)rpb * 8);
-    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-    hipLaunchKernelGGL(bn_reduce_k<0>, dim3((unsigned)g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, sums);
+    const int g = bn_grid(n, C);
+    hipLaunchKernelGGL(bn_reduce_k<0>, dim3(g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws);
+    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 63) / 64), dim3(64), 0, s, (const double*)ws, g, 2 * C, (double)n, 1, sums);
     return check_launch("bn_stats");
 }
 
@@ -203,14 +224,13 @@ int u3d_bn_apply(const float* x, const float* scale, const float* shift, int rel
 }
 
 int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
-                     const float* shift, int relu, int64_t n, int C, double* sums, u3d_stream_t stream) {
-    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !bn_ok(n, C)) return U3D_EINVAL;
+                     const float* shift, int relu, int64_t n, int C, double* sums, void* ws, u3d_stream_t stream) {
+    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !ws || !bn_ok(n, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
-    const int rpb = 256 / (C / 4);
-    int64_t g = ceil_div(n, (int64_t)rpb * 8);
-    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-    hipLaunchKernelGGL(bn_reduce_k<1>, dim3((unsigned)g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, sums);
+    const int g = bn_grid(n, C);
+    hipLaunchKernelGGL(bn_reduce_k<1>, dim3(g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws);
+    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 63) / 64), dim3(64), 0, s, (const double*)ws, g, 2 * C, 0.0, 0, sums);
     return check_launch("bn_bwd_stats");
 }
 
@@ -224,6 +244,25 @@ int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const f
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, sums,
                        1.0 / count, n4, C, dx, dgamma, dbeta);
     return check_launch("bn_bwd_apply");
+}
+
+int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, int relu, float* y, float* st, double* sums, void* ws,
+                   u3d_stream_t stream) {
+    int rc = u3d_bn_stats(x, n, C, sums, ws, stream);
+    if (rc) return rc;
+    rc = u3d_bn_finalize(sums, -1.0, gamma, beta, eps, momentum, running_mean, running_var, C, st, st + C, st + 2 * C,
+                         st + 3 * C, stream);
+    if (rc) return rc;
+    return u3d_bn_apply(x, st + 2 * C, st + 3 * C, relu, n, C, y, stream);
+}
+
+int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, double* sums, int64_t n, int C, float* dx,
+                    float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
+    // sums[2C] must hold the forward row count; sums[0..2C) are overwritten
+    int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, stream);
+    if (rc) return rc;
+    return u3d_bn_bwd_apply(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, sums, -1.0, n, C, dx, dgamma, dbeta, stream);
 }
 
 }  // extern "C"

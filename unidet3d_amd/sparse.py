@@ -235,52 +235,66 @@ class _BNReLUFn(torch.autograd.Function):
         dev = x.device
         st = torch.empty(4, C, dtype=torch.float32, device=dev)     # mean, invstd, scale, shift
         y = torch.empty_like(x)
-        cnt = None
-        if training:
-            sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)   # [sum x, sum x^2, rows]
-            sums[2 * C] = float(n)
-            if n:
-                L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(sums), L.stream())
+        ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
+        sums = None
+        if training and n:
+            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)   # [sum x, sum x^2, rows]
             if sync and _dist_on():
+                L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(sums), L.ptr(ws), L.stream())
                 allreduce_bn_sums(sums)          # rows ride along: no host read-back on the critical path
-            L.call('u3d_bn_finalize', L.ptr(sums), -1.0, L.ptr(gamma), L.ptr(beta), eps, momentum,
-                   L.ptr(running_mean), L.ptr(running_var), C, L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                   L.stream())
-            cnt = sums[2 * C:]
+                L.call('u3d_bn_finalize', L.ptr(sums), -1.0, L.ptr(gamma), L.ptr(beta), eps, momentum,
+                       L.ptr(running_mean), L.ptr(running_var), C, L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]),
+                       L.ptr(st[3]), L.stream())
+                L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
+            else:                                # one call: stats -> finalize -> apply
+                L.call('u3d_bn_forward', L.ptr(x), n, C, L.ptr(gamma), L.ptr(beta), eps, momentum, L.ptr(running_mean),
+                       L.ptr(running_var), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
         else:
             st[0] = running_mean
             st[1] = torch.rsqrt(running_var + eps)
             st[2] = gamma * st[1]
             st[3] = beta - running_mean * st[2]
-        if n:
-            L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
-        ctx.save_for_backward(x, st, cnt)
+            if n:
+                L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
+        ctx.save_for_backward(x, st, sums)
         ctx.relu, ctx.training, ctx.sync = relu, training, sync
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, st, cnt = ctx.saved_tensors
+        x, st, fsums = ctx.saved_tensors
         dy = dy.contiguous()
         n, C = x.shape
-        sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=x.device)
+        dev = x.device
         dx = torch.empty_like(x)
-        if n:
-            L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                   int(ctx.relu), n, C, L.ptr(sums), L.stream())
-        dbeta = sums[:C].to(torch.float32)          # local sums: DDP averages parameter grads afterwards
-        dgamma = sums[C:2 * C].to(torch.float32)
-        if ctx.training:
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)       # dgamma, dbeta (local sums: DDP averages later)
+        if not n:
+            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None
+        ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        if ctx.training and fsums is not None:
+            sums[2 * C:] = fsums[2 * C:]             # global row count of the forward pass
             if ctx.sync and _dist_on():
-                allreduce_bn_sums(sums)
-            sums[2 * C:] = cnt                      # global row count of the forward pass
-        else:
-            sums.zero_()                            # eval: statistics are constants
+                L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
+                       int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
+                dgb[1] = sums[:C].to(torch.float32)
+                dgb[0] = sums[C:2 * C].to(torch.float32)
+                dist.all_reduce(sums[:2 * C], op=dist.ReduceOp.SUM)
+                L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
+                       int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.stream())
+            else:                                    # one call: bwd_stats -> bwd_apply (+ dgamma / dbeta)
+                L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(sums), n, C, L.ptr(dx),
+                       L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(ws), L.stream())
+        else:                                        # eval: statistics are constants -> dx = scale * dy'
+            L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
+                   int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
+            dgb[1] = sums[:C].to(torch.float32)
+            dgb[0] = sums[C:2 * C].to(torch.float32)
+            sums.zero_()
             sums[2 * C] = 1.0
-        if n:
             L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
                    int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.stream())
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 class SparseBatchNorm(nn.Module):
@@ -415,12 +429,15 @@ class SubMConv3d(_ConvBase):
             # plain [N, Cin] x [Cin, Cout] library GEMM (hipBLASLt), no rulebook (K5)
             y = F.linear(x.features, self.weight.view(self.out_channels, self.in_channels))
             return x.replace_feature(y if addend is None else y + addend)
+        return x.replace_feature(sparse_conv(_pad16(x.features), self._w16(), self.geometry(x), 'fwd', addend))
+
+    def geometry(self, x: SparseConvTensor) -> Rulebook:
         key = self.indice_key if self.indice_key is not None else ('__subm__', id(self))
         rb = x.indice_dict.get(key)
         if rb is None:
             rb = build_subm_rulebook(x.indices, x.index)
             x.indice_dict[key] = rb
-        return x.replace_feature(sparse_conv(_pad16(x.features), self._w16(), rb, 'fwd', addend))
+        return rb
 
 
 class SparseConv3d(_ConvBase):
@@ -429,10 +446,19 @@ class SparseConv3d(_ConvBase):
         assert kernel_size == 2 and stride == 2 and padding == 0, 'only k=2,s=2 is on the hot path'
 
     def forward(self, x: SparseConvTensor) -> SparseConvTensor:
-        oc, oshape, ix2, rb = build_down_rulebook(x.indices, x.batch_size, x.spatial_shape)
-        x.indice_dict[self.indice_key] = (rb, x.indices, x.spatial_shape, x._index)
+        oc, oshape, ix2, rb = self.geometry(x)
         f = sparse_conv(_pad16(x.features), self._w16(), rb, 'fwd')
         return SparseConvTensor(f, oc, oshape, x.batch_size, x.indice_dict, ix2)
+
+    def geometry(self, x: SparseConvTensor):
+        """Coarser level + rulebook for this conv; cached in ``indice_dict`` (the inverse conv reads the
+        same entry), so it can be built ahead of the feature pass (``prepare_geometry``)."""
+        key = ('__down__', self.indice_key)
+        if key not in x.indice_dict:
+            oc, oshape, ix2, rb = build_down_rulebook(x.indices, x.batch_size, x.spatial_shape)
+            x.indice_dict[key] = (oc, oshape, ix2, rb)
+            x.indice_dict[self.indice_key] = (rb, x.indices, x.spatial_shape, x._index)
+        return x.indice_dict[key]
 
 
 class SparseInverseConv3d(_ConvBase):

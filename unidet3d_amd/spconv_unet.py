@@ -100,6 +100,16 @@ class SpConvUNet(nn.Module):
                                     normalize_before=normalize_before))
                 for i in range(block_reps)))
 
+    def prepare_geometry(self, x: SparseConvTensor):
+        """Build every level's coordinates and rulebooks before any feature kernel is queued: the voxel
+        counts of the coarser levels are host read-backs, and taking them here (integer kernels only in
+        flight) keeps them from draining a pipeline full of convolutions later."""
+        [m for m in self.blocks[0].conv_branch if isinstance(m, SubMConv3d) and m.kernel_size == 3][0].geometry(x)
+        if len(self.num_planes) > 1:
+            down = [m for m in self.conv if isinstance(m, SparseConv3d)][0]
+            oc, oshape, ix2, _ = down.geometry(x)
+            self.u.prepare_geometry(SparseConvTensor(None, oc, oshape, x.batch_size, x.indice_dict, ix2))
+
     def forward(self, input: SparseConvTensor, previous_outputs=None):
         output = self.blocks(input)
         identity = output

@@ -71,6 +71,8 @@ class UniDet3D(nn.Module):
         """input conv -> U-Net -> BN/ReLU -> mean-pool voxel features into superpoints -> split per scene.
         ``superpoints`` is either the int64 [Np] tensor of batch-global ids (reference signature) or a
         prebuilt ``ops.PoolPlan``."""
+        if hasattr(self.unet, 'prepare_geometry'):
+            self.unet.prepare_geometry(x)
         x = self.input_conv(x)
         x, _ = self.unet(x)
         x = self.output_layer(x)

@@ -110,6 +110,15 @@ def ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+def h2d(values, dtype, device) -> torch.Tensor:
+    """Small host list -> device tensor without draining the stream: pinned staging + non_blocking copy
+    (a pageable H2D copy makes the host wait for everything already queued on the stream)."""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 _SCRATCH = {}
 
 

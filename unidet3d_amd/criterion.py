@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ._lib import h2d as _h2d
 from .registry import MODELS, TASK_UTILS
 from .structures import InstanceData_
 
@@ -201,62 +202,67 @@ class UniDet3DCriterion:
             valid[b, :n] = True
             dest.append(torch.arange(b * n_max, b * n_max + n, device=device))
         rows = torch.cat(dest)                                  # packed row -> slot in the padded batch
-        has_gt = torch.tensor([len(i) > 0 for i in insts], device=device)
+        has_gt = _h2d([len(i) > 0 for i in insts], torch.bool, device)
         return dict(labels=labels, boxes=boxes, qmask=qmask.transpose(1, 2), rows=rows, valid=valid, has_gt=has_gt,
                     uniform=len(set(sizes)) == 1)
 
-    def _layer_loss_packed(self, cls, box, gt, name):
+    def _loss_packed(self, cls, box, gt, name):
+        """All decoder layers and all scenes at once: cls [L, sum n_i, C+1], box [L, sum n_i, 6] ->
+        sum over layers of (w_cls * mean_scenes CE + w_box * mean_scenes DIoU) with per-layer re-matching."""
         idx = self.datasets.index(name)
         weight, topk = self.datasets_weights[idx], self.topk[idx]
+        L = cls.shape[0]
         B, n = gt['valid'].shape
         if gt['uniform']:
-            cls_b, box_b = cls.view(B, n, -1), box.view(B, n, 6)
+            cls_b, box_b = cls.view(L, B, n, -1), box.view(L, B, n, 6)
         else:       # index_copy into the padded layout: its backward is an index_select (no scatter-add kernel)
-            cls_b = cls.new_zeros(B * n, cls.shape[1]).index_copy(0, gt['rows'], cls).view(B, n, -1)
-            pad_box = box.new_zeros(B * n, 6)
+            rows = (gt['rows'][None] + torch.arange(L, device=cls.device)[:, None] * (B * n)).reshape(-1)
+            cls_b = cls.new_zeros(L * B * n, cls.shape[-1]).index_copy(0, rows, cls.reshape(-1, cls.shape[-1])).view(L, B, n, -1)
+            pad_box = box.new_zeros(L * B * n, 6)
             pad_box[:, 3:] = 1.0
-            box_b = pad_box.index_copy(0, gt['rows'], box).view(B, n, 6)
+            box_b = pad_box.index_copy(0, rows, box.reshape(-1, 6)).view(L, B, n, 6)
         n_cls = cls_b.shape[-1] - 1
-        gtb = _bbox_to_loss(gt['boxes'])[:, None]                                  # [B,1,g,6]
-        with torch.no_grad():                                                      # UniMatcher (criterion.py:286-320)
-            prob = cls_b.softmax(-1)
-            c_cls = -prob.gather(2, gt['labels'][:, None, :].expand(-1, n, -1)) * self.matcher.costs[0].weight
-            pb = _bbox_to_loss(box_b)[:, :, None]                                  # [B,n,1,6]
-            iou_loss = 1 - _aligned_iou_3d(pb, gtb)                                # [B,n,g]
+        g = gt['labels'].shape[1]
+        labels = gt['labels'][None].expand(L, -1, -1)                              # [L,B,g]
+        gtb = _bbox_to_loss(gt['boxes'])[None, :, None]                            # [1,B,1,g,6]
+        pbx = _bbox_to_loss(box_b)[:, :, :, None]                                  # [L,B,n,1,6]
+
+        def diou_terms(pb):
+            iou_loss = 1 - _aligned_iou_3d(pb, gtb)                                # [L,B,n,g]
             pc, tc = (pb[..., :3] + pb[..., 3:]) / 2, (gtb[..., :3] + gtb[..., 3:]) / 2
             r2 = ((pc - tc) ** 2).sum(-1)
             c2 = ((torch.minimum(pb[..., :3], gtb[..., :3]) - torch.maximum(pb[..., 3:], gtb[..., 3:])) ** 2).sum(-1)
-            c_box = (iou_loss + (r2 / c2)[:, :, :1]) * self.matcher.costs[1].weight    # the reference's [:, 0] term
-            cost = torch.where(gt['qmask'], c_cls + c_box, cls_b.new_tensor(self.matcher.inf))
-            kth = torch.topk(cost, topk + 1, dim=1, sorted=True, largest=False).values[:, -1:, :]
-            matched = cost < kth                                                   # [B,n,g]
-            g = matched.shape[2]
-            last = (matched * torch.arange(1, g + 1, device=cls.device)).amax(2) - 1   # highest matched gt wins
-            target = torch.where(last >= 0, gt['labels'].gather(1, last.clamp(min=0)), n_cls)
+            return iou_loss, r2 / c2
+
+        with torch.no_grad():                                                      # UniMatcher (criterion.py:286-320)
+            prob = cls_b.softmax(-1)
+            c_cls = -prob.gather(3, labels[:, :, None, :].expand(-1, -1, n, -1)) * self.matcher.costs[0].weight
+            iou_loss, rc = diou_terms(pbx)
+            c_box = (iou_loss + rc[..., :1]) * self.matcher.costs[1].weight        # the reference's [:, 0] term
+            cost = torch.where(gt['qmask'][None], c_cls + c_box, cls_b.new_tensor(self.matcher.inf))
+            kth = torch.topk(cost, topk + 1, dim=2, sorted=True, largest=False).values[:, :, -1:, :]
+            matched = cost < kth                                                   # [L,B,n,g]
+            last = (matched * torch.arange(1, g + 1, device=cls.device)).amax(3) - 1   # highest matched gt wins
+            target = torch.where(last >= 0, labels.gather(2, last.clamp(min=0)), n_cls)
             cw = cls_b.new_ones(n_cls + 1)
             cw[-1] = self.non_object_weight
-            w = cw[target] * gt['valid']
-        nll = -torch.log_softmax(cls_b, -1).gather(2, target[..., None])[..., 0]
-        cls_loss = (weight * (nll * w).sum(1) / w.sum(1)).mean()
-        pbx, gbx = _bbox_to_loss(box_b)[:, :, None], gtb
-        diou = 1 - _aligned_iou_3d(pbx, gbx)
-        pc, tc = (pbx[..., :3] + pbx[..., 3:]) / 2, (gbx[..., :3] + gbx[..., 3:]) / 2
-        diou = diou + ((pc - tc) ** 2).sum(-1) / \
-            ((torch.minimum(pbx[..., :3], gbx[..., :3]) - torch.maximum(pbx[..., 3:], gbx[..., 3:])) ** 2).sum(-1)
-        cnt = matched.sum((1, 2))
-        per_scene = (torch.where(matched, diou, diou.new_zeros(())).sum((1, 2)) / cnt.clamp(min=1)) * weight
-        has = (cnt > 0) & gt['has_gt']
-        bbox_loss = (per_scene * has).sum() / has.sum().clamp(min=1)
-        return self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss
+            w = cw[target] * gt['valid'][None]
+        nll = -torch.log_softmax(cls_b, -1).gather(3, target[..., None])[..., 0]
+        cls_loss = (weight * (nll * w).sum(2) / w.sum(2)).mean(1)                  # [L]
+        iou_loss, rc = diou_terms(pbx)
+        diou = iou_loss + rc
+        cnt = matched.sum((2, 3))                                                  # [L,B]
+        per_scene = (torch.where(matched, diou, diou.new_zeros(())).sum((2, 3)) / cnt.clamp(min=1)) * weight
+        has = (cnt > 0) & gt['has_gt'][None]
+        bbox_loss = (per_scene * has).sum(1) / has.sum(1).clamp(min=1)             # [L]
+        return (self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss).sum()
 
     def __call__(self, pred, insts, datasets_names):
         if self._can_pack(pred, insts, datasets_names):
             pk = pred['_packed']
             gt = self._pack_gt(insts, pk['sizes'], pk['cls'][0].device)
-            loss = 0
-            for cls, box in zip(pk['cls'], pk['box']):       # final layer + the aux layers, re-matched each
-                loss = loss + self._layer_loss_packed(cls, box, gt, datasets_names[0])
-            return {'det_loss': loss}
+            # final layer + the aux layers, each re-matched (iter_matcher), in one batched pass
+            return {'det_loss': self._loss_packed(torch.stack(pk['cls']), torch.stack(pk['box']), gt, datasets_names[0])}
         loss = self.get_layer_loss(pred, insts, datasets_names)
         if 'aux_outputs' in pred:
             indices = None        # iter_matcher=True re-matches per layer; the reference leaves `indices`

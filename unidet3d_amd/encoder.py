@@ -148,6 +148,13 @@ class UniDet3DEncoder(nn.Module):
         self.outs_cls = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, len(unique_cls)))
         self.datasets_cls_idxs = [[unique_cls.index(c) for c in dc] + [-1] for dc in datasets_classes]
         self.out_bboxes = PredBBox(d_model, 8)
+        self._cidx_cache = {}
+
+    def _cidx(self, idx, device):
+        key = (idx, str(device))
+        if key not in self._cidx_cache:      # class-column indices live on the device once: no per-call H2D copy
+            self._cidx_cache[key] = torch.as_tensor(self.datasets_cls_idxs[idx], dtype=torch.long, device=device)
+        return self._cidx_cache[key]
 
     def _forward_head(self, feats, sizes, sp_centers, centers_packed, datasets_names):
         """Packed head: one LayerNorm / class MLP / box Linear over all scenes (encoder.py:165-201).
@@ -158,15 +165,13 @@ class UniDet3DEncoder(nn.Module):
         box_all = self.out_bboxes(nq)
         if len(set(datasets_names)) == 1:
             idx = self.datasets.index(datasets_names[0])
-            cidx = torch.as_tensor(self.datasets_cls_idxs[idx], dtype=torch.long, device=feats.device)
-            cls_p = cls_all[:, cidx]
+            cls_p = cls_all[:, self._cidx(idx, feats.device)]
             box_p = _bbox_pred_to_bbox(centers_packed, box_all if self.angles[idx] else box_all[:, :6])
             return list(cls_p.split(sizes)), list(box_p.split(sizes)), (cls_p, box_p)
         cls_preds, boxes = [], []
         for i, (c, pb, name) in enumerate(zip(cls_all.split(sizes), box_all.split(sizes), datasets_names)):
             idx = self.datasets.index(name)
-            cidx = torch.as_tensor(self.datasets_cls_idxs[idx], dtype=torch.long, device=feats.device)
-            cls_preds.append(c[:, cidx])
+            cls_preds.append(c[:, self._cidx(idx, feats.device)])
             if not self.angles[idx]:
                 pb = pb[:, :6]
             boxes.append(_bbox_pred_to_bbox(sp_centers[i], pb))
@@ -175,7 +180,7 @@ class UniDet3DEncoder(nn.Module):
     def forward(self, x: List[torch.Tensor], sp_centers: List[torch.Tensor], datasets_names: List[str]):
         sizes = [int(t.shape[0]) for t in x]
         dev = x[0].device
-        cu = torch.tensor([0] + list(itertools.accumulate(sizes)), dtype=torch.int32, device=dev)
+        cu = L.h2d([0] + list(itertools.accumulate(sizes)), torch.int32, dev)
         max_len = max(sizes) if sizes else 0
         centers_packed = torch.cat(sp_centers) if len(sp_centers) > 1 else sp_centers[0]
         feats = self.input_proj(torch.cat(x) if len(x) > 1 else x[0])

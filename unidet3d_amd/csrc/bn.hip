@@ -84,16 +84,20 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
     }
 }
 
-// sums[c] = sum_b partial[b][c] in fixed order (deterministic); optionally sums[2C] = rows
-__global__ void bn_sum_partials_k(const double* __restrict__ partial, int nblk, int C2, double rows, int set_rows,
-                                  double* __restrict__ sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// sums[c] = sum_b partial[b][c] in a fixed order (deterministic); optionally sums[2C] = rows.
+// One wave per column: lane l adds rows l, l+64, ... then a fixed shuffle tree.
+__global__ __launch_bounds__(256) void bn_sum_partials_k(const double* __restrict__ partial, int nblk, int C2, double rows,
+                                                         int set_rows, double* __restrict__ sums) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c < C2) {
         double t = 0.0;
-        for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * C2 + c];
-        sums[c] = t;
+        for (int b = lane; b < nblk; b += 64) t += partial[(int64_t)b * C2 + c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0) sums[c] = t;
     }
-    if (c == 0 && set_rows) sums[C2] = rows;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && set_rows) sums[C2] = rows;
 }
 
 __global__ void bn_finalize_k(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
@@ -200,7 +204,7 @@ int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, void* ws, u3d_s
     const int g = bn_grid(n, C);
     hipLaunchKernelGGL(bn_reduce_k<0>, dim3(g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws);
-    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 63) / 64), dim3(64), 0, s, (const double*)ws, g, 2 * C, (double)n, 1, sums);
+    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 3) / 4), dim3(256), 0, s, (const double*)ws, g, 2 * C, (double)n, 1, sums);
     return check_launch("bn_stats");
 }
 
@@ -230,7 +234,7 @@ int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const f
     ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
     const int g = bn_grid(n, C);
     hipLaunchKernelGGL(bn_reduce_k<1>, dim3(g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws);
-    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 63) / 64), dim3(64), 0, s, (const double*)ws, g, 2 * C, 0.0, 0, sums);
+    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 3) / 4), dim3(256), 0, s, (const double*)ws, g, 2 * C, 0.0, 0, sums);
     return check_launch("bn_bwd_stats");
 }
 

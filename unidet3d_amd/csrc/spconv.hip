@@ -52,32 +52,46 @@ constexpr int GMM_CDS = 32;            // output columns per wave
 constexpr int GMM_ALD = GMM_CDS + 4;   // padded accumulator row
 
 // one or two 16-pair chunks of offset k: gather -> MFMA over all source channels -> scatter-add into LDS
+// raw rulebook indices of one work item (two 16-pair chunks of one offset), loaded one item ahead
+struct GmmIdx {
+    int g0, g1;
+    int s0[4], s1[4];
+};
+
+// unconditional, clamped loads: lanes past the end of the range read a valid (duplicate) entry; their rows
+// are computed but only ever added into the scratch row, so no load has to wait on a branch.
+__device__ __forceinline__ void gmm_load_idx(GmmIdx& ix, const GmmParams& p, int k, int base, int e, int i16, int q) {
+    const int32_t* gl = p.gather + (int64_t)k * p.cap;
+    const int32_t* sl = p.scatter + (int64_t)k * p.cap;
+    const int last = e - 1;
+    ix.g0 = gl[min(base + i16, last)];
+    ix.g1 = gl[min(base + 16 + i16, last)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i0 = base + q * 4 + r;
+        ix.s0[r] = sl[min(i0, last)];
+        ix.s1[r] = sl[min(i0 + 16, last)];
+    }
+}
+
+// one or two 16-pair chunks of offset k: gather -> MFMA over all source channels -> scatter-add into LDS
 template <int CS16, bool TWO, int TRASH>
-__device__ __forceinline__ void gmm_chunks(const GmmParams& p, const int32_t* __restrict__ gl, const int32_t* __restrict__ sl,
-                                           const float* __restrict__ wk, int base, int e, int64_t row0, float* acc, int i16, int q) {
+__device__ __forceinline__ void gmm_chunks(const GmmParams& p, GmmIdx ix, const float* __restrict__ wk, int base, int e,
+                                           int64_t row0, float* acc, int i16, int q) {
     constexpr int JB = CS16 <= 8 ? CS16 : CS16 / 2;     // 16-channel groups held in registers at a time
     constexpr int NJB = CS16 / JB;
-    // every load is unconditional (indices clamped into the range): lanes past the end compute garbage
-    // rows that are simply never scattered, and no load waits on a branch.
-    const int last = e - 1;
-    const int g0 = gl[min(base + i16, last)];
-    const int g1 = TWO ? gl[min(base + 16 + i16, last)] : 0;
+    // keep the compiler from sinking the index loads into the validity selects below (it would then wait
+    // for each of them separately): the asm makes every loaded value live here.
+    asm volatile("" : "+v"(ix.g0), "+v"(ix.g1));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ix.s0[r]), "+v"(ix.s1[r]));
+    const int g0 = ix.g0, g1 = ix.g1;
     int srow0[4], srow1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i0 = base + q * 4 + r, i1 = i0 + 16;
-        srow0[r] = sl[min(i0, last)];
-        srow1[r] = TWO ? sl[min(i1, last)] : 0;
-    }
-    // keep the compiler from sinking the index loads into the validity branches below (it would then
-    // wait for each of them separately): the asm makes every loaded value live here.
-#pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(srow0[r]), "+v"(srow1[r]));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i0 = base + q * 4 + r, i1 = i0 + 16;
-        srow0[r] = i0 < e ? (int)(srow0[r] - row0) : TRASH;        // lanes past the end add into a scratch row
-        srow1[r] = (TWO && i1 < e) ? (int)(srow1[r] - row0) : TRASH;
+        srow0[r] = i0 < e ? (int)(ix.s0[r] - row0) : TRASH;        // lanes past the end add into a scratch row
+        srow1[r] = (TWO && i1 < e) ? (int)(ix.s1[r] - row0) : TRASH;
     }
     f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     const int i16 = lane & 15, q = lane >> 4;
     float* acc = smem + wave * ((R + 1) * GMM_ALD);      // R rows + one scratch row
 
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wid = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wave;     // neighbouring row tiles share an XCD / L2
     const int per_sub = p.n_slices * p.G;
     const int64_t sub = wid / per_sub;
     if (sub >= p.n_sub) return;                      // wave-uniform; there are no barriers in this kernel
@@ -161,16 +175,34 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         ts_s = p.ts[lane * tsld + sub];
         ts_e = p.ts[lane * tsld + sub + 1];
     }
-    for (int k = k_lo; k < k_hi; ++k) {
-        const int s = __builtin_amdgcn_readfirstlane(__shfl(ts_s, k, 64));     // wave-uniform -> scalar control flow
-        const int e = __builtin_amdgcn_readfirstlane(__shfl(ts_e, k, 64));
-        if (s == e) continue;
-        const int32_t* gl = p.gather + (int64_t)k * p.cap;
-        const int32_t* sl = p.scatter + (int64_t)k * p.cap;
+    // work items = (offset k, 32-pair window); the raw indices of item i+1 are loaded while item i computes
+    auto range_of = [&](int k, int& s_, int& e_) {
+        s_ = __builtin_amdgcn_readfirstlane(__shfl(ts_s, k, 64));      // wave-uniform -> scalar control flow
+        e_ = __builtin_amdgcn_readfirstlane(__shfl(ts_e, k, 64));
+    };
+    int k = k_lo, base = 0, e = 0;
+    for (; k < k_hi; ++k) {                     // first non-empty offset
+        range_of(k, base, e);
+        if (base < e) break;
+    }
+    GmmIdx cur;
+    if (k < k_hi) gmm_load_idx(cur, p, k, base, e, i16, q);
+    while (k < k_hi) {
+        // ---- locate the next item and start its index loads ----
+        int nk = k, nbase = base + 32, ne = e;
+        if (nbase >= e) {
+            for (nk = k + 1; nk < k_hi; ++nk) {
+                range_of(nk, nbase, ne);
+                if (nbase < ne) break;
+            }
+        }
+        GmmIdx nxt = cur;
+        if (nk < k_hi) gmm_load_idx(nxt, p, nk, nbase, ne, i16, q);
+        // ---- compute the current item ----
         const float* wk = p.w + ((int64_t)(n0 + i16) * p.K + k) * p.Cs + q * 4;     // this lane's B row; +16 rows for the 2nd column block
-        int base = s;
-        for (; base + 16 < e; base += 32) gmm_chunks<CS16, true, R>(p, gl, sl, wk, base, e, row0, acc, i16, q);
-        if (base < e) gmm_chunks<CS16, false, R>(p, gl, sl, wk, base, e, row0, acc, i16, q);
+        if (base + 16 < e) gmm_chunks<CS16, true, R>(p, cur, wk, base, e, row0, acc, i16, q);
+        else gmm_chunks<CS16, false, R>(p, cur, wk, base, e, row0, acc, i16, q);
+        cur = nxt; k = nk; base = nbase; e = ne;
     }
     float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
     for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
@@ -214,109 +246,153 @@ static int launch_gmm(const GmmParams& p, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------
 // weight gradient: dW_k[n][c] = sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]
-// grid (n_split, K); each workgroup reduces a pair range, staging 32..128 gathered rows of x and
-// dy in LDS, 16x16x4 fp32 MFMA with the pair index as the reduction dim; wave (wr,wc) owns a
-// (Cd/2 x Cs/2) rectangle of dW so operand fragments are reused; one fp32 atomic add per element
-// per workgroup at the end.
+// Pair-stationary, barrier-free: a wave walks a contiguous range of offset k's pair list and keeps its
+// (sub-)block of dW_k in MFMA accumulators.  The 16x16x4 fp32 MFMA takes the PAIR index as its
+// reduction dim (4 pairs per instruction) and the channels as M / N.  Channel blocks are STRIDED
+// (block s = channels {NG*i + s}): lane i16 then needs NG consecutive floats of its pair's row, so one
+// load instruction fetches four complete, contiguous rows (16 lanes x NG*4 bytes each) -- a fraction of
+// the cache-line look-ups of a fragment-shaped gather and no LDS staging at all.  Large channel counts are
+// split over the 4 waves of a workgroup (sub-blocks of <= 32 accumulators); for small ones the 4 waves
+// take 4 ranges and pre-reduce in LDS so that a workgroup issues one fp32 atomic per dW element.
 struct WgParams {
     const float* x;
     const float* dy;
     const int32_t* rows_x;
     const int32_t* rows_dy;
     const int32_t* counts;
-    float* dW;
+    float* partial;   // [K][RK][Cd*Cs] per-range blocks in accumulator-register order
     int K;
     int64_t cap;
-    int R;   // pairs per workgroup
+    int R;    // pairs per range
+    int RK;   // ranges per offset
 };
 
-template <int CS16, int CD16, int PC>
-__global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
-    constexpr int CS = CS16 * 16, CD = CD16 * 16, XLD = CS + 4, GLD = CD + 4;
-    constexpr int NCI = CS16 >= 2 ? CS16 / 2 : 1, NCO = CD16 / 2;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;
-    float* gs = smem + PC * XLD;
-    const int k = blockIdx.y;
-    const int cnt = p.counts[k];
-    const int lo = blockIdx.x * p.R;
-    if (lo >= cnt) return;
-    const int hi = min(cnt, lo + p.R);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
-    const int wr = wave & 1, wc = wave >> 1;
-    const bool wave_active = CS16 >= 2 || wc == 0;
-    const int32_t* rx = p.rows_x + (int64_t)k * p.cap;
-    const int32_t* rg = p.rows_dy + (int64_t)k * p.cap;
-
-    f32x4 d[NCO][NCI];
+template <int N>
+__device__ __forceinline__ void load_row_part(float (&v)[N], const float* __restrict__ p) {
+    if constexpr (N % 4 == 0) {
 #pragma unroll
-    for (int a = 0; a < NCO; ++a)
-#pragma unroll
-        for (int b = 0; b < NCI; ++b) d[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int base = lo; base < hi; base += PC) {
-        __syncthreads();
-        // stage PC gathered rows of x and dy (zeros past the end)
-        for (int idx = tid; idx < PC * (CS / 4); idx += 256) {
-            const int r = idx / (CS / 4), c4 = idx % (CS / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (base + r < hi) v = *reinterpret_cast<const float4*>(p.x + (int64_t)rx[base + r] * CS + c4 * 4);
-            *reinterpret_cast<float4*>(xs + r * XLD + c4 * 4) = v;
+        for (int s = 0; s < N; s += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p + s);
+            v[s] = t.x; v[s + 1] = t.y; v[s + 2] = t.z; v[s + 3] = t.w;
         }
-        for (int idx = tid; idx < PC * (CD / 4); idx += 256) {
-            const int r = idx / (CD / 4), c4 = idx % (CD / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (base + r < hi) v = *reinterpret_cast<const float4*>(p.dy + (int64_t)rg[base + r] * CD + c4 * 4);
-            *reinterpret_cast<float4*>(gs + r * GLD + c4 * 4) = v;
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int s = 0; s < N; s += 2) {
+            const float2 t = *reinterpret_cast<const float2*>(p + s);
+            v[s] = t.x; v[s + 1] = t.y;
         }
-        __syncthreads();
-        if (wave_active) {
-#pragma unroll 2
-            for (int kk = 0; kk < PC / 4; ++kk) {
-                const int pr = kk * 4 + q;
-                float av[NCO], bv[NCI];
+    } else {
 #pragma unroll
-                for (int a = 0; a < NCO; ++a) av[a] = gs[pr * GLD + (wr * NCO + a) * 16 + i16];
-#pragma unroll
-                for (int b = 0; b < NCI; ++b) bv[b] = xs[pr * XLD + ((CS16 >= 2 ? wc * NCI : 0) + b) * 16 + i16];
-#pragma unroll
-                for (int a = 0; a < NCO; ++a)
-#pragma unroll
-                    for (int b = 0; b < NCI; ++b) d[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], d[a][b], 0, 0, 0);
-            }
-        }
-    }
-    if (wave_active) {
-#pragma unroll
-        for (int a = 0; a < NCO; ++a)
-#pragma unroll
-            for (int b = 0; b < NCI; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = (wr * NCO + a) * 16 + q * 4 + r;
-                    const int c = ((CS16 >= 2 ? wc * NCI : 0) + b) * 16 + i16;
-                    atomicAdd(p.dW + ((int64_t)n * p.K + k) * CS + c, d[a][b][r]);
-                }
+        for (int s = 0; s < N; ++s) v[s] = p[s];
     }
 }
 
-template <int CS16, int CD16>
-static int launch_wgrad(const WgParams& p0, int64_t n_rows_hint, hipStream_t s) {
-    constexpr int total = (CS16 + CD16) * 16;
-    constexpr int PC = total <= 64 ? 128 : (total <= 192 ? 64 : 32);
-    WgParams p = p0;
-    int64_t R = ceil_div(p.cap, (int64_t)(1024 / p.K > 0 ? 1024 / p.K : 1));
-    R = ceil_div(R, PC) * PC;
-    if (R < 2 * PC) R = 2 * PC;
-    p.R = (int)R;
-    const int64_t nsplit = ceil_div(p.cap, R);
-    const size_t lds = (size_t)PC * ((CS16 + CD16) * 16 + 8) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_wgrad_k<CS16, CD16, PC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+// NG = Cd/16, NX = Cs/16 floats per lane per row; SG x SX waves share one pair range
+template <int NG, int NX, int SG, int SX>
+__global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
+    constexpr int NGW = NG / SG, NXW = NX / SX, SPLIT = SG * SX, RPW = 4 / SPLIT;   // RPW ranges per workgroup
+    constexpr int CD = NG * 16, CS = NX * 16;
+    const int k = blockIdx.y;
+    const int cnt = p.counts[k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+    const int sub = wave % SPLIT, wa = sub % SG, wb = sub / SG;
+    const int range = blockIdx.x * RPW + wave / SPLIT;      // (an XCD-contiguous remap was tried: slower, the tail ranges are empty)
+    const int lo = range * p.R;
+    const int hi = min(cnt, lo + p.R);
+    if (range >= p.RK || lo >= cnt) return;              // wave-uniform; the kernel has no barrier
+    const int32_t* rx = p.rows_x + (int64_t)k * p.cap;
+    const int32_t* rg = p.rows_dy + (int64_t)k * p.cap;
+    const float* gbase = p.dy + NG * i16 + wa * NGW;
+    const float* xbase = p.x + NX * i16 + wb * NXW;
+
+    f32x4 acc[NGW][NXW];
+#pragma unroll
+    for (int a = 0; a < NGW; ++a)
+#pragma unroll
+        for (int b = 0; b < NXW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int base = lo; base < hi; base += 16) {        // 4 MFMA K-steps (16 pairs) per trip, all loads up front
+        int io[4], ix[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pi = min(base + 4 * u + q, hi - 1);
+            io[u] = rg[pi];
+            ix[u] = rx[pi];
+        }
+        float gv[4][NGW], xv[4][NXW];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load_row_part<NGW>(gv[u], gbase + (int64_t)io[u] * CD);
+            load_row_part<NXW>(xv[u], xbase + (int64_t)ix[u] * CS);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = base + 4 * u + q < hi;        // pairs past the end contribute exact zeros
+#pragma unroll
+            for (int a = 0; a < NGW; ++a) {
+                const float ga = ok ? gv[u][a] : 0.f;
+#pragma unroll
+                for (int b = 0; b < NXW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, xv[u][b], acc[a][b], 0, 0, 0);
+            }
+        }
     }
-    hipLaunchKernelGGL((spconv_wgrad_k<CS16, CD16, PC>), dim3((unsigned)nsplit, p.K), dim3(256), lds, s, p);
+    // partial block of this range in register order [sub][(a*NXW + b)*4 + r][lane]: 256-byte coalesced stores,
+    // no atomics; wgrad_reduce_k maps it back to dW[co][k][ci] and sums the ranges in a fixed order.
+    float* out = p.partial + ((int64_t)k * p.RK + range) * (CD * CS) + (int64_t)sub * (NGW * NXW * 256) + lane;
+#pragma unroll
+    for (int a = 0; a < NGW; ++a)
+#pragma unroll
+        for (int b = 0; b < NXW; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[((a * NXW + b) * 4 + r) * 64] = acc[a][b][r];
+}
+
+// dW[co][k][ci] = sum over the active ranges of offset k (fixed order -> deterministic; overwrites dW)
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ partial, const int32_t* __restrict__ counts, int R, int RK,
+                                                      int K, int NG, int NX, int SG, int SX, float* __restrict__ dW) {
+    const int CS = NX * 16, E = NG * NX * 256;
+    const int k = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= E) return;
+    const int cnt = counts[k];
+    const int n_act = min(RK, (cnt + R - 1) / R);
+    const float* src = partial + (int64_t)k * RK * E + idx;
+    float v = 0.f;
+    for (int r = 0; r < n_act; ++r) v += src[(int64_t)r * E];
+    const int NGW = NG / SG, NXW = NX / SX, per_sub = NGW * NXW * 256;
+    const int sub = idx / per_sub, rem = idx % per_sub;
+    const int e = rem >> 6, lane = rem & 63, i16 = lane & 15, q = lane >> 4;
+    const int rr = e & 3, b = (e >> 2) % NXW, a = (e >> 2) / NXW;
+    const int wa = sub % SG, wb = sub / SG;
+    const int co = NG * (4 * q + rr) + wa * NGW + a, ci = NX * i16 + wb * NXW + b;
+    dW[((int64_t)co * K + k) * CS + ci] = v;
+}
+
+struct WgPlan { int R, RK; };
+static WgPlan plan_wgrad(int K, int64_t cap, int Cs, int Cd) {
+    // ranges per offset: bounded by a 64 MB partial buffer, by 512, and by >= 64 pairs per range
+    int64_t rk = (int64_t)(64 << 20) / ((int64_t)K * Cs * Cd * 4);
+    rk = rk > 512 ? 512 : (rk < 1 ? 1 : rk);
+    const int64_t by_len = ceil_div(cap, 64);
+    if (rk > by_len) rk = by_len;
+    int64_t R = ceil_div(ceil_div(cap, rk), 16) * 16;
+    rk = ceil_div(cap, R);
+    return WgPlan{(int)R, (int)rk};
+}
+
+template <int NX, int NG>     // (Cs/16, Cd/16) as the dispatch macro passes them
+static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
+    // split over the 4 waves until a wave's sub-block is <= 32 accumulators (128 VGPRs)
+    constexpr int SG = (NG * NX > 32 && NG % 2 == 0 && NG >= NX) ? 2 : ((NG * NX > 64 && NG % 2 == 0) ? 2 : 1);
+    constexpr int SX = ((NG / SG) * NX > 32 && NX % 2 == 0) ? 2 : 1;
+    constexpr int SPLIT = SG * SX, RPW = 4 / SPLIT;
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "wave split");
+    WgParams p = p0;
+    const WgPlan pl = plan_wgrad(p.K, p.cap, NX * 16, NG * 16);
+    p.R = pl.R; p.RK = pl.RK;
+    hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX>), dim3((unsigned)ceil_div(p.RK, RPW), p.K), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, p.counts, p.R, p.RK, p.K, NG, NX,
+                       SG, SX, dW);
     return check_launch("spconv_wgrad");
 }
 
@@ -378,17 +454,24 @@ int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather,
     return rc;
 }
 
+int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t cap, int Cs, int Cd) {
+    if (K <= 0 || cap <= 0 || Cs <= 0 || Cd <= 0) return 0;
+    const WgPlan pl = plan_wgrad(K, cap, Cs, Cd);
+    return (int64_t)K * pl.RK * Cs * Cd * 4 + 256;
+}
+
 int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
-                     const int32_t* counts, int K, int64_t cap, int Cs, int Cd, float* dW, double flops_hint,
+                     const int32_t* counts, int K, int64_t cap, int Cs, int Cd, float* dW, void* ws, double flops_hint,
                      u3d_stream_t stream) {
-    if (!x || !dy || !rows_x || !rows_dy || !counts || !dW || K <= 0 || cap <= 0) return U3D_EINVAL;
+    if (!x || !dy || !rows_x || !rows_dy || !counts || !dW || !ws || K <= 0 || cap <= 0) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_CONV_WGRAD, s, flops_hint);
     WgParams p;
-    p.x = x; p.dy = dy; p.rows_x = rows_x; p.rows_dy = rows_dy; p.counts = counts; p.dW = dW; p.K = K; p.cap = cap; p.R = 0;
+    p.x = x; p.dy = dy; p.rows_x = rows_x; p.rows_dy = rows_dy; p.counts = counts; p.partial = (float*)ws; p.K = K; p.cap = cap;
+    p.R = 0; p.RK = 0;
     const int cs16 = Cs / 16, cd16 = Cd / 16;
     if (Cs % 16 || Cd % 32) return U3D_EUNSUPPORTED;
-#define U3D_WG_CASE(cs, cd) if (cs16 == cs && cd16 == cd) return launch_wgrad<cs, cd>(p, cap, s);
+#define U3D_WG_CASE(cs, cd) if (cs16 == cs && cd16 == cd) return launch_wgrad<cs, cd>(p, dW, s);
     U3D_WG_CASE(1, 2) U3D_WG_CASE(2, 2) U3D_WG_CASE(4, 2) U3D_WG_CASE(4, 4) U3D_WG_CASE(8, 4)
     U3D_WG_CASE(6, 6) U3D_WG_CASE(12, 6) U3D_WG_CASE(8, 8) U3D_WG_CASE(16, 8) U3D_WG_CASE(10, 10)
     U3D_WG_CASE(2, 4) U3D_WG_CASE(4, 6) U3D_WG_CASE(6, 8) U3D_WG_CASE(8, 10)

@@ -32,6 +32,14 @@ inline int check_launch(const char* what) {
 
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// XCD-aware work-id remap (MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8, each XCD has its own
+// 4 MB L2): XCD x gets the CONTIGUOUS chunk of work ids so that neighbouring tiles, which gather the same
+// feature rows, share an L2.  Bijective for any n (speed only -- correctness never depends on placement).
+__device__ __forceinline__ int64_t xcd_swizzle(int64_t b, int64_t n) {
+    const int64_t q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // exclusive scan of n int32 values produced by a functor; out has n+1 entries (out[n] = total)
 int exclusive_scan_popc64(const uint64_t* words, int64_t n, int32_t* out, void* ws, hipStream_t s);
 int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hipStream_t s);

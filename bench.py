@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--voxel-size', type=float, default=0.02)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL over xGMI); 'gloo' lets two ranks "
+                    "share one GPU to exercise the N>1 code path on a single-GPU box")
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (diagnostic, not the reported config)')
     return ap.parse_args()
 
@@ -123,11 +125,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
     L.lib()                                           # fail loudly if the HIP library is missing
-    rank, world, local = init_from_env('nccl')
+    if args.backend != 'nccl':
+        os.environ['LOCAL_RANK_DEVICE'] = str(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
+    local_dev = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    rank, world, local = init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local_dev)
 
     torch.manual_seed(0)
     model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)

@@ -25,12 +25,17 @@ def _worker(rank, world, port, q):
     torch.manual_seed(100 + rank)                     # ranks start different, broadcast must align them
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
     broadcast_params(net)
-    bucket = FlatGradBucket(net.parameters())
+    bucket = FlatGradBucket(net.parameters(), attach=(rank == 0))     # rank 0: in-place views; rank 1: pack() after backward
     g = torch.Generator().manual_seed(7)
     X = torch.randn(8, 6, generator=g); Y = torch.randn(8, 3, generator=g)
     xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
-    bucket.zero()
+    if rank == 0:
+        bucket.zero()
+    else:
+        bucket.clear_grads()
     ((net(xs) - ys) ** 2).mean().backward()
+    if rank == 1:
+        bucket.pack()
     assert bucket.check_views()
     bucket.allreduce_mean()
     # SyncBN statistics: per-rank partial sums of different row counts -> global mean / var

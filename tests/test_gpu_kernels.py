@@ -229,3 +229,40 @@ def test_superpoint_pool_and_centers():
                        for p, s in zip(pts_cpu, scenes)])
     cen_g = ops.superpoint_centers(vb.points, plan.sp_offsets, plan.sp_points, bias, vb.stats, vb.pt_offsets)
     assert _rel(cen_g, cen_o) < 1e-5
+
+
+# ---------------------------------------------------------------------------- edge cases / maximum sizes
+def test_stress_1m_points_rulebook_bit_exact():
+    """BASELINE cfg5 shape: one S3DIS-like room, 1M points, 2 cm voxels (~0.5M active voxels, extents > 256):
+    voxel coordinates, inverse map and the level-1 / level-2 rulebooks stay bit-exact; counts fit int32."""
+    from unidet3d_amd import ops, sparse
+    from unidet3d_amd.synthetic import make_scene
+    sc = make_scene(99, n_points=1_000_000, area_scale=10.0)
+    p = [torch.from_numpy(sc.points)]
+    oc, of, oinv, oshape = so.voxelize(p, 0.02, 128)
+    vb = ops.voxelize([p[0].to(_dev())], 0.02, 128)
+    assert len(oc) > 300_000 and max(vb.spatial_shape) > 256
+    assert vb.spatial_shape == [int(s) for s in oshape]
+    assert torch.equal(vb.coords.cpu(), oc) and torch.equal(vb.inverse.cpu(), oinv)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    _check_pairs(rb.lists(), so.build_subm_rulebook(oc, oshape))
+    oc2, oshape2, opairs = so.build_down_rulebook(oc, oshape)
+    c2, shape2, ix2, rb2 = sparse.build_down_rulebook(vb.coords, 1, vb.spatial_shape)
+    assert torch.equal(c2.cpu(), oc2)
+    _check_pairs(rb2.lists(), opairs)
+
+
+def test_batch_with_empty_and_single_point_scenes():
+    from unidet3d_amd import ops, sparse
+    g = torch.Generator().manual_seed(9)
+    pts_cpu = [torch.rand(300, 6, generator=g) * 2, torch.zeros(0, 6), torch.rand(1, 6, generator=g), torch.rand(50, 6, generator=g)]
+    oc, of, oinv, oshape = so.voxelize([p for p in pts_cpu if len(p)], 0.05, 16)     # the oracle cannot take an empty scene
+    vb = ops.voxelize([p.to(_dev()) for p in pts_cpu], 0.05, 16)
+    c = vb.coords.cpu().clone()
+    assert set(c[:, 0].tolist()) == {0, 2, 3}                     # scene 1 contributes no voxel
+    c[:, 0] = torch.where(c[:, 0] > 1, c[:, 0] - 1, c[:, 0])      # oracle batch ids skip the empty scene
+    assert torch.equal(c, oc) and torch.equal(vb.inverse.cpu(), oinv)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    x = torch.randn(len(oc), 32, device=_dev())
+    w = torch.zeros(32, 27, 32, device=_dev()); w[:, 13, :] = torch.eye(32, device=_dev())
+    assert torch.equal(sparse.sparse_conv(x, w.view(32, 3, 3, 3, 32), rb), x)

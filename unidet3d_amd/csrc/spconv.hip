@@ -20,6 +20,8 @@
 //     gather latency; deep U-Net levels (a few thousand rows) get their parallelism from column
 //     slices and offset groups (partials summed by a small deterministic reduce kernel).
 //   * fp32 in / fp32 accumulate MFMA (exact fp32, 157 TF peak) -- BASELINE config 2 is fp32.
+#include <stdlib.h>
+
 #include "u3d_common.h"
 
 namespace u3d {
@@ -232,6 +234,7 @@ static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
     if (ceil_div(n_dst, 64) * slices < want) r = 32;
     const int64_t waves = ceil_div(n_dst, r) * slices;
     if (waves < want && K >= 27) g = waves * 3 >= want ? 3 : 9;
+    if (const char* e = getenv("U3D_GMM_R")) r = atoi(e) == 32 ? 32 : 64;      // experiment knob (tools/prof_conv.py)
     *R = r;
     *G = g;
 }
@@ -292,11 +295,16 @@ template <int NG, int NX, int SG, int SX>
 __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
     constexpr int NGW = NG / SG, NXW = NX / SX, SPLIT = SG * SX, RPW = 4 / SPLIT;   // RPW ranges per workgroup
     constexpr int CD = NG * 16, CS = NX * 16;
-    const int k = blockIdx.y;
+    // Workgroup b runs on XCD b % 8 (private 4 MB L2).  XCD x takes range groups x, x+8, x+16, ... and walks ALL
+    // offsets of a group back to back, so the x / dy rows of that slab are fetched once and re-read 26 times from
+    // the XCD's own L2 (PMC before: TCC hit rate 11 %, 1.05 GB fabric traffic per L1 launch).  Interleaving the
+    // groups over the XCDs keeps the (empty) tail ranges evenly spread.
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int k = j % p.K;
     const int cnt = p.counts[k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
     const int sub = wave % SPLIT, wa = sub % SG, wb = sub / SG;
-    const int range = blockIdx.x * RPW + wave / SPLIT;      // (an XCD-contiguous remap was tried: slower, the tail ranges are empty)
+    const int range = ((j / p.K) * 8 + xcd) * RPW + wave / SPLIT;
     const int lo = range * p.R;
     const int hi = min(cnt, lo + p.R);
     if (range >= p.RK || lo >= cnt) return;              // wave-uniform; the kernel has no barrier
@@ -390,7 +398,8 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     WgParams p = p0;
     const WgPlan pl = plan_wgrad(p.K, p.cap, NX * 16, NG * 16);
     p.R = pl.R; p.RK = pl.RK;
-    hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX>), dim3((unsigned)ceil_div(p.RK, RPW), p.K), dim3(256), 0, s, p);
+    const int64_t groups = ceil_div(ceil_div(p.RK, RPW), 8) * 8;
+    hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, p.counts, p.R, p.RK, p.K, NG, NX,
                        SG, SX, dW);
     return check_launch("spconv_wgrad");

@@ -82,7 +82,7 @@ def init_from_env(backend: str = 'nccl'):
         os.environ.setdefault('MASTER_PORT', '29500')
         kw = {}
         if backend == 'nccl':
-            kw['device_id'] = torch.device('cuda', local)
+            kw['device_id'] = torch.device('cuda', local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 

@@ -38,7 +38,7 @@ const char* u3d_last_error(void);
 
 /* ---- kernel timing (HIP events on the launch stream; used by bench.py's roofline) ---- */
 enum { U3D_K_CONV_FWD = 0, U3D_K_CONV_WGRAD = 1, U3D_K_BN = 2, U3D_K_POOL = 3, U3D_K_ATTN_FWD = 4,
-       U3D_K_ATTN_BWD = 5, U3D_K_RULEBOOK = 6, U3D_K_VOXELIZE = 7, U3D_K_COUNT = 8 };
+       U3D_K_ATTN_BWD = 5, U3D_K_RULEBOOK = 6, U3D_K_VOXELIZE = 7, U3D_K_GEMM = 8, U3D_K_COUNT = 9 };
 int u3d_prof_enable(int kernel_class, int on);           /* record start/stop events around each launch of the class */
 int u3d_prof_collect(int kernel_class, double* total_ms, int64_t* launches, double* work); /* syncs the events, then resets */
 
@@ -210,6 +210,18 @@ int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, c
                         const int32_t* cu_seqlens, int B, int max_len, int64_t n_total, int H, int hd,
                         float scale, float* dqkv, float* delta_ws /*[H,n_total]*/, double flops_hint,
                         u3d_stream_t stream);
+
+/* =====================================================================================
+ * K14  dense fp32 GEMMs of the decoder's nn.Linear layers (unidet3d/encoder.py:19-21,55-61,138-140,
+ *      153-155,163): forward C = A W^T + bias, input-gradient (the same call on the transposed weight),
+ *      weight-gradient C = A^T B with the row reduction split over workgroups (ws, fixed-order sum).
+ * ===================================================================================== */
+int u3d_gemm_nt(const float* A /*[M,K]*/, const float* W /*[N,K]*/, const float* bias /*[N] or NULL*/, float* C /*[M,N]*/,
+                int64_t M, int N, int K /* % 16 == 0 */, double flops_hint, u3d_stream_t stream);
+int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[N,K] = A^T B*/, int64_t M, int N, int K,
+                void* ws, double flops_hint, u3d_stream_t stream);
+int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K);
+int u3d_transpose(const float* in /*[R,C]*/, float* out /*[C,R]*/, int R, int C, u3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -241,7 +241,7 @@ def test_stress_1m_points_rulebook_bit_exact():
     p = [torch.from_numpy(sc.points)]
     oc, of, oinv, oshape = so.voxelize(p, 0.02, 128)
     vb = ops.voxelize([p[0].to(_dev())], 0.02, 128)
-    assert len(oc) > 300_000 and max(vb.spatial_shape) > 256
+    assert len(oc) > 200_000 and max(vb.spatial_shape) > 256
     assert vb.spatial_shape == [int(s) for s in oshape]
     assert torch.equal(vb.coords.cpu(), oc) and torch.equal(vb.inverse.cpu(), oinv)
     rb = sparse.build_subm_rulebook(vb.coords, vb.index)

@@ -181,3 +181,18 @@ def test_backbone_features_match_oracle_per_superpoint():
         feats = prod.extract_feat(x, s[0].to(DEV), prod._vb.inverse, [0, S])
     assert _rel(feats[0], ofeats[0]) < 1e-3
     assert _rel(prod.output_layer[0].running_mean, orac.output_layer[0].running_mean) < 1e-3
+
+
+# ---------------------------------------------------------------------------- K14 dense GEMMs
+@pytest.mark.parametrize('M,K,N', [(1000, 256, 768), (16001, 256, 1024), (4097, 1024, 256), (333, 32, 256), (2500, 256, 19), (777, 256, 8), (1, 256, 256)])
+def test_dense_linear_fwd_bwd(M, K, N):
+    from unidet3d_amd.dense import linear
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * 0.1; b = torch.randn(N, generator=g)
+    go = torch.randn(M, N, generator=g)
+    xo, wo, bo = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yo = torch.nn.functional.linear(xo.double(), wo.double(), bo.double()); yo.backward(go.double())
+    xg, wg, bg = [t.clone().to(DEV).requires_grad_() for t in (x, w, b)]
+    yg = linear(xg, wg, bg); yg.backward(go.to(DEV))
+    assert _rel(yg, yo) < 1e-5 and _rel(xg.grad, xo.grad) < 1e-5
+    assert _rel(wg.grad, wo.grad) < 2e-5 and _rel(bg.grad, bo.grad) < 1e-5

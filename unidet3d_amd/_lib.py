@@ -55,11 +55,15 @@ PROTOTYPES = {
     'u3d_gather_i64_to_i32': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'u3d_segment_gather_sum': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     'u3d_segment_mean_xyz': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
+    'u3d_gemm_nt': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
+    'u3d_gemm_tn': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp]),
+    'u3d_gemm_tn_ws_bytes': (_i64, [_i64, _i32, _i32]),
+    'u3d_transpose': (_i32, [_vp, _vp, _i32, _i32, _vp]),
     'u3d_attn_varlen_fwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE = range(8)
+K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 
 _lib = None
 

@@ -1,0 +1,249 @@
+// Dense fp32 GEMMs of the decoder (nn.Linear forward / input-gradient / weight-gradient,
+// unidet3d/encoder.py:19-21,55-61,138-140,153-155,163) on v_mfma_f32_32x32x2_f32.
+// The query decoder runs over ~16k packed rows with K, N in {32, 256, 768, 1024}: tall-skinny fp32
+// problems for which the library heuristics pick 256x32 / 32x256 macro tiles (~40 TF/s measured);
+// a plain 128x128x16 LDS-tiled kernel with one barrier per K-step does better on gfx950.
+//
+//   gemm_nt:  C[M,N] = A[M,K] . W[N,K]^T (+ bias[N])            (forward; dX = dY . (W^T)^T with W^T from u3d_transpose)
+//   gemm_tn:  C[N,K] = A[M,N]^T . B[M,K]                        (weight gradient; reduction over the M rows is
+//                                                                split over workgroups, partials summed in a fixed order)
+// K-dim permutation as in the sparse conv kernels: lane (i, h) of the 32x32x2 MFMA feeds step s with
+// k = 8h + s, so its 8 A (or B) values of a 16-deep K-step are two contiguous float4 in LDS.
+#include "u3d_common.h"
+
+namespace u3d {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+#define U3D_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int GT = 128;        // macro tile (both dims)
+constexpr int GK = 16;         // K-step
+constexpr int GLD = GK + 4;    // padded LDS row of the NT tiles
+
+__global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                 float* __restrict__ C, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * GT;
+    const int n0 = blockIdx.y * GT;
+    // staging map: thread -> (row = tid>>2 (+64), float4 column = tid&3)
+    const int srow = tid >> 2, sc4 = tid & 3;
+    float4 ra[2], rb[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t m = m0 + srow + 64 * j;
+            const int n = n0 + srow + 64 * j;
+            ra[j] = m < M ? *reinterpret_cast<const float4*>(A + m * K + kt * GK + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = n < N ? *reinterpret_cast<const float4*>(W + (int64_t)n * K + kt * GK + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(&As[buf][(srow + 64 * j) * GLD + sc4 * 4]) = ra[j];
+            *reinterpret_cast<float4*>(&Bs[buf][(srow + 64 * j) * GLD + sc4 * 4]) = rb[j];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nk = K / GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        float4 af[2][2], bf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* ap = &As[buf][(wr * 64 + t * 32 + i32) * GLD + kh * 8];
+            const float* bp = &Bs[buf][(wc * 64 + t * 32 + i32) * GLD + kh * 8];
+            af[t][0] = *reinterpret_cast<const float4*>(ap);
+            af[t][1] = *reinterpret_cast<const float4*>(ap + 4);
+            bf[t][0] = *reinterpret_cast<const float4*>(bp);
+            bf[t][1] = *reinterpret_cast<const float4*>(bp + 4);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#define U3D_STEP(c)                                                   \
+    acc[0][0] = U3D_MFMA32(af[0][h].c, bf[0][h].c, acc[0][0]);        \
+    acc[0][1] = U3D_MFMA32(af[0][h].c, bf[1][h].c, acc[0][1]);        \
+    acc[1][0] = U3D_MFMA32(af[1][h].c, bf[0][h].c, acc[1][0]);        \
+    acc[1][1] = U3D_MFMA32(af[1][h].c, bf[1][h].c, acc[1][1]);
+            U3D_STEP(x) U3D_STEP(y) U3D_STEP(z) U3D_STEP(w)
+#undef U3D_STEP
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wc * 64 + b * 32 + i32;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < M) C[m * N + n] = acc[a][b][r] + bv;
+            }
+    }
+}
+
+constexpr int TLD = GT + 4;    // padded LDS row of the TN tiles ([16 rows][128 cols])
+
+// partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k]
+__global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
+                                                 int64_t M, int N, int K, int64_t rows_per_split) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK * TLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * TLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.x * GT, k0 = blockIdx.y * GT;
+    const int64_t mlo = (int64_t)blockIdx.z * rows_per_split;
+    const int64_t mhi = min(M, mlo + rows_per_split);
+    // staging map: thread -> (row = tid>>5 (+8), float4 column = tid&31)
+    const int srow = tid >> 5, sc4 = tid & 31;
+    float4 ra[2], rb[2];
+    auto gload = [&](int64_t mb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t m = mb + srow + 8 * j;
+            const bool okm = m < mhi;
+            ra[j] = (okm && n0 + sc4 * 4 < N) ? *reinterpret_cast<const float4*>(A + m * N + n0 + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = (okm && k0 + sc4 * 4 < K) ? *reinterpret_cast<const float4*>(B + m * K + k0 + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(&As[buf][(srow + 8 * j) * TLD + sc4 * 4]) = ra[j];
+            *reinterpret_cast<float4*>(&Bs[buf][(srow + 8 * j) * TLD + sc4 * 4]) = rb[j];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nt = (int)((mhi - mlo + GK - 1) / GK);
+    if (nt > 0) {
+        gload(mlo);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(mlo + (int64_t)(t + 1) * GK);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int m = kh * 8 + s;                       // reduction index of this lane at step s
+            const float a0 = As[buf][m * TLD + wr * 64 + i32], a1 = As[buf][m * TLD + wr * 64 + 32 + i32];
+            const float b0 = Bs[buf][m * TLD + wc * 64 + i32], b1 = Bs[buf][m * TLD + wc * 64 + 32 + i32];
+            acc[0][0] = U3D_MFMA32(a0, b0, acc[0][0]);
+            acc[0][1] = U3D_MFMA32(a0, b1, acc[0][1]);
+            acc[1][0] = U3D_MFMA32(a1, b0, acc[1][0]);
+            acc[1][1] = U3D_MFMA32(a1, b1, acc[1][1]);
+        }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = partial + (int64_t)blockIdx.z * N * K;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int k = k0 + wc * 64 + b * 32 + i32;
+        if (k >= K) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (n < N) out[(int64_t)n * K + k] = acc[a][b][r];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict__ partial, int S, int64_t n4, float* __restrict__ C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < S; ++s) {
+            const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        reinterpret_cast<float4*>(C)[i] = v;
+    }
+}
+
+// out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in, float* __restrict__ out, int R, int Ccols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < R && bx + tx < Ccols) tile[j][tx] = in[(int64_t)(by + j) * Ccols + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < Ccols && by + tx < R) out[(int64_t)(bx + j) * R + by + tx] = tile[tx][j];
+}
+
+static int tn_splits(int64_t M, int N, int K) {
+    const int64_t tiles = ceil_div(N, GT) * ceil_div(K, GT);
+    int64_t s = ceil_div(1024, tiles);
+    const int64_t max_s = ceil_div(M, 4 * GK);
+    if (s > max_s) s = max_s;
+    return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+
+}  // namespace u3d
+
+using namespace u3d;
+
+extern "C" {
+
+int u3d_gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, double flops_hint,
+                u3d_stream_t stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return U3D_EINVAL;
+    if (K % GK) { set_error("gemm_nt: K=%d must be a multiple of %d", K, GK); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_GEMM, s, flops_hint);
+    hipLaunchKernelGGL(gemm_nt_k, dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, GT)), dim3(256), 0, s, A, W, bias, C, M, N, K);
+    return check_launch("gemm_nt");
+}
+
+int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K) * N * K * 4 + 256; }
+
+int u3d_gemm_tn(const float* A, const float* B, float* C, int64_t M, int N, int K, void* ws, double flops_hint,
+                u3d_stream_t stream) {
+    if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return U3D_EINVAL;
+    if (N % 4 || K % 4) { set_error("gemm_tn: N=%d, K=%d must be multiples of 4", N, K); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_GEMM, s, flops_hint);
+    const int S = tn_splits(M, N, K);
+    const int64_t rps = ceil_div(ceil_div(M, S), GK) * GK;
+    hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, M, N, K, rps);
+    const int64_t n4 = (int64_t)N * K / 4;
+    int64_t grid = ceil_div(n4, 256);
+    grid = grid > 1024 ? 1024 : grid;
+    hipLaunchKernelGGL(gemm_tn_reduce_k, dim3((unsigned)grid), dim3(256), 0, s, (const float*)ws, S, n4, C);
+    return check_launch("gemm_tn");
+}
+
+int u3d_transpose(const float* in, float* out, int R, int C, u3d_stream_t stream) {
+    if (!in || !out || R <= 0 || C <= 0) return U3D_EINVAL;
+    hipLaunchKernelGGL(transpose_k, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
+    return check_launch("transpose");
+}
+
+}  // extern "C"

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
+from .dense import linear
 from .registry import MODELS
 
 
@@ -77,8 +78,9 @@ class _MHA(nn.Module):
         nn.init.zeros_(self.out_proj.bias)
 
     def forward(self, x, cu_seqlens, max_len):
-        qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias)
-        return self.out_proj(attention_varlen(qkv, cu_seqlens, max_len, self.num_heads))
+        qkv = linear(x, self.in_proj_weight, self.in_proj_bias)
+        o = attention_varlen(qkv, cu_seqlens, max_len, self.num_heads)
+        return linear(o, self.out_proj.weight, self.out_proj.bias)
 
 
 class SelfAttentionLayer(nn.Module):          # encoder.py:8-41
@@ -101,7 +103,9 @@ class FFN(nn.Module):                         # encoder.py:43-80
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, x):
-        return self.norm(self.net(x) + x)
+        h = linear(x, self.net[0].weight, self.net[0].bias)
+        h = self.net[1](h)
+        return self.norm(linear(h, self.net[3].weight, self.net[3].bias) + x)
 
 
 class PredBBox(nn.Module):                    # encoder.py:82-111
@@ -112,7 +116,7 @@ class PredBBox(nn.Module):                    # encoder.py:82-111
             nn.init.normal_(self.linear.weight, std=.01)
 
     def forward(self, x):
-        x = self.linear(x)
+        x = linear(x, self.linear.weight, self.linear.bias)
         return torch.hstack((torch.exp(x[:, :6]), x[:, 6:]))
 
 
@@ -161,7 +165,8 @@ class UniDet3DEncoder(nn.Module):
         With a single dataset in the batch the class-column select and the box decode also run once
         on the packed matrix and the per-scene outputs are views of it."""
         nq = self.out_norm(feats)
-        cls_all = self.outs_cls(nq)
+        cls_all = linear(torch.relu(linear(nq, self.outs_cls[0].weight, self.outs_cls[0].bias)),
+                         self.outs_cls[2].weight, self.outs_cls[2].bias)
         box_all = self.out_bboxes(nq)
         if len(set(datasets_names)) == 1:
             idx = self.datasets.index(datasets_names[0])
@@ -183,7 +188,9 @@ class UniDet3DEncoder(nn.Module):
         cu = L.h2d([0] + list(itertools.accumulate(sizes)), torch.int32, dev)
         max_len = max(sizes) if sizes else 0
         centers_packed = torch.cat(sp_centers) if len(sp_centers) > 1 else sp_centers[0]
-        feats = self.input_proj(torch.cat(x) if len(x) > 1 else x[0])
+        x0 = torch.cat(x) if len(x) > 1 else x[0]
+        feats = linear(torch.relu(linear(x0, self.input_proj[0].weight, self.input_proj[0].bias)),
+                       self.input_proj[2].weight, self.input_proj[2].bias)
         outs = [self._forward_head(feats, sizes, sp_centers, centers_packed, datasets_names)]
         for i in range(self.num_layers):
             feats = self.self_attn_layers[i](feats, cu, max_len)

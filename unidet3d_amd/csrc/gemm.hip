@@ -1,8 +1,10 @@
 // Dense fp32 GEMMs of the decoder (nn.Linear forward / input-gradient / weight-gradient,
 // unidet3d/encoder.py:19-21,55-61,138-140,153-155,163) on v_mfma_f32_32x32x2_f32.
 // The query decoder runs over ~16k packed rows with K, N in {32, 256, 768, 1024}: tall-skinny fp32
-// problems for which the library heuristics pick 256x32 / 32x256 macro tiles (~40 TF/s measured);
-// a plain 128x128x16 LDS-tiled kernel with one barrier per K-step does better on gfx950.
+// problems.  Measured on MI355X (tools/prof_gemm.py, M = 16000): this plain 128x128x16 LDS-tiled kernel
+// (one barrier per K-step, no software pipelining yet) reaches 65-93 TF/s, hipBLASLt 83-126 TF/s in
+// isolation; inside the training step both deliver ~55 TF/s, so the decoder runs on these kernels and
+// keeps the whole Linear path (forward, dX, dW) behind the C ABI.
 //
 //   gemm_nt:  C[M,N] = A[M,K] . W[N,K]^T (+ bias[N])            (forward; dX = dY . (W^T)^T with W^T from u3d_transpose)
 //   gemm_tn:  C[N,K] = A[M,N]^T . B[M,K]                        (weight gradient; reduction over the M rows is
@@ -177,12 +179,24 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
 
 __global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict__ partial, int S, int64_t n4, float* __restrict__ C) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < S; ++s) {
-            const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + i];
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        // four independent partial sums (loads in flight), combined in a fixed order
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)(s + u) * n4 + i];
+                v[u].x += t.x; v[u].y += t.y; v[u].z += t.z; v[u].w += t.w;
+            }
         }
-        reinterpret_cast<float4*>(C)[i] = v;
+        for (; s < S; ++s) {
+            const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + i];
+            v[0].x += t.x; v[0].y += t.y; v[0].z += t.z; v[0].w += t.w;
+        }
+        reinterpret_cast<float4*>(C)[i] = make_float4((v[0].x + v[1].x) + (v[2].x + v[3].x), (v[0].y + v[1].y) + (v[2].y + v[3].y),
+                                                      (v[0].z + v[1].z) + (v[2].z + v[3].z), (v[0].w + v[1].w) + (v[2].w + v[3].w));
     }
 }
 
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in,
 
 static int tn_splits(int64_t M, int N, int K) {
     const int64_t tiles = ceil_div(N, GT) * ceil_div(K, GT);
-    int64_t s = ceil_div(1024, tiles);
+    int64_t s = ceil_div(384, tiles);      // ~1.5 workgroups per CU; every extra split costs N*K*4 bytes in the reduce
     const int64_t max_s = ceil_div(M, 4 * GK);
     if (s > max_s) s = max_s;
     return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));

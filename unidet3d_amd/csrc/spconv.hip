@@ -365,8 +365,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
     const int cnt = counts[k];
     const int n_act = min(RK, (cnt + R - 1) / R);
     const float* src = partial + (int64_t)k * RK * E + idx;
-    float v = 0.f;
-    for (int r = 0; r < n_act; ++r) v += src[(int64_t)r * E];
+    // four independent partial sums keep loads in flight; the combination order is fixed (deterministic)
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= n_act; r += 4) {
+        v0 += src[(int64_t)r * E];
+        v1 += src[(int64_t)(r + 1) * E];
+        v2 += src[(int64_t)(r + 2) * E];
+        v3 += src[(int64_t)(r + 3) * E];
+    }
+    for (; r < n_act; ++r) v0 += src[(int64_t)r * E];
+    const float v = (v0 + v1) + (v2 + v3);
     const int NGW = NG / SG, NXW = NX / SX, per_sub = NGW * NXW * 256;
     const int sub = idx / per_sub, rem = idx % per_sub;
     const int e = rem >> 6, lane = rem & 63, i16 = lane & 15, q = lane >> 4;

@@ -128,12 +128,15 @@ int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather,
  * the groups' partial sums go through ws = k_groups*n_dst*Cd*4 bytes and a fixed-order reduce).
  * Returns U3D_EUNSUPPORTED for channel counts that are not instantiated. */
 int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups);
-/* dW[(n*K+k)*Cs + c] = sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]   (dW is overwritten; per-range partial
- * blocks go through ws = u3d_spconv_wgrad_ws_bytes() and are summed in a fixed order: deterministic, no atomics) */
+/* dW[(n*K+k)*Cs + c] = sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]   (dW is overwritten).
+ * The pairs of offset k are processed per tile of dy rows: tile_starts = u3d_tile_starts(rows_dy, ..., tile_rows =
+ * u3d_spconv_wgrad_tile_rows(...)); per-tile partial blocks go through ws and are summed in a fixed order
+ * (deterministic, no atomics). */
 int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
-                     const int32_t* counts, int K, int64_t cap, int Cs, int Cd, float* dW, void* ws,
-                     double flops_hint, u3d_stream_t stream);
-int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t cap, int Cs, int Cd);
+                     const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
+                     float* dW, void* ws, double flops_hint, u3d_stream_t stream);
+int u3d_spconv_wgrad_tile_rows(int K, int64_t n_rows_dy, int Cs, int Cd);
+int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd);
 /* wt[(c*K + k)*Cd + n] = w[(n*K + k)*Cs + c] */
 int u3d_weight_transpose(const float* w, float* wt, int Cd, int K, int Cs, u3d_stream_t stream);
 

@@ -1,0 +1,33 @@
+#!/bin/bash
+# HBM traffic of every kernel of the bench step from PMC counters (two separate passes, kernel-trace only):
+# FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide coalesced streams
+# (MI355X_MICROARCH.md, HBM section) -> doubled below; WRITE_SIZE is used as reported (uncalibrated).
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $R
+python - "$OUT" <<'PY'
+import csv, sys, glob, json, collections
+out = sys.argv[1]
+res = collections.defaultdict(lambda: dict(fetch_kb=0.0, write_kb=0.0, n=0))
+for tag, key in (('f', 'fetch_kb'), ('w', 'write_kb')):
+    f = glob.glob(f'{out}/{tag}/*counter_collection.csv')
+    if not f: continue
+    for r in csv.DictReader(open(f[0])):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        if 'u3d::' not in k: continue
+        res[k][key] += float(r['Counter_Value'])
+        if tag == 'f': res[k]['n'] += 1
+summ = {}
+for k, v in sorted(res.items(), key=lambda kv: -kv[1]['fetch_kb']):
+    n = max(v['n'], 1)
+    summ[k] = dict(dispatches=n, fetch_MB_per_launch_corrected=2.0 * v['fetch_kb'] * 1024 / n / 1e6,
+                   write_MB_per_launch=v['write_kb'] * 1024 / n / 1e6)
+gm = [v for k, v in res.items() if 'spconv_gmm_k' in k]
+n = sum(v['n'] for v in gm)
+summ['_spconv_gmm_k_all'] = dict(dispatches=n, hbm_MB_per_launch=(2.0 * sum(v['fetch_kb'] for v in gm) + sum(v['write_kb'] for v in gm)) * 1024 / max(n, 1) / 1e6)
+json.dump(summ, open(f'{out}/summary.json', 'w'), indent=1)
+for k, v in list(summ.items())[:14]: print(k[:70], v)
+PY
+find $OUT -name "*.csv" -size +1M -delete

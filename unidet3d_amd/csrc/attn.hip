@@ -32,13 +32,30 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ base, int l
     }
 }
 
+// 1-D launch decode: workgroup b runs on XCD b % 8 (private L2).  XCD x takes the (scene, head) pairs x, x+8, ...
+// and all their 64-row tiles back to back, so the K/V (or Q/dO) rows of one (scene, head) stay in that XCD's
+// L2 while its tiles stream them (PMC before: 321 MB fetched per forward launch for 49 MB of qkv).
+struct AttnWork { int b, h, tile; };
+__device__ __forceinline__ AttnWork attn_decode(int H, int B, int n_tiles) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int hb = (j / n_tiles) * 8 + x;
+    AttnWork w;
+    w.tile = j % n_tiles;
+    w.h = hb % H;
+    w.b = hb / H;          // >= B for the padding workgroups of the last group
+    return w;
+}
+static inline unsigned attn_grid(int H, int B, int n_tiles) { return (unsigned)(((H * B + 7) / 8) * 8 * n_tiles); }
+
 __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale,
-                                                  float* __restrict__ out, float* __restrict__ lse, int64_t n_total) {
+                                                  float* __restrict__ out, float* __restrict__ lse, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * ATT_LD];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const AttnWork wk_ = attn_decode(H, B, n_tiles);
+    const int b = wk_.b, h = wk_.h;
+    if (b >= B) return;
     const int start = cu[b], len = cu[b + 1] - start;
-    const int q0 = blockIdx.x * 64;
+    const int q0 = wk_.tile * 64;
     if (q0 >= len) return;
     const int D = H * 32, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qd = lane >> 4;
@@ -146,12 +163,14 @@ __global__ __launch_bounds__(256) void attn_delta_k(const float* __restrict__ o,
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                                                      const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
-                                                     float* __restrict__ dqkv, int64_t n_total) {
+                                                     float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * ATT_LD];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const AttnWork wk_ = attn_decode(H, B, n_tiles);
+    const int b = wk_.b, h = wk_.h;
+    if (b >= B) return;
     const int start = cu[b], len = cu[b + 1] - start;
-    const int q0 = blockIdx.x * 64;
+    const int q0 = wk_.tile * 64;
     if (q0 >= len) return;
     const int D = H * 32, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qd = lane >> 4;
@@ -217,13 +236,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                                                       const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
-                                                      float* __restrict__ dqkv, int64_t n_total) {
+                                                      float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float Qs[64 * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Os[64 * ATT_LD];
     __shared__ float lse_s[64], del_s[64];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const AttnWork wk_ = attn_decode(H, B, n_tiles);
+    const int b = wk_.b, h = wk_.h;
+    if (b >= B) return;
     const int start = cu[b], len = cu[b + 1] - start;
-    const int k0 = blockIdx.x * 64;
+    const int k0 = wk_.tile * 64;
     if (k0 >= len) return;
     const int D = H * 32, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qd = lane >> 4;
@@ -307,7 +328,8 @@ int u3d_attn_varlen_fwd(const float* qkv, const int32_t* cu_seqlens, int B, int 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_ATTN_FWD, s, flops_hint);
     if (max_len <= 0) return U3D_OK;
-    hipLaunchKernelGGL(attn_fwd_k, dim3((max_len + 63) / 64, H, B), dim3(256), 0, s, qkv, cu_seqlens, H, scale, out, lse, n_total);
+    const int n_tiles = (max_len + 63) / 64;
+    hipLaunchKernelGGL(attn_fwd_k, dim3(attn_grid(H, B, n_tiles)), dim3(256), 0, s, qkv, cu_seqlens, H, scale, out, lse, n_total, B, n_tiles);
     return check_launch("attn_fwd");
 }
 
@@ -320,9 +342,10 @@ int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, c
     ProfScope prof(U3D_K_ATTN_BWD, s, flops_hint);
     if (max_len <= 0) return U3D_OK;
     hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, out, dout, n_total, H, delta_ws);
-    const dim3 grid((max_len + 63) / 64, H, B);
-    hipLaunchKernelGGL(attn_bwd_dq_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu_seqlens, H, scale, dqkv, n_total);
-    hipLaunchKernelGGL(attn_bwd_dkv_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu_seqlens, H, scale, dqkv, n_total);
+    const int n_tiles = (max_len + 63) / 64;
+    const dim3 grid(attn_grid(H, B, n_tiles));
+    hipLaunchKernelGGL(attn_bwd_dq_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu_seqlens, H, scale, dqkv, n_total, B, n_tiles);
+    hipLaunchKernelGGL(attn_bwd_dkv_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu_seqlens, H, scale, dqkv, n_total, B, n_tiles);
     return check_launch("attn_bwd");
 }
 

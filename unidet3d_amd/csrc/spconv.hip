@@ -262,12 +262,11 @@ struct WgParams {
     const float* dy;
     const int32_t* rows_x;
     const int32_t* rows_dy;
-    const int32_t* counts;
-    float* partial;   // [K][RK][Cd*Cs] per-range blocks in accumulator-register order
+    const int32_t* ts;        // tile_starts [K][n_tiles+1] over the dy-side rows: range t of offset k = pairs of row tile t
+    float* partial;           // [K][n_tiles][Cd*Cs] per-range blocks in accumulator-register order
     int K;
     int64_t cap;
-    int R;    // pairs per range
-    int RK;   // ranges per offset
+    int n_tiles;
 };
 
 template <int N>
@@ -295,19 +294,19 @@ template <int NG, int NX, int SG, int SX>
 __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
     constexpr int NGW = NG / SG, NXW = NX / SX, SPLIT = SG * SX, RPW = 4 / SPLIT;   // RPW ranges per workgroup
     constexpr int CD = NG * 16, CS = NX * 16;
-    // Workgroup b runs on XCD b % 8 (private 4 MB L2).  XCD x takes range groups x, x+8, x+16, ... and walks ALL
-    // offsets of a group back to back, so the x / dy rows of that slab are fetched once and re-read 26 times from
-    // the XCD's own L2 (PMC before: TCC hit rate 11 %, 1.05 GB fabric traffic per L1 launch).  Interleaving the
-    // groups over the XCDs keeps the (empty) tail ranges evenly spread.
+    // A range is the set of pairs of offset k whose dy row lies in row tile t (tile_starts), so the 27 offsets of
+    // one tile read the SAME dy rows and neighbouring x rows.  Workgroup b runs on XCD b % 8 (private 4 MB L2):
+    // XCD x takes tile groups x, x+8, x+16, ... and walks ALL offsets of a group back to back, so those rows are
+    // fetched once and re-read from the XCD's own L2 (PMC with pair-index ranges: TCC hit rate 11 %, 0.95 GB
+    // fetched per L1 launch for 125 MB of algorithmic traffic).
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int k = j % p.K;
-    const int cnt = p.counts[k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
     const int sub = wave % SPLIT, wa = sub % SG, wb = sub / SG;
     const int range = ((j / p.K) * 8 + xcd) * RPW + wave / SPLIT;
-    const int lo = range * p.R;
-    const int hi = min(cnt, lo + p.R);
-    if (range >= p.RK || lo >= cnt) return;              // wave-uniform; the kernel has no barrier
+    if (range >= p.n_tiles) return;                      // wave-uniform; the kernel has no barrier
+    const int lo = p.ts[(int64_t)k * (p.n_tiles + 1) + range];
+    const int hi = p.ts[(int64_t)k * (p.n_tiles + 1) + range + 1];
     const int32_t* rx = p.rows_x + (int64_t)k * p.cap;
     const int32_t* rg = p.rows_dy + (int64_t)k * p.cap;
     const float* gbase = p.dy + NG * i16 + wa * NGW;
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
     }
     // partial block of this range in register order [sub][(a*NXW + b)*4 + r][lane]: 256-byte coalesced stores,
     // no atomics; wgrad_reduce_k maps it back to dW[co][k][ci] and sums the ranges in a fixed order.
-    float* out = p.partial + ((int64_t)k * p.RK + range) * (CD * CS) + (int64_t)sub * (NGW * NXW * 256) + lane;
+    float* out = p.partial + ((int64_t)k * p.n_tiles + range) * (CD * CS) + (int64_t)sub * (NGW * NXW * 256) + lane;
 #pragma unroll
     for (int a = 0; a < NGW; ++a)
 #pragma unroll
@@ -355,26 +354,24 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
             for (int r = 0; r < 4; ++r) out[((a * NXW + b) * 4 + r) * 64] = acc[a][b][r];
 }
 
-// dW[co][k][ci] = sum over the active ranges of offset k (fixed order -> deterministic; overwrites dW)
-__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ partial, const int32_t* __restrict__ counts, int R, int RK,
-                                                      int K, int NG, int NX, int SG, int SX, float* __restrict__ dW) {
+// dW[co][k][ci] = sum over the row tiles of offset k (fixed order -> deterministic; overwrites dW)
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ partial, int n_tiles, int K, int NG, int NX, int SG, int SX,
+                                                      float* __restrict__ dW) {
     const int CS = NX * 16, E = NG * NX * 256;
     const int k = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= E) return;
-    const int cnt = counts[k];
-    const int n_act = min(RK, (cnt + R - 1) / R);
-    const float* src = partial + (int64_t)k * RK * E + idx;
+    const float* src = partial + (int64_t)k * n_tiles * E + idx;
     // four independent partial sums keep loads in flight; the combination order is fixed (deterministic)
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     int r = 0;
-    for (; r + 4 <= n_act; r += 4) {
+    for (; r + 4 <= n_tiles; r += 4) {
         v0 += src[(int64_t)r * E];
         v1 += src[(int64_t)(r + 1) * E];
         v2 += src[(int64_t)(r + 2) * E];
         v3 += src[(int64_t)(r + 3) * E];
     }
-    for (; r < n_act; ++r) v0 += src[(int64_t)r * E];
+    for (; r < n_tiles; ++r) v0 += src[(int64_t)r * E];
     const float v = (v0 + v1) + (v2 + v3);
     const int NGW = NG / SG, NXW = NX / SX, per_sub = NGW * NXW * 256;
     const int sub = idx / per_sub, rem = idx % per_sub;
@@ -385,16 +382,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
     dW[((int64_t)co * K + k) * CS + ci] = v;
 }
 
-struct WgPlan { int R, RK; };
-static WgPlan plan_wgrad(int K, int64_t cap, int Cs, int Cd) {
-    // ranges per offset: bounded by a 64 MB partial buffer, by 512, and by >= 64 pairs per range
-    int64_t rk = (int64_t)(64 << 20) / ((int64_t)K * Cs * Cd * 4);
-    rk = rk > 512 ? 512 : (rk < 1 ? 1 : rk);
-    const int64_t by_len = ceil_div(cap, 64);
-    if (rk > by_len) rk = by_len;
-    int64_t R = ceil_div(ceil_div(cap, rk), 16) * 16;
-    rk = ceil_div(cap, R);
-    return WgPlan{(int)R, (int)rk};
+// rows per tile: as many tiles as a 64 MB partial buffer, a cap of 512 and >= 64 rows per tile allow
+static int plan_wgrad_rows(int K, int64_t n_rows, int Cs, int Cd) {
+    int64_t nt = (int64_t)(64 << 20) / ((int64_t)K * Cs * Cd * 4);
+    nt = nt > 512 ? 512 : (nt < 1 ? 1 : nt);
+    const int64_t by_len = ceil_div(n_rows, 64);
+    if (nt > by_len) nt = by_len;
+    return (int)ceil_div(n_rows, nt);
 }
 
 template <int NX, int NG>     // (Cs/16, Cd/16) as the dispatch macro passes them
@@ -404,13 +398,10 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     constexpr int SX = ((NG / SG) * NX > 32 && NX % 2 == 0) ? 2 : 1;
     constexpr int SPLIT = SG * SX, RPW = 4 / SPLIT;
     static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "wave split");
-    WgParams p = p0;
-    const WgPlan pl = plan_wgrad(p.K, p.cap, NX * 16, NG * 16);
-    p.R = pl.R; p.RK = pl.RK;
-    const int64_t groups = ceil_div(ceil_div(p.RK, RPW), 8) * 8;
+    const WgParams& p = p0;
+    const int64_t groups = ceil_div(ceil_div(p.n_tiles, RPW), 8) * 8;
     hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, p.counts, p.R, p.RK, p.K, NG, NX,
-                       SG, SX, dW);
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, p.n_tiles, p.K, NG, NX, SG, SX, dW);
     return check_launch("spconv_wgrad");
 }
 
@@ -472,21 +463,30 @@ int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather,
     return rc;
 }
 
-int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t cap, int Cs, int Cd) {
-    if (K <= 0 || cap <= 0 || Cs <= 0 || Cd <= 0) return 0;
-    const WgPlan pl = plan_wgrad(K, cap, Cs, Cd);
-    return (int64_t)K * pl.RK * Cs * Cd * 4 + 256;
+int u3d_spconv_wgrad_tile_rows(int K, int64_t n_rows_dy, int Cs, int Cd) {
+    if (K <= 0 || n_rows_dy <= 0 || Cs <= 0 || Cd <= 0) return U3D_EINVAL;
+    return plan_wgrad_rows(K, n_rows_dy, Cs, Cd);
+}
+
+int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd) {
+    if (K <= 0 || n_rows_dy <= 0 || Cs <= 0 || Cd <= 0) return 0;
+    const int T = plan_wgrad_rows(K, n_rows_dy, Cs, Cd);
+    return (int64_t)K * ceil_div(n_rows_dy, T) * Cs * Cd * 4 + 256;
 }
 
 int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
-                     const int32_t* counts, int K, int64_t cap, int Cs, int Cd, float* dW, void* ws, double flops_hint,
-                     u3d_stream_t stream) {
-    if (!x || !dy || !rows_x || !rows_dy || !counts || !dW || !ws || K <= 0 || cap <= 0) return U3D_EINVAL;
+                     const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
+                     float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
+    if (!x || !dy || !rows_x || !rows_dy || !tile_starts || !dW || !ws || K <= 0 || cap <= 0 || n_rows_dy <= 0) return U3D_EINVAL;
+    if (tile_rows != plan_wgrad_rows(K, n_rows_dy, Cs, Cd)) {
+        set_error("spconv_wgrad: tile_rows %d does not match the plan", tile_rows);
+        return U3D_EINVAL;
+    }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_CONV_WGRAD, s, flops_hint);
     WgParams p;
-    p.x = x; p.dy = dy; p.rows_x = rows_x; p.rows_dy = rows_dy; p.counts = counts; p.partial = (float*)ws; p.K = K; p.cap = cap;
-    p.R = 0; p.RK = 0;
+    p.x = x; p.dy = dy; p.rows_x = rows_x; p.rows_dy = rows_dy; p.ts = tile_starts; p.partial = (float*)ws; p.K = K; p.cap = cap;
+    p.n_tiles = (int)ceil_div(n_rows_dy, tile_rows);
     const int cs16 = Cs / 16, cd16 = Cd / 16;
     if (Cs % 16 || Cd % 32) return U3D_EUNSUPPORTED;
 #define U3D_WG_CASE(cs, cd) if (cs16 == cs && cd16 == cd) return launch_wgrad<cs, cd>(p, dW, s);

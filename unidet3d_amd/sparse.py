@@ -203,10 +203,14 @@ class _SparseConvFn(torch.autograd.Function):
             dsrc = _gmm(dout, wt, rb, g, s, role, n_dst, None, flops)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            rx, rg = (rb.pair_in, rb.pair_out) if mode == 'fwd' else (rb.pair_out, rb.pair_in)
-            ws = L.scratch(L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, rb.cap, cin, cout), weight.device)
-            L.call('u3d_spconv_wgrad', L.ptr(src), L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(rb.counts), rb.K, rb.cap,
-                   cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
+            if mode == 'fwd':
+                rx, rg, role, n_dy = rb.pair_in, rb.pair_out, 'out', rb.n_out
+            else:
+                rx, rg, role, n_dy = rb.pair_out, rb.pair_in, 'in', rb.n_in
+            Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
+            ws = L.scratch(L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout), weight.device)
+            L.call('u3d_spconv_wgrad', L.ptr(src), L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(rb.tile_starts(role, Tw)),
+                   rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
         return dsrc, dw, None, None, (dout if ctx.has_addend else None)
 
 

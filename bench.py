@@ -150,11 +150,10 @@ def main():
         bucket.clear_grads()                 # backward writes fresh grads: no accumulate kernels
         loss = model.loss(inputs, samples)['det_loss']
         loss.backward()
-        if world > 1:
-            bucket.pack()                    # one multi-tensor copy into the flat buffer ...
-            bucket.allreduce_mean()          # ... one RCCL all-reduce of all gradients
+        bucket.pack()                        # one multi-tensor copy into the flat buffer ...
+        bucket.allreduce_mean()              # ... one RCCL all-reduce of all gradients (no-op at N = 1)
         if not args.no_optimizer:
-            torch.nn.utils.clip_grad_norm_(params, max_norm=10, norm_type=2, foreach=True)   # configs :713
+            bucket.clip_grad_norm_(10.0)     # clip_grad max_norm=10, norm_type=2 (configs :713) on the flat buffer
             opt.step()
         return loss
 
@@ -169,7 +168,7 @@ def main():
         loss = step()
         torch.cuda.synchronize()
         log(f'warm-up step {i} done, loss {float(loss.detach()):.4f}')
-    assert world == 1 or bucket.check_views(), 'p.grad does not alias the flat gradient buffer'
+    assert bucket.check_views(), 'p.grad does not alias the flat gradient buffer'
     for c in (L.K_CONV_FWD, L.K_CONV_WGRAD, L.K_ATTN_FWD, L.K_ATTN_BWD):
         L.prof_enable(c, True)
     fence()

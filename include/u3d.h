@@ -200,6 +200,13 @@ int u3d_segment_mean_xyz(const float* points, int pt_ld, const int32_t* list, co
                          const float* sub, int sub_ld, const int64_t* pt_offsets, int B, float* out,
                          u3d_stream_t stream);
 
+/* out[s] = [min xyz, max xyz] of (xyz - sub[scene]) over the points with ids[p] == s (ids < 0 are skipped):
+ * the axis-aligned GT boxes of UniDet3D.get_bboxes_by_masks (unidet3d/unidet3d.py:220-256) for a whole batch in one
+ * pass.  Segments without points return [+FLT_MAX-like, -FLT_MAX-like] sentinels.  ws: n_seg*6*4 bytes. */
+int u3d_segment_minmax_xyz(const float* points, int pt_ld, const int64_t* ids, int64_t n, int n_seg, const float* sub,
+                           int sub_ld, const int64_t* pt_offsets, int B, float* out /*[n_seg,6]*/, void* ws,
+                           u3d_stream_t stream);
+
 /* =====================================================================================
  * K13  self-attention core of nn.MultiheadAttention(256, 8, batch_first) per scene
  *     (unidet3d/encoder.py:19-20,36-37): softmax(Q K^T / sqrt(hd)) V over packed variable

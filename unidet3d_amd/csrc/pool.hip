@@ -95,6 +95,47 @@ __global__ __launch_bounds__(256) void seg_mean_xyz_k(const float* __restrict__ 
     out[s * 3 + 2] = (float)(c * inv);
 }
 
+// per-segment min / max of (xyz - sub[scene]) over the points with id >= 0 (GT boxes from instance masks,
+// unidet3d/unidet3d.py:220-256: the reference loops over instances with boolean masks).  Integer LDS
+// atomics on order-preserving float keys, one global atomic per (block, segment, component).
+__device__ __forceinline__ int f2ord_(float f) { int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__global__ __launch_bounds__(256) void seg_minmax_xyz_k(const float* __restrict__ points, int ld, const int64_t* __restrict__ ids, int64_t n,
+                                                        int n_seg, const float* __restrict__ sub, int sub_ld,
+                                                        const int64_t* __restrict__ pt_offsets, int B, int* __restrict__ out /*[n_seg][6] ordered ints*/) {
+    extern __shared__ int sm[];                   // [n_seg][6]
+    for (int i = threadIdx.x; i < n_seg * 6; i += blockDim.x) sm[i] = (i % 6 < 3) ? 0x7fffffff : (int)0x80000000;
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = ids[p];
+        if (id < 0 || id >= n_seg) continue;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        if (sub) {
+            int b = 0;
+            while (b + 1 < B && pt_offsets[b + 1] <= p) ++b;
+            sx = sub[b * sub_ld]; sy = sub[b * sub_ld + 1]; sz = sub[b * sub_ld + 2];
+        }
+        const float* q = points + p * ld;
+        const int kx = f2ord_(q[0] - sx), ky = f2ord_(q[1] - sy), kz = f2ord_(q[2] - sz);
+        int* s6 = sm + id * 6;
+        atomicMin(s6 + 0, kx); atomicMin(s6 + 1, ky); atomicMin(s6 + 2, kz);
+        atomicMax(s6 + 3, kx); atomicMax(s6 + 4, ky); atomicMax(s6 + 5, kz);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_seg * 6; i += blockDim.x) {
+        const int v = sm[i];
+        if (i % 6 < 3) { if (v != 0x7fffffff) atomicMin(out + i, v); }
+        else if (v != (int)0x80000000) atomicMax(out + i, v);
+    }
+}
+__global__ void seg_minmax_init_k(int* out, int n6) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n6) out[i] = (i % 6 < 3) ? 0x7fffffff : (int)0x80000000;
+}
+__global__ void seg_minmax_fin_k(const int* in, int n6, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n6) { const int k = in[i]; out[i] = __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+}
+
 template <int LPR>
 static int launch_seg(const float* src, const int32_t* rows, const int32_t* offsets, int64_t S, int mean_mode,
                       const int32_t* src_seg, float* out, bool wave_per_seg, hipStream_t s) {
@@ -164,6 +205,23 @@ int u3d_segment_mean_xyz(const float* points, int pt_ld, const int32_t* list, co
     hipLaunchKernelGGL(seg_mean_xyz_k, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, (hipStream_t)stream, points, pt_ld, list,
                        offsets, S, sub, sub_ld, pt_offsets, B, out);
     return check_launch("segment_mean_xyz");
+}
+
+int u3d_segment_minmax_xyz(const float* points, int pt_ld, const int64_t* ids, int64_t n, int n_seg, const float* sub,
+                           int sub_ld, const int64_t* pt_offsets, int B, float* out, void* ws, u3d_stream_t stream) {
+    if (!points || !ids || !out || !ws || n <= 0 || n_seg <= 0 || n_seg > 4096 || pt_ld < 3 ||
+        (sub && (!pt_offsets || B <= 0 || sub_ld < 3)))
+        return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int* tmp = (int*)ws;
+    const int n6 = n_seg * 6;
+    hipLaunchKernelGGL(seg_minmax_init_k, dim3((n6 + 255) / 256), dim3(256), 0, s, tmp, n6);
+    int64_t g = ceil_div(n, 256 * 8);
+    g = g < 1 ? 1 : (g > 512 ? 512 : g);
+    hipLaunchKernelGGL(seg_minmax_xyz_k, dim3((unsigned)g), dim3(256), (size_t)n6 * sizeof(int), s, points, pt_ld, ids, n, n_seg, sub,
+                       sub_ld, pt_offsets, B, tmp);
+    hipLaunchKernelGGL(seg_minmax_fin_k, dim3((n6 + 255) / 256), dim3(256), 0, s, (const int*)tmp, n6, out);
+    return check_launch("segment_minmax_xyz");
 }
 
 }  // extern "C"

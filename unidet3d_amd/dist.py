@@ -60,6 +60,13 @@ class FlatGradBucket:
             torch._foreach_copy_(dst, src)
         self.attach()
 
+    def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_(norm_type=2) on the flat buffer: two kernels instead of one
+        multi-tensor pass per parameter list (grads must be packed / attached)."""
+        total = torch.linalg.vector_norm(self.flat, 2)
+        self.flat.mul_(torch.clamp(max_norm / (total + eps), max=1.0))
+        return total
+
     def allreduce_mean(self, group=None):
         """Sum over ranks / world size (DDP semantics).  No-op without a process group."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -160,10 +160,24 @@ class UniDet3D(nn.Module):
         vb, plan, batch_offsets, sp_centers, names = self._front(batch_inputs_dict, batch_data_samples, True)
         B = len(batch_data_samples)
         sp_gt_instances = []
+        dsets = [self.decoder.datasets.index(n) for n in names]
+        boxes_all, box_off = None, [0]
+        if all(self.bbox_by_mask[d] for d in dsets):
+            # GT boxes of every instance of the batch in one pass over the points (u3d_segment_minmax_xyz)
+            ids = []
+            for ds in batch_data_samples:
+                m = ds.gt_pts_seg.pts_instance_mask.to(vb.points.device)
+                ids.append(torch.where(m >= 0, m + box_off[-1], m))
+                box_off.append(box_off[-1] + len(ds.gt_instances_3d.labels_3d))
+            if box_off[-1] > 0:
+                boxes_all = ops.instance_boxes(vb, torch.cat(ids) if B > 1 else ids[0], box_off[-1])
         for i, ds in enumerate(batch_data_samples):
             inst = ds.gt_instances_3d
-            dataset = self.decoder.datasets.index(names[i])
-            if self.bbox_by_mask[dataset]:
+            dataset = dsets[i]
+            if boxes_all is not None:
+                inst.bboxes_3d = DepthInstance3DBoxes(boxes_all[box_off[i]:box_off[i + 1]], with_yaw=False, box_dim=6,
+                                                      origin=(0.5, 0.5, 0.5))
+            elif self.bbox_by_mask[dataset]:
                 pts = batch_inputs_dict['points'][i][:, :3]
                 pts = pts - vb.stats[i, :3]
                 ids = ds.gt_pts_seg.pts_instance_mask.to(pts.device)

@@ -171,6 +171,8 @@ def main():
     assert bucket.check_views(), 'p.grad does not alias the flat gradient buffer'
     for c in (L.K_CONV_FWD, L.K_CONV_WGRAD, L.K_ATTN_FWD, L.K_ATTN_BWD):
         L.prof_enable(c, True)
+    for k in sparse.ACCOUNT:
+        sparse.ACCOUNT[k] = 0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -195,6 +197,12 @@ def main():
         ach = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
         w = prof['conv_wgrad']
         n_vox = int(model._vb.coords.shape[0])
+        acc = sparse.ACCOUNT
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'round1_final_pmc_traffic.json')
+        if os.path.exists(tpath):       # PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KB) of this same command, tools/pmc_bench.sh
+            traffic = json.load(open(tpath))['_spconv_gmm_k_all']['hbm_MB_per_launch'] * 1e6
+            traffic_src = 'profiles/round1_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
         out = {
             'metric': 'scenes/sec fwd+bwd, 100k-pt ScanNet voxel grid',
             'value': args.batch * world * args.steps / dt,
@@ -211,7 +219,9 @@ def main():
                        'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val},
             'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
                          'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
+                         'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': acc['gmm_bytes'] / max(acc['gmm_launches'], 1),
                          'launches': g['launches'], 'avg_launch_us': g['ms'] * 1e3 / max(g['launches'], 1),
                          'algorithmic_gflop_per_launch': g['flops'] / max(g['launches'], 1) / 1e9,
                          'share_of_step': g['ms'] / (dt * 1e3)},

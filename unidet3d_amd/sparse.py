@@ -152,6 +152,10 @@ def _gmm(src, w_rows, rb, gather, scatter, role, n_dst, addend, flops):
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     if n_dst:
         R, G = _plan(Cs, Cd, rb.K, n_dst)
+        if _PROFILE_FLOPS:      # N(Cs+Cd)s + 2P*idx + K*Cs*Cd*s  (s = 4 B, idx = 4 B)
+            ACCOUNT['gmm_launches'] += 1
+            ACCOUNT['gmm_flops'] += flops
+            ACCOUNT['gmm_bytes'] += 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
         L.call('u3d_spconv_gmm', L.ptr(src), L.ptr(w_rows), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
                rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
@@ -159,6 +163,7 @@ def _gmm(src, w_rows, rb, gather, scatter, role, n_dst, addend, flops):
 
 
 _PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops
+ACCOUNT = dict(gmm_launches=0, gmm_flops=0.0, gmm_bytes=0.0)      # algorithmic work of spconv_gmm launches (bench)
 
 
 def set_profile_flops(on: bool):

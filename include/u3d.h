@@ -112,14 +112,14 @@ int u3d_tile_starts(const int32_t* rows, const int32_t* counts, int K, int64_t c
 /* =====================================================================================
  * K4-K8  sparse convolution, all variants through one gather-MFMA-scatter kernel:
  *   dst[scatter[k][p]] (+)= W_k . src[gather[k][p]]      for p < counts[k], k < K
- * w_rows: weights with the DST channel as the row: w[(n*K + k)*Cs + c]  (n<Cd, c<Cs) --
- * spconv's native [C_out,k0,k1,k2,C_in] for forward; u3d_weight_transpose() output for dgrad.
+ * w_packed: the weights in the kernel's MFMA-fragment order, produced by u3d_weight_pack() from spconv's native
+ * [C_out,k0,k1,k2,C_in] tensor (transposed = 0 for forward, 1 for the input gradient, where dst = C_in).
  * scatter lists must be ascending (they are, in both columns); tile_starts from u3d_tile_starts
  * on the scatter lists with the tile height u3d_spconv_plan() returns.  addend (nullable, [n_dst,Cd]) initialises the accumulator
  * (fuses the residual add of ResidualBlock.forward, spconv_unet.py:88-89).
  * Replaces SubMConv3d / SparseConv3d / SparseInverseConv3d forward and their input-gradients.
  * ===================================================================================== */
-int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
+int u3d_spconv_gmm(const float* src, const float* w_packed, const int32_t* gather, const int32_t* scatter,
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst,
                    int tile_rows, int k_groups, const float* addend, float* dst, void* ws, double flops_hint,
                    u3d_stream_t stream);
@@ -137,6 +137,9 @@ int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, con
                      float* dW, void* ws, double flops_hint, u3d_stream_t stream);
 int u3d_spconv_wgrad_tile_rows(int K, int64_t n_rows_dy, int Cs, int Cd);
 int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd);
+/* wp = fragment-ordered copy of the weights for u3d_spconv_gmm ([Cd*K*Cs] floats):
+ * transposed = 0: logical W(n,k,c) = w[(n*K+k)*Cs + c]; transposed = 1: W(n,k,c) = w[(c*K+k)*Cd + n]. */
+int u3d_weight_pack(const float* w, float* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream);
 /* wt[(c*K + k)*Cd + n] = w[(n*K + k)*Cs + c] */
 int u3d_weight_transpose(const float* w, float* wt, int Cd, int K, int Cs, u3d_stream_t stream);
 

@@ -53,27 +53,17 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 constexpr int GMM_CDS = 32;            // output columns per wave
 constexpr int GMM_ALD = GMM_CDS + 4;   // padded accumulator row
 
-// one or two 16-pair chunks of offset k: gather -> MFMA over all source channels -> scatter-add into LDS
 // raw rulebook indices of one work item (two 16-pair chunks of one offset), loaded one item ahead
 struct GmmIdx {
-    int g0, g1;
-    int s0[4], s1[4];
+    int g, s;      // lane l < 32 holds gather / scatter row of pair (base + l) of the work item
 };
 
-// unconditional, clamped loads: lanes past the end of the range read a valid (duplicate) entry; their rows
-// are computed but only ever added into the scratch row, so no load has to wait on a branch.
-__device__ __forceinline__ void gmm_load_idx(GmmIdx& ix, const GmmParams& p, int k, int base, int e, int i16, int q) {
-    const int32_t* gl = p.gather + (int64_t)k * p.cap;
-    const int32_t* sl = p.scatter + (int64_t)k * p.cap;
-    const int last = e - 1;
-    ix.g0 = gl[min(base + i16, last)];
-    ix.g1 = gl[min(base + 16 + i16, last)];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i0 = base + q * 4 + r;
-        ix.s0[r] = sl[min(i0, last)];
-        ix.s1[r] = sl[min(i0 + 16, last)];
-    }
+// Two coalesced 128-byte loads per item (lanes 0..31 = the item's 32 pairs; indices clamped into the range so the
+// load is unconditional); gmm_chunks distributes them to the MFMA fragment layout with shuffles.
+__device__ __forceinline__ void gmm_load_idx(GmmIdx& ix, const GmmParams& p, int k, int base, int e, int lane) {
+    const int pi = min(base + (lane & 31), e - 1);
+    ix.g = p.gather[(int64_t)k * p.cap + pi];
+    ix.s = p.scatter[(int64_t)k * p.cap + pi];
 }
 
 // one or two 16-pair chunks of offset k: gather -> MFMA over all source channels -> scatter-add into LDS
@@ -82,24 +72,22 @@ __device__ __forceinline__ void gmm_chunks(const GmmParams& p, GmmIdx ix, const 
                                            int64_t row0, float* acc, int i16, int q) {
     constexpr int JB = CS16 <= 8 ? CS16 : CS16 / 2;     // 16-channel groups held in registers at a time
     constexpr int NJB = CS16 / JB;
-    // keep the compiler from sinking the index loads into the validity selects below (it would then wait
-    // for each of them separately): the asm makes every loaded value live here.
-    asm volatile("" : "+v"(ix.g0), "+v"(ix.g1));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ix.s0[r]), "+v"(ix.s1[r]));
-    const int g0 = ix.g0, g1 = ix.g1;
+    // lanes past the end of the range hold a clamped (valid) index: their rows are computed but only ever
+    // added into the scratch row, so nothing here waits on a branch.
+    const int g0 = __shfl(ix.g, i16, 64), g1 = TWO ? __shfl(ix.g, 16 + i16, 64) : 0;
     int srow0[4], srow1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i0 = base + q * 4 + r, i1 = i0 + 16;
-        srow0[r] = i0 < e ? (int)(ix.s0[r] - row0) : TRASH;        // lanes past the end add into a scratch row
-        srow1[r] = (TWO && i1 < e) ? (int)(ix.s1[r] - row0) : TRASH;
+        const int v0 = __shfl(ix.s, q * 4 + r, 64);
+        const int v1 = TWO ? __shfl(ix.s, 16 + q * 4 + r, 64) : 0;
+        srow0[r] = i0 < e ? (int)(v0 - row0) : TRASH;        // lanes past the end add into a scratch row
+        srow1[r] = (TWO && i1 < e) ? (int)(v1 - row0) : TRASH;
     }
     f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const float* a0p = p.src + (int64_t)g0 * p.Cs + q * 4;
     const float* a1p = p.src + (int64_t)g1 * p.Cs + q * 4;
-    const int64_t nbs = (int64_t)16 * p.K * p.Cs;
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb) {
         float4 a0[JB], a1[JB];
@@ -110,8 +98,8 @@ __device__ __forceinline__ void gmm_chunks(const GmmParams& p, GmmIdx ix, const 
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            const float4 b0 = *reinterpret_cast<const float4*>(wk + (jb * JB + j) * 16);
-            const float4 b1 = *reinterpret_cast<const float4*>(wk + nbs + (jb * JB + j) * 16);
+            const float4 b0 = *reinterpret_cast<const float4*>(wk + ((jb * JB + j) * 2 + 0) * 256);    // 1 KB contiguous per wave
+            const float4 b1 = *reinterpret_cast<const float4*>(wk + ((jb * JB + j) * 2 + 1) * 256);
             // independent accumulator chains interleaved (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
 #define U3D_STEP(c)                                                                          \
     d0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].c, b0.c, d0[0], 0, 0, 0);             \
@@ -188,7 +176,7 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         if (base < e) break;
     }
     GmmIdx cur;
-    if (k < k_hi) gmm_load_idx(cur, p, k, base, e, i16, q);
+    if (k < k_hi) gmm_load_idx(cur, p, k, base, e, lane);
     while (k < k_hi) {
         // ---- locate the next item and start its index loads ----
         int nk = k, nbase = base + 32, ne = e;
@@ -199,9 +187,9 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
             }
         }
         GmmIdx nxt = cur;
-        if (nk < k_hi) gmm_load_idx(nxt, p, nk, nbase, ne, i16, q);
+        if (nk < k_hi) gmm_load_idx(nxt, p, nk, nbase, ne, lane);
         // ---- compute the current item ----
-        const float* wk = p.w + ((int64_t)(n0 + i16) * p.K + k) * p.Cs + q * 4;     // this lane's B row; +16 rows for the 2nd column block
+        const float* wk = p.w + ((int64_t)slice * p.K + k) * (CS16 * 512) + lane * 4;   // packed fragments of (slice, k)
         if (base + 16 < e) gmm_chunks<CS16, true, R>(p, cur, wk, base, e, row0, acc, i16, q);
         else gmm_chunks<CS16, false, R>(p, cur, wk, base, e, row0, acc, i16, q);
         cur = nxt; k = nk; base = nbase; e = ne;
@@ -405,6 +393,34 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     return check_launch("spconv_wgrad");
 }
 
+// wp[(((slice*K + k)*CS16 + j)*2 + nb)*256 + lane*4 + t] = W(n = slice*32 + nb*16 + (lane&15), k, c = j*16 + (lane>>4)*4 + t)
+// i.e. the B fragments of spconv_gmm_k in the order the kernel reads them (one contiguous 1 KB block per wave load).
+// transposed = 0: W(n,k,c) = w[(n*K + k)*Cs + c]  (forward, w = [Cd][K][Cs]);
+// transposed = 1: W(n,k,c) = w[(c*K + k)*Cd + n]  (input gradient: w = [Cs][K][Cd] is the forward weight).
+__global__ __launch_bounds__(256) void weight_pack_k(const float* __restrict__ w, float* __restrict__ wp, int Cd, int K, int Cs, int transposed) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 per thread
+    const int cs16 = Cs / 16;
+    const int64_t total = (int64_t)(Cd / 32) * K * cs16 * 2 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    int64_t t = idx >> 6;
+    const int nb = (int)(t & 1); t >>= 1;
+    const int j = (int)(t % cs16); t /= cs16;
+    const int k = (int)(t % K);
+    const int slice = (int)(t / K);
+    const int n = slice * 32 + nb * 16 + (lane & 15), c = j * 16 + (lane >> 4) * 4;
+    float4 v;
+    if (!transposed) {
+        v = *reinterpret_cast<const float4*>(w + ((int64_t)n * K + k) * Cs + c);
+    } else {
+        v.x = w[((int64_t)(c + 0) * K + k) * Cd + n];
+        v.y = w[((int64_t)(c + 1) * K + k) * Cd + n];
+        v.z = w[((int64_t)(c + 2) * K + k) * Cd + n];
+        v.w = w[((int64_t)(c + 3) * K + k) * Cd + n];
+    }
+    reinterpret_cast<float4*>(wp)[idx] = v;
+}
+
 __global__ void weight_transpose_k(const float* __restrict__ w, float* __restrict__ wt, int Cd, int K, int Cs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)Cd * K * Cs;
@@ -497,6 +513,13 @@ int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, con
 #undef U3D_WG_CASE
     set_error("spconv_wgrad: no instantiation for Cs=%d Cd=%d", Cs, Cd);
     return U3D_EUNSUPPORTED;
+}
+
+int u3d_weight_pack(const float* w, float* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {
+    if (!w || !wp || Cd <= 0 || K <= 0 || Cs <= 0 || Cd % 32 || Cs % 16) return U3D_EINVAL;
+    const int64_t total4 = (int64_t)Cd * K * Cs / 4;
+    hipLaunchKernelGGL(weight_pack_k, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cd, K, Cs, transposed);
+    return check_launch("weight_pack");
 }
 
 int u3d_weight_transpose(const float* w, float* wt, int Cd, int K, int Cs, u3d_stream_t stream) {

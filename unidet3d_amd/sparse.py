@@ -147,8 +147,9 @@ def _plan(Cs, Cd, K, n_dst):
     return R.value, G.value
 
 
-def _gmm(src, w_rows, rb, gather, scatter, role, n_dst, addend, flops):
-    Cs, Cd = src.shape[1], w_rows.shape[0]
+def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops):
+    """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in)."""
+    Cs, Cd = src.shape[1], (weight.shape[2] if transposed else weight.shape[0])
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     if n_dst:
         R, G = _plan(Cs, Cd, rb.K, n_dst)
@@ -157,7 +158,9 @@ def _gmm(src, w_rows, rb, gather, scatter, role, n_dst, addend, flops):
             ACCOUNT['gmm_flops'] += flops
             ACCOUNT['gmm_bytes'] += 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
-        L.call('u3d_spconv_gmm', L.ptr(src), L.ptr(w_rows), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
+        wp = torch.empty(weight.numel(), dtype=torch.float32, device=src.device)       # MFMA-fragment order
+        L.call('u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
+        L.call('u3d_spconv_gmm', L.ptr(src), L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
                rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
     return dst
 
@@ -185,7 +188,7 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
-        dst = _gmm(src, w, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops)
+        dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops)
         ctx.save_for_backward(src, weight)
         ctx.rb, ctx.mode, ctx.has_addend = rb, mode, addend is not None
         return dst
@@ -199,13 +202,11 @@ class _SparseConvFn(torch.autograd.Function):
         dsrc = dw = None
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
         if ctx.needs_input_grad[0]:
-            wt = torch.empty(cin, rb.K, cout, dtype=torch.float32, device=weight.device)
-            L.call('u3d_weight_transpose', L.ptr(weight), L.ptr(wt), cout, rb.K, cin, L.stream())
             if mode == 'fwd':
                 g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
             else:
                 g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
-            dsrc = _gmm(dout, wt, rb, g, s, role, n_dst, None, flops)
+            dsrc = _gmm(dout, weight.reshape(cout, rb.K, cin).contiguous(), True, rb, g, s, role, n_dst, None, flops)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             if mode == 'fwd':

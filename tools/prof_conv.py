@@ -36,12 +36,20 @@ else:
     def f():
         y = sparse.sparse_conv(xg, wg, rb)
         y.backward(go)
+from unidet3d_amd import _lib as L  # noqa: E402
 for _ in range(2):
     f()
 torch.cuda.synchronize()
+for c in (0, 1):
+    L.prof_enable(c, True)
 t0 = time.perf_counter()
 for _ in range(iters):
     f()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters
+for c, nm in ((0, 'spconv_gmm (+reduce)'), (1, 'spconv_wgrad (+reduce)')):     # HIP-event time of the kernels alone
+    ms, cnt, _w = L.prof_collect(c)
+    L.prof_enable(c, False)
+    if cnt:
+        print(f'  {nm}: {ms / cnt * 1e3:.1f} us/launch over {cnt} launches -> {2.0 * pairs * C * C / (ms / cnt * 1e-3) / 1e12:.2f} TFLOP/s')
 print(f'{mode}: {dt * 1e6:.1f} us/iter  -> {2.0 * pairs * C * C / dt / 1e12:.2f} TFLOP/s (fwd flops only)', flush=True)

@@ -12,6 +12,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-ato
          '-I', os.path.join(ROOT, 'include'), '-I', HERE]
 
 
+# per-file code generation options
+EXTRA = {'spconv.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}     # MFMA results are consumed by VALU/LDS right away
+
+
 def _hipcc():
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -34,7 +38,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(HERE, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(src, obj):
-            jobs.append([hipcc, *FLAGS, '-c', src, '-o', obj])
+            jobs.append([hipcc, *FLAGS, *EXTRA.get(s, []), '-c', src, '-o', obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):

@@ -44,6 +44,7 @@ struct GmmParams {
     int n_slices;
     int G;
     int kper;
+    unsigned long long* trace;   // experiment (env U3D_GMM_TRACE): per-phase cycle sums over all waves, else nullptr
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
@@ -53,90 +54,218 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 constexpr int GMM_CDS = 32;            // output columns per wave
 constexpr int GMM_ALD = GMM_CDS + 4;   // padded accumulator row
 
-// raw rulebook indices of one work item (two 16-pair chunks of one offset), loaded one item ahead
-struct GmmIdx {
-    int g, s;      // lane l < 32 holds gather / scatter row of pair (base + l) of the work item
+// ---- software-pipelined wave program ---------------------------------------------------------------------
+// A wave's work is a sequence of ITEMS (offset k, window of W = 16*NCH pairs of k's range in this row tile);
+// an item is computed in NJB UNITS of JB 16-channel groups of the source channels.  Per unit the wave holds
+// the A fragments (gathered rows) and B fragments (packed weights) in registers; the loads of unit u+1 are
+// issued BEFORE the MFMAs of unit u, and the raw gather/scatter indices are loaded two items ahead, so a
+// single wave keeps its MFMAs fed without relying on other resident waves to hide the gather latency
+// (PMC before this: 2.4 waves/SIMD resident on average, MFMA pipe busy 38 %, 49 % of wave cycles in
+// s_waitcnt vmcnt).  Two register buffers alternate; the unit sequence is unrolled so buffer roles are static.
+template <int NCH, int JB>
+struct GmmBuf {
+    float4 a[NCH][JB];
+    float4 b[JB][2];
 };
 
-// Two coalesced 128-byte loads per item (lanes 0..31 = the item's 32 pairs; indices clamped into the range so the
-// load is unconditional); gmm_chunks distributes them to the MFMA fragment layout with shuffles.
-__device__ __forceinline__ void gmm_load_idx(GmmIdx& ix, const GmmParams& p, int k, int base, int e, int lane) {
-    const int pi = min(base + (lane & 31), e - 1);
-    ix.g = p.gather[(int64_t)k * p.cap + pi];
-    ix.s = p.scatter[(int64_t)k * p.cap + pi];
-}
+struct GmmItem {
+    int k, base, e;      // wave-uniform; when !valid the fields still name a real item (addresses stay legal)
+    bool valid;
+};
 
-// one or two 16-pair chunks of offset k: gather -> MFMA over all source channels -> scatter-add into LDS
-template <int CS16, bool TWO, int TRASH>
-__device__ __forceinline__ void gmm_chunks(const GmmParams& p, GmmIdx ix, const float* __restrict__ wk, int base, int e,
-                                           int64_t row0, float* acc, int i16, int q) {
-    constexpr int JB = CS16 <= 8 ? CS16 : CS16 / 2;     // 16-channel groups held in registers at a time
-    constexpr int NJB = CS16 / JB;
-    // lanes past the end of the range hold a clamped (valid) index: their rows are computed but only ever
-    // added into the scratch row, so nothing here waits on a branch.
-    const int g0 = __shfl(ix.g, i16, 64), g1 = TWO ? __shfl(ix.g, 16 + i16, 64) : 0;
-    int srow0[4], srow1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i0 = base + q * 4 + r, i1 = i0 + 16;
-        const int v0 = __shfl(ix.s, q * 4 + r, 64);
-        const int v1 = TWO ? __shfl(ix.s, 16 + q * 4 + r, 64) : 0;
-        srow0[r] = i0 < e ? (int)(v0 - row0) : TRASH;        // lanes past the end add into a scratch row
-        srow1[r] = (TWO && i1 < e) ? (int)(v1 - row0) : TRASH;
+template <int CS16, int R, int NJB_, bool TR>
+struct GmmWave {
+    static constexpr int NCH = R / 32;            // 16-pair chunks per item
+    static constexpr int NJB = NJB_;
+    static constexpr int JB = CS16 / NJB;
+    static constexpr int W = 16 * NCH;
+    static constexpr int TRASH = R;               // scratch accumulator row for lanes past the end of a range
+    using Buf = GmmBuf<NCH, JB>;
+
+    const GmmParams& p;
+    float* acc;
+    int lane, i16, q, slice, k_hi;
+    int64_t row0;
+    int ts_s, ts_e;                               // lane k: pair range of offset k in this row tile
+
+    GmmItem it0, it1;                             // item being computed / item whose first unit is fetched next
+    int s_cur;                                    // it0: scatter row of pair (base + lane), lanes < W
+    int g_cur[NCH];                               // it0: gather rows in fragment layout (for its later units)
+    int ix1_g, ix1_s;                             // it1: raw indices, lanes < W
+    f32x4 d[NCH][2];
+    unsigned long long tr[4];                     // TR only: cycles in {search + load issue, MFMA, scatter}, items
+
+    __device__ __forceinline__ GmmWave(const GmmParams& p_) : p(p_) {}
+
+    __device__ __forceinline__ bool range_of(int k, int& s_, int& e_) const {
+        s_ = __builtin_amdgcn_readlane(ts_s, k);
+        e_ = __builtin_amdgcn_readlane(ts_e, k);
+        return s_ < e_;
     }
-    f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const float* a0p = p.src + (int64_t)g0 * p.Cs + q * 4;
-    const float* a1p = p.src + (int64_t)g1 * p.Cs + q * 4;
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb) {
-        float4 a0[JB], a1[JB];
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            a0[j] = *reinterpret_cast<const float4*>(a0p + (jb * JB + j) * 16);
-            if (TWO) a1[j] = *reinterpret_cast<const float4*>(a1p + (jb * JB + j) * 16);
+    __device__ __forceinline__ GmmItem first_item(int k_lo) const {
+        GmmItem n{k_lo, 0, 0, false};
+        for (int k = k_lo; k < k_hi; ++k)
+            if (range_of(k, n.base, n.e)) { n.k = k; n.valid = true; break; }
+        return n;
+    }
+    __device__ __forceinline__ GmmItem next_of(const GmmItem& it) const {
+        GmmItem n = it;
+        if (!it.valid) return n;
+        n.base = it.base + W;
+        if (n.base < n.e) return n;
+        for (int k = it.k + 1; k < k_hi; ++k) {
+            int s_, e_;
+            if (range_of(k, s_, e_)) { n.k = k; n.base = s_; n.e = e_; return n; }
         }
+        n = it;
+        n.valid = false;
+        return n;
+    }
+    // two coalesced loads per item (lanes < W = the item's pairs, clamped into the range -> unconditional)
+    __device__ __forceinline__ void load_idx(const GmmItem& it, int& g, int& s_) const {
+        const int pi = min(it.base + (lane & (W - 1)), it.e - 1);
+        g = p.gather[(int64_t)it.k * p.cap + pi];
+        s_ = p.scatter[(int64_t)it.k * p.cap + pi];
+    }
+    __device__ __forceinline__ void frag_rows(int raw_g, int (&g)[NCH]) const {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) g[c] = __shfl(raw_g, c * 16 + i16, 64);
+    }
+    __device__ __forceinline__ void issue(Buf& buf, const int (&g)[NCH], int k, int u) const {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float* ap = p.src + (int64_t)g[c] * p.Cs + q * 4 + u * JB * 16;
+#pragma unroll
+            for (int j = 0; j < JB; ++j) buf.a[c][j] = *reinterpret_cast<const float4*>(ap + j * 16);
+        }
+        const float* wk = p.w + ((int64_t)slice * p.K + k) * (CS16 * 512) + u * JB * 512 + lane * 4;   // 1 KB per wave load
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            const float4 b0 = *reinterpret_cast<const float4*>(wk + ((jb * JB + j) * 2 + 0) * 256);    // 1 KB contiguous per wave
-            const float4 b1 = *reinterpret_cast<const float4*>(wk + ((jb * JB + j) * 2 + 1) * 256);
-            // independent accumulator chains interleaved (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
-#define U3D_STEP(c)                                                                          \
-    d0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].c, b0.c, d0[0], 0, 0, 0);             \
-    d0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].c, b1.c, d0[1], 0, 0, 0);             \
-    if (TWO) {                                                                               \
-        d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].c, b0.c, d1[0], 0, 0, 0);         \
-        d1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].c, b1.c, d1[1], 0, 0, 0);         \
+            buf.b[j][0] = *reinterpret_cast<const float4*>(wk + (j * 2 + 0) * 256);
+            buf.b[j][1] = *reinterpret_cast<const float4*>(wk + (j * 2 + 1) * 256);
+        }
+    }
+    // independent accumulator chains interleaved (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
+    template <bool TWO>
+    __device__ __forceinline__ void mfma(const Buf& buf) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+#define U3D_STEP(c)                                                                                      \
+    d[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[0][j].c, buf.b[j][0].c, d[0][0], 0, 0, 0);        \
+    d[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[0][j].c, buf.b[j][1].c, d[0][1], 0, 0, 0);        \
+    if constexpr (TWO) {                                                                                 \
+        d[NCH - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[NCH - 1][j].c, buf.b[j][0].c, d[NCH - 1][0], 0, 0, 0); \
+        d[NCH - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[NCH - 1][j].c, buf.b[j][1].c, d[NCH - 1][1], 0, 0, 0); \
     }
             U3D_STEP(x) U3D_STEP(y) U3D_STEP(z) U3D_STEP(w)
 #undef U3D_STEP
         }
     }
-    // scatter: the accumulator tile is private to this wave and, inside one offset, every destination row
-    // occurs at most once -> a plain LDS read-modify-write is exact (ds_add_f32 atomics measured ~10x slower:
-    // SQ_WAIT_INST_LDS was 83 % of all wave cycles with them).
-    float o0[2][4], o1[2][4];
+    // the accumulator tile is private to this wave and, inside one offset, every destination row occurs at most
+    // once -> a plain LDS read-modify-write is exact (ds_add_f32 atomics measured ~10x slower: SQ_WAIT_INST_LDS
+    // was 83 % of all wave cycles with them).
+    template <bool TWO>
+    __device__ __forceinline__ void scatter() {
+        constexpr int NC = TWO ? NCH : 1;
+        // lane l < W owns pair (base + l): it resolves that pair's accumulator row ONCE (scratch row for lanes past
+        // the end) and the fragment layout fetches the finished word offsets with one shuffle each.
+        const int mine = (it0.base + (lane & (W - 1)) < it0.e) ? (int)(s_cur - row0) : TRASH;
+        const int mine_off = mine * GMM_ALD;
+        const float* accl = acc + i16;
+        float o[NC][2][4];
+        int off[NC][4];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o0[nb][r] = acc[srow0[r] * GMM_ALD + nb * 16 + i16];
-            if (TWO) o1[nb][r] = acc[srow1[r] * GMM_ALD + nb * 16 + i16];
+            for (int r = 0; r < 4; ++r) off[c][r] = __shfl(mine_off, c * 16 + q * 4 + r, 64);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[c][nb][r] = accl[off[c][r] + nb * 16];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) const_cast<float*>(accl)[off[c][r] + nb * 16] = o[c][nb][r] + d[c][nb][r];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) d[c][0] = d[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    template <int U>
+    __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
+        const bool two = NCH == 2 && it0.base + 16 < it0.e;      // wave-uniform
+        if constexpr (U == NJB - 1) {
+            const unsigned long long t0 = TR ? __builtin_readcyclecounter() : 0;
+            int gn[NCH];
+            frag_rows(ix1_g, gn);
+            const GmmItem it2 = next_of(it1);
+            int g2, s2;
+            load_idx(it2, g2, s2);
+            issue(nxt, gn, it1.k, 0);
+            const unsigned long long t1 = TR ? __builtin_readcyclecounter() : 0;
+            if (two) mfma<NCH == 2>(cur);
+            else mfma<false>(cur);
+            const unsigned long long t2 = TR ? __builtin_readcyclecounter() : 0;
+            if (two) scatter<NCH == 2>();
+            else scatter<false>();
+            if (TR) {
+                const unsigned long long t3 = __builtin_readcyclecounter();
+                tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += 1;
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) g_cur[c] = gn[c];
+            s_cur = ix1_s; ix1_g = g2; ix1_s = s2;
+            it0 = it1; it1 = it2;
+        } else {
+            issue(nxt, g_cur, it0.k, U + 1);
+            if (two) mfma<NCH == 2>(cur);
+            else mfma<false>(cur);
         }
+    }
+
+    __device__ __forceinline__ void item(Buf& first, Buf& second) {
+        unit<0>(first, second);
+        if constexpr (NJB >= 2) unit<1>(second, first);
+        if constexpr (NJB >= 4) { unit<2>(first, second); unit<3>(second, first); }
+    }
+
+    __device__ __forceinline__ void run(int k_lo) {
+        it0 = first_item(k_lo);
+        if (!it0.valid) return;
+        int g0;
+        load_idx(it0, g0, s_cur);
+        it1 = next_of(it0);
+        load_idx(it1, ix1_g, ix1_s);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[srow0[r] * GMM_ALD + nb * 16 + i16] = o0[nb][r] + d0[nb][r];
-            if (TWO) acc[srow1[r] * GMM_ALD + nb * 16 + i16] = o1[nb][r] + d1[nb][r];
+        for (int c = 0; c < NCH; ++c) d[c][0] = d[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Buf X, Y;
+        frag_rows(g0, g_cur);
+        issue(X, g_cur, it0.k, 0);
+        while (true) {
+            item(X, Y);
+            if (!it0.valid) break;
+            if constexpr (NJB == 1) {
+                item(Y, X);
+                if (!it0.valid) break;
+            }
         }
+    }
+};
+
+// units per item: keep a unit's fragments at <= 4 (R = 32) / 2-3 (R = 64) 16-channel groups so that two buffers fit in
+// ~100 VGPRs (4 waves per SIMD)
+constexpr int gmm_njb(int cs16, int r) {
+    return r == 64 ? (cs16 <= 2 ? 1 : ((cs16 <= 6 || cs16 % 4) ? 2 : 4)) : (cs16 <= 4 ? 1 : (cs16 <= 10 ? 2 : 4));
 }
 
-template <int CS16, int R>
+template <int CS16, int R, bool TR = false>
 __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i16 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
     float* acc = smem + wave * ((R + 1) * GMM_ALD);      // R rows + one scratch row
 
     const int64_t wid = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wave;     // neighbouring row tiles share an XCD / L2
@@ -158,42 +287,24 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         *reinterpret_cast<float4*>(acc + r * GMM_ALD + c4 * 4) = v;
     }
 
-    const int k_lo = g * p.kper, k_hi = min(p.K, k_lo + p.kper);
+    GmmWave<CS16, R, gmm_njb(CS16, R), TR> w(p);
+    const unsigned long long tw0 = TR ? __builtin_readcyclecounter() : 0;
+    if (TR) w.tr[0] = w.tr[1] = w.tr[2] = w.tr[3] = 0;
+    w.acc = acc; w.lane = lane; w.i16 = lane & 15; w.q = lane >> 4; w.slice = slice; w.row0 = row0;
+    const int k_lo = g * p.kper;
+    w.k_hi = min(p.K, k_lo + p.kper);
     // all (start, end) ranges of this wave's offsets in one round trip: lane k holds offset k's range
-    int ts_s = 0, ts_e = 0;
+    w.ts_s = 0; w.ts_e = 0;
     if (lane < p.K) {
-        ts_s = p.ts[lane * tsld + sub];
-        ts_e = p.ts[lane * tsld + sub + 1];
+        w.ts_s = p.ts[lane * tsld + sub];
+        w.ts_e = p.ts[lane * tsld + sub + 1];
     }
-    // work items = (offset k, 32-pair window); the raw indices of item i+1 are loaded while item i computes
-    auto range_of = [&](int k, int& s_, int& e_) {
-        s_ = __builtin_amdgcn_readfirstlane(__shfl(ts_s, k, 64));      // wave-uniform -> scalar control flow
-        e_ = __builtin_amdgcn_readfirstlane(__shfl(ts_e, k, 64));
-    };
-    int k = k_lo, base = 0, e = 0;
-    for (; k < k_hi; ++k) {                     // first non-empty offset
-        range_of(k, base, e);
-        if (base < e) break;
+    w.run(k_lo);
+    if (TR && lane == 0) {
+        atomicAdd(p.trace + 0, w.tr[0]); atomicAdd(p.trace + 1, w.tr[1]); atomicAdd(p.trace + 2, w.tr[2]); atomicAdd(p.trace + 3, w.tr[3]);
+        atomicAdd(p.trace + 4, (unsigned long long)(__builtin_readcyclecounter() - tw0)); atomicAdd(p.trace + 5, 1ull);
     }
-    GmmIdx cur;
-    if (k < k_hi) gmm_load_idx(cur, p, k, base, e, lane);
-    while (k < k_hi) {
-        // ---- locate the next item and start its index loads ----
-        int nk = k, nbase = base + 32, ne = e;
-        if (nbase >= e) {
-            for (nk = k + 1; nk < k_hi; ++nk) {
-                range_of(nk, nbase, ne);
-                if (nbase < ne) break;
-            }
-        }
-        GmmIdx nxt = cur;
-        if (nk < k_hi) gmm_load_idx(nxt, p, nk, nbase, ne, lane);
-        // ---- compute the current item ----
-        const float* wk = p.w + ((int64_t)slice * p.K + k) * (CS16 * 512) + lane * 4;   // packed fragments of (slice, k)
-        if (base + 16 < e) gmm_chunks<CS16, true, R>(p, cur, wk, base, e, row0, acc, i16, q);
-        else gmm_chunks<CS16, false, R>(p, cur, wk, base, e, row0, acc, i16, q);
-        cur = nxt; k = nk; base = nbase; e = ne;
-    }
+
     float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
     for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
         const int r = idx >> 3, c4 = idx & 7;
@@ -231,6 +342,21 @@ template <int CS16, int R>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
     const size_t lds = (size_t)4 * (R + 1) * GMM_ALD * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
+    if constexpr (R == 64 && (CS16 == 2 || CS16 == 4)) {
+        if (getenv("U3D_GMM_TRACE")) {          // experiment: per-phase cycle breakdown of the wave program (synchronous)
+            GmmParams q = p;
+            unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+            if (hipMalloc(&q.trace, sizeof(h)) != hipSuccess) return U3D_ELAUNCH;
+            hipMemcpy(q.trace, h, sizeof(h), hipMemcpyHostToDevice);
+            hipLaunchKernelGGL((spconv_gmm_k<CS16, R, true>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, q);
+            hipStreamSynchronize(s);
+            hipMemcpy(h, q.trace, sizeof(h), hipMemcpyDeviceToHost);
+            hipFree(q.trace);
+            fprintf(stderr, "[gmm trace CS16=%d] waves %llu items %llu | per item: issue %.0f mfma %.0f scatter %.0f clk | per wave %.0f clk\n", CS16, h[5],
+                    h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[5]);
+            return check_launch("spconv_gmm");
+        }
+    }
     hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");
 }
@@ -463,6 +589,7 @@ int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather,
     p.out = G > 1 ? (float*)ws : dst;
     p.K = K; p.cap = cap; p.Cs = Cs; p.Cd = Cd; p.n_dst = n_dst; p.n_sub = ceil_div(n_dst, R);
     p.n_slices = Cd / GMM_CDS; p.G = G; p.kper = (int)ceil_div(K, G);
+    p.trace = nullptr;
     const int cs16 = Cs / 16;
     int rc = U3D_EUNSUPPORTED;
 #define U3D_GMM_CASE(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64>(p, s) : launch_gmm<cs, 32>(p, s);

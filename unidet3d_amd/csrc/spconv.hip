@@ -57,15 +57,23 @@ constexpr int GMM_ALD = GMM_CDS + 4;   // padded accumulator row
 // ---- software-pipelined wave program ---------------------------------------------------------------------
 // A wave's work is a sequence of ITEMS (offset k, window of W = 16*NCH pairs of k's range in this row tile);
 // an item is computed in NJB UNITS of JB 16-channel groups of the source channels.  Per unit the wave holds
-// the A fragments (gathered rows) and B fragments (packed weights) in registers; the loads of unit u+1 are
-// issued BEFORE the MFMAs of unit u, and the raw gather/scatter indices are loaded two items ahead, so a
-// single wave keeps its MFMAs fed without relying on other resident waves to hide the gather latency
-// (PMC before this: 2.4 waves/SIMD resident on average, MFMA pipe busy 38 %, 49 % of wave cycles in
-// s_waitcnt vmcnt).  Two register buffers alternate; the unit sequence is unrolled so buffer roles are static.
-template <int NCH, int JB>
+// the gathered rows and the B fragments (packed weights) in registers; the loads of unit u+1 are issued
+// BEFORE the MFMAs of unit u, and the raw gather/scatter indices are loaded two items ahead, so a single wave
+// keeps its MFMAs fed without relying on other resident waves to hide the gather latency.
+// Two register buffers alternate; the unit sequence is unrolled so buffer roles are static.
+//
+// The gather is shaped for the texture-addresser, not for the MFMA: the vector L1 spends ~4 cycles (L1 hit) to
+// ~7 cycles (L2 hit) per distinct 128-byte line a wave instruction touches (tools/l1_bw.hip: fragment-shaped loads,
+// 16 rows x 64 B per instruction, reach 15 B/clk/CU from L1 and 9 from L2; whole-line loads 31-39), and that
+// rate -- not MFMA, HBM or L2 bandwidth -- bounded the kernel while every lane fetched its own MFMA fragment
+// (per-item trace: 8.8k cycles stalled in load issue vs 1.05k in MFMA).  So a load instruction now reads
+// 64/PPR complete rows (PPR = JB*4 lanes x 16 B per row = whole lines), the wave transposes the unit through a
+// private, XOR-swizzled LDS image (ds_write_b128 -> ds_read_b128, both conflict-free, no barrier: LDS
+// operations of one wave execute in order) and picks up its A fragments from there.
+template <int NI, int JB>
 struct GmmBuf {
-    float4 a[NCH][JB];
-    float4 b[JB][2];
+    f32x4 a[NI];         // instruction i: rows i*RPI + lane/PPR of the item, 16-byte piece lane%PPR of the unit
+    f32x4 b[JB][2];
 };
 
 struct GmmItem {
@@ -73,30 +81,44 @@ struct GmmItem {
     bool valid;
 };
 
-template <int CS16, int R, int NJB_, bool TR>
+template <int CS16, int R, int JB_, bool TR>
 struct GmmWave {
     static constexpr int NCH = R / 32;            // 16-pair chunks per item
-    static constexpr int NJB = NJB_;
-    static constexpr int JB = CS16 / NJB;
+    static constexpr int JB = JB_;                // 16-channel groups per unit (1, 2 or 4)
+    static constexpr int NJB = CS16 / JB;
     static constexpr int W = 16 * NCH;
+    static constexpr int PPR = JB * 4;            // 16-byte pieces (lanes) per row of a unit
+    static constexpr int RPI = 64 / PPR;          // rows per load instruction
+    static constexpr int NI = W / RPI;            // load instructions per unit (= NCH*JB)
     static constexpr int TRASH = R;               // scratch accumulator row for lanes past the end of a range
-    using Buf = GmmBuf<NCH, JB>;
+    static_assert(CS16 % JB == 0 && (JB == 1 || JB == 2 || JB == 4), "unit shape");
+    using Buf = GmmBuf<NI, JB>;
 
     const GmmParams& p;
     float* acc;
+    float* stage;                                 // W rows x PPR pieces, piece slot p ^ swz(row)
     int lane, i16, q, slice, k_hi;
     int64_t row0;
     int ts_s, ts_e;                               // lane k: pair range of offset k in this row tile
+    int wr_off, rd_off[JB];                       // float offsets into `stage` of this lane's write / fragment reads
 
     GmmItem it0, it1;                             // item being computed / item whose first unit is fetched next
-    int s_cur;                                    // it0: scatter row of pair (base + lane), lanes < W
-    int g_cur[NCH];                               // it0: gather rows in fragment layout (for its later units)
+    int s_cur, g_cur;                             // it0: scatter / gather row of pair (base + lane), lanes < W
     int ix1_g, ix1_s;                             // it1: raw indices, lanes < W
     f32x4 d[NCH][2];
     unsigned long long tr[4];                     // TR only: cycles in {search + load issue, MFMA, scatter}, items
 
     __device__ __forceinline__ GmmWave(const GmmParams& p_) : p(p_) {}
 
+    // conflict-free for the ds_read_b128 lane groups of gfx950 (brute-forced against the bank model)
+    static __device__ __forceinline__ int swz(int row) { return PPR == 4 ? ((row >> 1) & 3) : (row & (PPR - 1)); }
+
+    __device__ __forceinline__ void init_offsets() {
+        const int lr = lane / PPR, lp = lane % PPR;
+        wr_off = (lr * PPR + (lp ^ swz(lr))) * 4;             // swz(i*RPI + lr) == swz(lr) for PPR = 4, 8
+#pragma unroll
+        for (int j = 0; j < JB; ++j) rd_off[j] = (i16 * PPR + ((j * 4 + q) ^ swz(i16))) * 4;     // + c*16*PPR*4
+    }
     __device__ __forceinline__ bool range_of(int k, int& s_, int& e_) const {
         s_ = __builtin_amdgcn_readlane(ts_s, k);
         e_ = __builtin_amdgcn_readlane(ts_e, k);
@@ -127,37 +149,49 @@ struct GmmWave {
         g = p.gather[(int64_t)it.k * p.cap + pi];
         s_ = p.scatter[(int64_t)it.k * p.cap + pi];
     }
-    __device__ __forceinline__ void frag_rows(int raw_g, int (&g)[NCH]) const {
+    __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u) const {
+        const int lr = lane / PPR, lp = lane % PPR;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) g[c] = __shfl(raw_g, c * 16 + i16, 64);
-    }
-    __device__ __forceinline__ void issue(Buf& buf, const int (&g)[NCH], int k, int u) const {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const float* ap = p.src + (int64_t)g[c] * p.Cs + q * 4 + u * JB * 16;
-#pragma unroll
-            for (int j = 0; j < JB; ++j) buf.a[c][j] = *reinterpret_cast<const float4*>(ap + j * 16);
+        for (int i = 0; i < NI; ++i) {
+            const int g = __shfl(raw_g, i * RPI + lr, 64);
+            buf.a[i] = *reinterpret_cast<const f32x4*>(p.src + (int64_t)g * p.Cs + (u * JB * 4 + lp) * 4);
         }
         const float* wk = p.w + ((int64_t)slice * p.K + k) * (CS16 * 512) + u * JB * 512 + lane * 4;   // 1 KB per wave load
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            buf.b[j][0] = *reinterpret_cast<const float4*>(wk + (j * 2 + 0) * 256);
-            buf.b[j][1] = *reinterpret_cast<const float4*>(wk + (j * 2 + 1) * 256);
+            buf.b[j][0] = *reinterpret_cast<const f32x4*>(wk + (j * 2 + 0) * 256);
+            buf.b[j][1] = *reinterpret_cast<const f32x4*>(wk + (j * 2 + 1) * 256);
         }
     }
-    // independent accumulator chains interleaved (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
+    // rows -> LDS image -> A fragments; then the MFMAs: independent accumulator chains interleaved
+    // (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
     template <bool TWO>
     __device__ __forceinline__ void mfma(const Buf& buf) {
 #pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int off = wr_off + i * (RPI * PPR * 4);
+            if constexpr (PPR == 16) {       // swz(row) depends on i here: recompute the slot
+                const int lr = lane / PPR, lp = lane % PPR, row = i * RPI + lr;
+                off = (row * PPR + (lp ^ swz(row))) * 4;
+            }
+            *reinterpret_cast<f32x4*>(stage + off) = buf.a[i];
+        }
+        constexpr int NC = TWO ? NCH : 1;
+        f32x4 fa[NC][JB];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < JB; ++j) fa[c][j] = *reinterpret_cast<const f32x4*>(stage + rd_off[j] + c * (16 * PPR * 4));
+#pragma unroll
         for (int j = 0; j < JB; ++j) {
 #define U3D_STEP(c)                                                                                      \
-    d[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[0][j].c, buf.b[j][0].c, d[0][0], 0, 0, 0);        \
-    d[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[0][j].c, buf.b[j][1].c, d[0][1], 0, 0, 0);        \
+    d[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][j][c], buf.b[j][0][c], d[0][0], 0, 0, 0);         \
+    d[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][j][c], buf.b[j][1][c], d[0][1], 0, 0, 0);         \
     if constexpr (TWO) {                                                                                 \
-        d[NCH - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[NCH - 1][j].c, buf.b[j][0].c, d[NCH - 1][0], 0, 0, 0); \
-        d[NCH - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf.a[NCH - 1][j].c, buf.b[j][1].c, d[NCH - 1][1], 0, 0, 0); \
+        d[NCH - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[NC - 1][j][c], buf.b[j][0][c], d[NCH - 1][0], 0, 0, 0); \
+        d[NCH - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[NC - 1][j][c], buf.b[j][1][c], d[NCH - 1][1], 0, 0, 0); \
     }
-            U3D_STEP(x) U3D_STEP(y) U3D_STEP(z) U3D_STEP(w)
+            U3D_STEP(0) U3D_STEP(1) U3D_STEP(2) U3D_STEP(3)
 #undef U3D_STEP
         }
     }
@@ -171,7 +205,7 @@ struct GmmWave {
         // the end) and the fragment layout fetches the finished word offsets with one shuffle each.
         const int mine = (it0.base + (lane & (W - 1)) < it0.e) ? (int)(s_cur - row0) : TRASH;
         const int mine_off = mine * GMM_ALD;
-        const float* accl = acc + i16;
+        float* accl = acc + i16;
         float o[NC][2][4];
         int off[NC][4];
 #pragma unroll
@@ -189,7 +223,7 @@ struct GmmWave {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) const_cast<float*>(accl)[off[c][r] + nb * 16] = o[c][nb][r] + d[c][nb][r];
+                for (int r = 0; r < 4; ++r) accl[off[c][r] + nb * 16] = o[c][nb][r] + d[c][nb][r];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) d[c][0] = d[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -199,12 +233,10 @@ struct GmmWave {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;      // wave-uniform
         if constexpr (U == NJB - 1) {
             const unsigned long long t0 = TR ? __builtin_readcyclecounter() : 0;
-            int gn[NCH];
-            frag_rows(ix1_g, gn);
             const GmmItem it2 = next_of(it1);
             int g2, s2;
             load_idx(it2, g2, s2);
-            issue(nxt, gn, it1.k, 0);
+            issue(nxt, ix1_g, it1.k, 0);
             const unsigned long long t1 = TR ? __builtin_readcyclecounter() : 0;
             if (two) mfma<NCH == 2>(cur);
             else mfma<false>(cur);
@@ -215,9 +247,7 @@ struct GmmWave {
                 const unsigned long long t3 = __builtin_readcyclecounter();
                 tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += 1;
             }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) g_cur[c] = gn[c];
-            s_cur = ix1_s; ix1_g = g2; ix1_s = s2;
+            g_cur = ix1_g; s_cur = ix1_s; ix1_g = g2; ix1_s = s2;
             it0 = it1; it1 = it2;
         } else {
             issue(nxt, g_cur, it0.k, U + 1);
@@ -226,47 +256,47 @@ struct GmmWave {
         }
     }
 
-    __device__ __forceinline__ void item(Buf& first, Buf& second) {
-        unit<0>(first, second);
-        if constexpr (NJB >= 2) unit<1>(second, first);
-        if constexpr (NJB >= 4) { unit<2>(first, second); unit<3>(second, first); }
+    // units U .. NJB-1 of the current item, buffers alternating
+    template <int U>
+    __device__ __forceinline__ void units(Buf& a, Buf& b) {
+        unit<U>(a, b);
+        if constexpr (U + 1 < NJB) units<U + 1>(b, a);
     }
 
     __device__ __forceinline__ void run(int k_lo) {
         it0 = first_item(k_lo);
         if (!it0.valid) return;
-        int g0;
-        load_idx(it0, g0, s_cur);
+        load_idx(it0, g_cur, s_cur);
         it1 = next_of(it0);
         load_idx(it1, ix1_g, ix1_s);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) d[c][0] = d[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        init_offsets();
         Buf X, Y;
-        frag_rows(g0, g_cur);
         issue(X, g_cur, it0.k, 0);
         while (true) {
-            item(X, Y);
+            units<0>(X, Y);
             if (!it0.valid) break;
-            if constexpr (NJB == 1) {
-                item(Y, X);
+            if constexpr (NJB % 2 == 1) {          // an odd unit count leaves the next item's first unit in Y
+                units<0>(Y, X);
                 if (!it0.valid) break;
             }
         }
     }
 };
 
-// units per item: keep a unit's fragments at <= 4 (R = 32) / 2-3 (R = 64) 16-channel groups so that two buffers fit in
-// ~100 VGPRs (4 waves per SIMD)
-constexpr int gmm_njb(int cs16, int r) {
-    return r == 64 ? (cs16 <= 2 ? 1 : ((cs16 <= 6 || cs16 % 4) ? 2 : 4)) : (cs16 <= 4 ? 1 : (cs16 <= 10 ? 2 : 4));
-}
+// 16-channel groups per unit: 128-byte row pieces (JB = 2) for 64-row tiles, 256-byte pieces for 32-row tiles when
+// the channel count allows, so that the staging image stays at 4 KB per wave
+constexpr int gmm_jb(int cs16, int r) { return (cs16 % 4 == 0 && r == 32) ? 4 : (cs16 % 2 == 0 ? 2 : 1); }
+constexpr int gmm_stage_floats(int cs16, int r) { return (r / 2) * gmm_jb(cs16, r) * 16; }      // W rows x JB*16 floats
 
 template <int CS16, int R, bool TR = false>
 __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
-    float* acc = smem + wave * ((R + 1) * GMM_ALD);      // R rows + one scratch row
+    constexpr int WAVE_LDS = (R + 1) * GMM_ALD + gmm_stage_floats(CS16, R);      // accumulator (R rows + scratch row) + staging image
+    float* acc = smem + wave * WAVE_LDS;
 
     const int64_t wid = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wave;     // neighbouring row tiles share an XCD / L2
     const int per_sub = p.n_slices * p.G;
@@ -287,7 +317,8 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         *reinterpret_cast<float4*>(acc + r * GMM_ALD + c4 * 4) = v;
     }
 
-    GmmWave<CS16, R, gmm_njb(CS16, R), TR> w(p);
+    GmmWave<CS16, R, gmm_jb(CS16, R), TR> w(p);
+    w.stage = acc + (R + 1) * GMM_ALD;
     const unsigned long long tw0 = TR ? __builtin_readcyclecounter() : 0;
     if (TR) w.tr[0] = w.tr[1] = w.tr[2] = w.tr[3] = 0;
     w.acc = acc; w.lane = lane; w.i16 = lane & 15; w.q = lane >> 4; w.slice = slice; w.row0 = row0;
@@ -340,7 +371,7 @@ static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
 
 template <int CS16, int R>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
-    const size_t lds = (size_t)4 * (R + 1) * GMM_ALD * sizeof(float);
+    const size_t lds = (size_t)4 * ((R + 1) * GMM_ALD + gmm_stage_floats(CS16, R)) * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
     if constexpr (R == 64 && (CS16 == 2 || CS16 == 4)) {
         if (getenv("U3D_GMM_TRACE")) {          // experiment: per-phase cycle breakdown of the wave program (synchronous)

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libu3d_hip.so')
+LIB_PATH = os.environ.get('U3D_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libu3d_hip.so')      # override: A/B runs of kernel builds
 
 _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 

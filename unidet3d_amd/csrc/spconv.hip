@@ -44,7 +44,6 @@ struct GmmParams {
     int n_slices;
     int G;
     int kper;
-    unsigned long long* trace;   // experiment (env U3D_GMM_TRACE): per-phase cycle sums over all waves, else nullptr
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
@@ -52,24 +51,42 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 }
 
 constexpr int GMM_CDS = 32;            // output columns per wave
-constexpr int GMM_ALD = GMM_CDS + 4;   // padded accumulator row
+constexpr int GMM_ALD = 40;            // accumulator row stride (floats): 160 B keeps the 16-byte accesses of consecutive rows on distinct banks
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+__device__ __forceinline__ f32x4 bload128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ int bload32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);     // raw dword buffer, 2 GiB window
+}
 
 // ---- software-pipelined wave program ---------------------------------------------------------------------
 // A wave's work is a sequence of ITEMS (offset k, window of W = 16*NCH pairs of k's range in this row tile);
 // an item is computed in NJB UNITS of JB 16-channel groups of the source channels.  Per unit the wave holds
-// the gathered rows and the B fragments (packed weights) in registers; the loads of unit u+1 are issued
-// BEFORE the MFMAs of unit u, and the raw gather/scatter indices are loaded two items ahead, so a single wave
-// keeps its MFMAs fed without relying on other resident waves to hide the gather latency.
-// Two register buffers alternate; the unit sequence is unrolled so buffer roles are static.
-//
-// The gather is shaped for the texture-addresser, not for the MFMA: the vector L1 spends ~4 cycles (L1 hit) to
-// ~7 cycles (L2 hit) per distinct 128-byte line a wave instruction touches (tools/l1_bw.hip: fragment-shaped loads,
-// 16 rows x 64 B per instruction, reach 15 B/clk/CU from L1 and 9 from L2; whole-line loads 31-39), and that
-// rate -- not MFMA, HBM or L2 bandwidth -- bounded the kernel while every lane fetched its own MFMA fragment
-// (per-item trace: 8.8k cycles stalled in load issue vs 1.05k in MFMA).  So a load instruction now reads
-// 64/PPR complete rows (PPR = JB*4 lanes x 16 B per row = whole lines), the wave transposes the unit through a
-// private, XOR-swizzled LDS image (ds_write_b128 -> ds_read_b128, both conflict-free, no barrier: LDS
-// operations of one wave execute in order) and picks up its A fragments from there.
+// the gathered rows and the packed weight fragments in registers; the loads of unit u+1 are issued BEFORE the
+// MFMAs of unit u and the raw gather/scatter indices are loaded two items ahead.  Two register buffers
+// alternate; the unit sequence is unrolled so buffer roles are static.  What shaped the rest (all measured on
+// MI355X, tools/coissue.hip, tools/l1_bw.hip, tools/mfma_peak.hip):
+//  * VALU instructions do NOT overlap with fp32 MFMAs of other waves on the same SIMD (MFMA loop 3.7 ms, fp32
+//    VALU loop 2.0 ms, both together 5.3 ms; LDS traffic does overlap).  SIMD time = 32 cycles per MFMA + 4-16 per
+//    VALU instruction, so the program is written for VALU count: buffer loads (one v_mad_u32_u24 per gathered
+//    row instead of 64-bit address chains), scalar weight offsets, per-lane constants hoisted, and an epilogue
+//    without VALU arithmetic (below).  ~20 VALU instructions per 32-pair item against 16-32 MFMAs.
+//  * The MFMA computes the TRANSPOSED tile (A operand = weight fragment, B operand = gathered rows), so a lane
+//    ends up with 4 consecutive output columns of ONE pair: the accumulator row is read with a single
+//    ds_read_b128 straight into the MFMA's C operand and written back with one ds_write_b128 -- the MFMA does
+//    the accumulation, there is no v_add, no zero fill, and one index shuffle per chunk instead of four.
+//    (Inside one offset every destination row occurs at most once and the tile is private to the wave, so the
+//    plain read-modify-write is exact; ds_add_f32 atomics measured ~10x slower.)
+//  * The vector L1 spends ~4 (L1 hit) to ~7 (L2 hit) cycles per distinct 128-byte line a wave instruction touches:
+//    a load instruction therefore reads 64/PPR COMPLETE rows (PPR = JB*4 lanes x 16 B each), and the wave
+//    transposes them to MFMA fragments through a private XOR-swizzled LDS image (ds_write_b128 -> ds_read_b128,
+//    both conflict-free; LDS operations of one wave execute in order, so no barrier).
 template <int NI, int JB>
 struct GmmBuf {
     f32x4 a[NI];         // instruction i: rows i*RPI + lane/PPR of the item, 16-byte piece lane%PPR of the unit
@@ -81,7 +98,7 @@ struct GmmItem {
     bool valid;
 };
 
-template <int CS16, int R, int JB_, bool TR>
+template <int CS16, int R, int JB_>
 struct GmmWave {
     static constexpr int NCH = R / 32;            // 16-pair chunks per item
     static constexpr int JB = JB_;                // 16-channel groups per unit (1, 2 or 4)
@@ -89,35 +106,40 @@ struct GmmWave {
     static constexpr int W = 16 * NCH;
     static constexpr int PPR = JB * 4;            // 16-byte pieces (lanes) per row of a unit
     static constexpr int RPI = 64 / PPR;          // rows per load instruction
-    static constexpr int NI = W / RPI;            // load instructions per unit (= NCH*JB)
+    static constexpr int NI = W / RPI;            // load instructions per unit
+    static constexpr int IPC = 16 / RPI;          // load instructions per 16-row chunk
     static constexpr int TRASH = R;               // scratch accumulator row for lanes past the end of a range
     static_assert(CS16 % JB == 0 && (JB == 1 || JB == 2 || JB == 4), "unit shape");
     using Buf = GmmBuf<NI, JB>;
 
-    const GmmParams& p;
-    float* acc;
-    float* stage;                                 // W rows x PPR pieces, piece slot p ^ swz(row)
-    int lane, i16, q, slice, k_hi;
-    int64_t row0;
+    __amdgpu_buffer_rsrc_t rs_src, rs_g, rs_s, rs_w;
+    char* accq;                                   // accumulator tile + this lane's column offset (q*16 bytes)
+    float* stage;                                 // 16 rows x PPR pieces, piece slot p ^ swz(row)
+    int lane, i16, slice, k_hi, cs4, K, row0;
+    int64_t cap;
     int ts_s, ts_e;                               // lane k: pair range of offset k in this row tile
+    int lr, lp16, lane16, lw, lw4;                // per-lane constants
     int wr_off, rd_off[JB];                       // float offsets into `stage` of this lane's write / fragment reads
 
     GmmItem it0, it1;                             // item being computed / item whose first unit is fetched next
     int s_cur, g_cur;                             // it0: scatter / gather row of pair (base + lane), lanes < W
     int ix1_g, ix1_s;                             // it1: raw indices, lanes < W
-    f32x4 d[NCH][2];
-    unsigned long long tr[4];                     // TR only: cycles in {search + load issue, MFMA, scatter}, items
+    int soff0, soff1;                             // it0: byte offset of this lane's accumulator row, chunk 0 / 1
+    f32x4 d00, d01, d10, d11;                     // accumulators [chunk][column block]; named scalars: arrays get merged into
+                                                  // runtime-indexed scratch by the TWO / single-chunk tail merge
 
-    __device__ __forceinline__ GmmWave(const GmmParams& p_) : p(p_) {}
-
-    // conflict-free for the ds_read_b128 lane groups of gfx950 (brute-forced against the bank model)
     static __device__ __forceinline__ int swz(int row) { return PPR == 4 ? ((row >> 1) & 3) : (row & (PPR - 1)); }
 
-    __device__ __forceinline__ void init_offsets() {
-        const int lr = lane / PPR, lp = lane % PPR;
-        wr_off = (lr * PPR + (lp ^ swz(lr))) * 4;             // swz(i*RPI + lr) == swz(lr) for PPR = 4, 8
+    __device__ __forceinline__ void init(const GmmParams& p, float* acc, float* stage_, int lane_, int slice_, int64_t row0_) {
+        rs_src = make_rsrc(p.src); rs_g = make_rsrc(p.gather); rs_s = make_rsrc(p.scatter); rs_w = make_rsrc(p.w);
+        lane = lane_; i16 = lane & 15; slice = slice_; cs4 = p.Cs * 4; K = p.K; cap = p.cap; row0 = (int)row0_;
+        const int q = lane >> 4;
+        accq = reinterpret_cast<char*>(acc) + q * 16;
+        stage = stage_;
+        lr = lane / PPR; lp16 = (lane % PPR) * 16; lane16 = lane * 16; lw = lane & (W - 1); lw4 = lw * 4;
+        wr_off = (lr * PPR + ((lane % PPR) ^ swz(lr))) * 4;             // swz(i*RPI + lr) == swz(lr) for PPR = 4, 8
 #pragma unroll
-        for (int j = 0; j < JB; ++j) rd_off[j] = (i16 * PPR + ((j * 4 + q) ^ swz(i16))) * 4;     // + c*16*PPR*4
+        for (int j = 0; j < JB; ++j) rd_off[j] = (i16 * PPR + ((j * 4 + q) ^ swz(i16))) * 4;
     }
     __device__ __forceinline__ bool range_of(int k, int& s_, int& e_) const {
         s_ = __builtin_amdgcn_readlane(ts_s, k);
@@ -145,114 +167,98 @@ struct GmmWave {
     }
     // two coalesced loads per item (lanes < W = the item's pairs, clamped into the range -> unconditional)
     __device__ __forceinline__ void load_idx(const GmmItem& it, int& g, int& s_) const {
-        const int pi = min(it.base + (lane & (W - 1)), it.e - 1);
-        g = p.gather[(int64_t)it.k * p.cap + pi];
-        s_ = p.scatter[(int64_t)it.k * p.cap + pi];
+        const int voff = min(it.base * 4 + lw4, (it.e - 1) * 4);
+        const int soff_k = (int)(it.k * cap) * 4;
+        g = bload32(rs_g, voff, soff_k);
+        s_ = bload32(rs_s, voff, soff_k);
     }
     __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u) const {
-        const int lr = lane / PPR, lp = lane % PPR;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int g = __shfl(raw_g, i * RPI + lr, 64);
-            buf.a[i] = *reinterpret_cast<const f32x4*>(p.src + (int64_t)g * p.Cs + (u * JB * 4 + lp) * 4);
+            buf.a[i] = bload128(rs_src, (int)__umul24(g, cs4) + lp16, u * (JB * 64));
         }
-        const float* wk = p.w + ((int64_t)slice * p.K + k) * (CS16 * 512) + u * JB * 512 + lane * 4;   // 1 KB per wave load
+        const int wso = ((slice * K + k) * CS16 + u * JB) * 2048;       // bytes: (j, nb) blocks of 1 KB
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            buf.b[j][0] = *reinterpret_cast<const f32x4*>(wk + (j * 2 + 0) * 256);
-            buf.b[j][1] = *reinterpret_cast<const f32x4*>(wk + (j * 2 + 1) * 256);
+            buf.b[j][0] = bload128(rs_w, lane16, wso + j * 2048);
+            buf.b[j][1] = bload128(rs_w, lane16 + 1024, wso + j * 2048);
         }
     }
-    // rows -> LDS image -> A fragments; then the MFMAs: independent accumulator chains interleaved
-    // (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
-    template <bool TWO>
-    __device__ __forceinline__ void mfma(const Buf& buf) {
+    struct Frag { f32x4 v[JB]; };
+    // rows of one 16-pair chunk: registers -> swizzled LDS image -> fragments
+    template <int C>
+    __device__ __forceinline__ Frag frags(const Buf& buf) const {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int i = 0; i < IPC; ++i) {
             int off = wr_off + i * (RPI * PPR * 4);
             if constexpr (PPR == 16) {       // swz(row) depends on i here: recompute the slot
-                const int lr = lane / PPR, lp = lane % PPR, row = i * RPI + lr;
-                off = (row * PPR + (lp ^ swz(row))) * 4;
+                const int row = i * RPI + lr;
+                off = (row * PPR + ((lp16 >> 4) ^ swz(row))) * 4;
             }
-            *reinterpret_cast<f32x4*>(stage + off) = buf.a[i];
+            *reinterpret_cast<f32x4*>(stage + off) = buf.a[C * IPC + i];
         }
-        constexpr int NC = TWO ? NCH : 1;
-        f32x4 fa[NC][JB];
+        Frag f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int j = 0; j < JB; ++j) fa[c][j] = *reinterpret_cast<const f32x4*>(stage + rd_off[j] + c * (16 * PPR * 4));
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-#define U3D_STEP(c)                                                                                      \
-    d[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][j][c], buf.b[j][0][c], d[0][0], 0, 0, 0);         \
-    d[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][j][c], buf.b[j][1][c], d[0][1], 0, 0, 0);         \
-    if constexpr (TWO) {                                                                                 \
-        d[NCH - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[NC - 1][j][c], buf.b[j][0][c], d[NCH - 1][0], 0, 0, 0); \
-        d[NCH - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[NC - 1][j][c], buf.b[j][1][c], d[NCH - 1][1], 0, 0, 0); \
-    }
-            U3D_STEP(0) U3D_STEP(1) U3D_STEP(2) U3D_STEP(3)
-#undef U3D_STEP
-        }
-    }
-    // the accumulator tile is private to this wave and, inside one offset, every destination row occurs at most
-    // once -> a plain LDS read-modify-write is exact (ds_add_f32 atomics measured ~10x slower: SQ_WAIT_INST_LDS
-    // was 83 % of all wave cycles with them).
-    template <bool TWO>
-    __device__ __forceinline__ void scatter() {
-        constexpr int NC = TWO ? NCH : 1;
-        // lane l < W owns pair (base + l): it resolves that pair's accumulator row ONCE (scratch row for lanes past
-        // the end) and the fragment layout fetches the finished word offsets with one shuffle each.
-        const int mine = (it0.base + (lane & (W - 1)) < it0.e) ? (int)(s_cur - row0) : TRASH;
-        const int mine_off = mine * GMM_ALD;
-        float* accl = acc + i16;
-        float o[NC][2][4];
-        int off[NC][4];
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) off[c][r] = __shfl(mine_off, c * 16 + q * 4 + r, 64);
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[c][nb][r] = accl[off[c][r] + nb * 16];
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) accl[off[c][r] + nb * 16] = o[c][nb][r] + d[c][nb][r];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) d[c][0] = d[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JB; ++j) f.v[j] = *reinterpret_cast<const f32x4*>(stage + rd_off[j]);
+        return f;
     }
 
+    // One unit of the current item.  Chunk 1 (pairs 16..31 of the window) exists only when the window holds more than
+    // 16 pairs (wave-uniform): its accumulator rows, fragments and MFMAs sit in their own scalar-branch blocks.
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
-        const bool two = NCH == 2 && it0.base + 16 < it0.e;      // wave-uniform
+        const bool two = NCH == 2 && it0.base + 16 < it0.e;
+        GmmItem it2;
+        int g2 = 0, s2 = 0;
         if constexpr (U == NJB - 1) {
-            const unsigned long long t0 = TR ? __builtin_readcyclecounter() : 0;
-            const GmmItem it2 = next_of(it1);
-            int g2, s2;
+            it2 = next_of(it1);
             load_idx(it2, g2, s2);
             issue(nxt, ix1_g, it1.k, 0);
-            const unsigned long long t1 = TR ? __builtin_readcyclecounter() : 0;
-            if (two) mfma<NCH == 2>(cur);
-            else mfma<false>(cur);
-            const unsigned long long t2 = TR ? __builtin_readcyclecounter() : 0;
-            if (two) scatter<NCH == 2>();
-            else scatter<false>();
-            if (TR) {
-                const unsigned long long t3 = __builtin_readcyclecounter();
-                tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += 1;
+        } else {
+            issue(nxt, g_cur, it0.k, U + 1);
+        }
+        if constexpr (U == 0) {         // accumulator rows of the item -> C operands
+            const int mine = lw < it0.e - it0.base ? s_cur - row0 : TRASH;      // lane l < W owns pair base + l
+            const int mine_off = (int)__umul24(mine, GMM_ALD * 4);
+            soff0 = __shfl(mine_off, i16, 64);
+            d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
+            d01 = *reinterpret_cast<const f32x4*>(accq + soff0 + 64);
+            if (two) {
+                soff1 = __shfl(mine_off, 16 + i16, 64);
+                d10 = *reinterpret_cast<const f32x4*>(accq + soff1);
+                d11 = *reinterpret_cast<const f32x4*>(accq + soff1 + 64);
+            }
+        }
+        {
+            const Frag f = frags<0>(cur);
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][0][t], f.v[j][t], d00, 0, 0, 0);
+                    d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f.v[j][t], d01, 0, 0, 0);
+                }
+        }
+        if (two) {
+            const Frag f = frags<NCH - 1>(cur);
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][0][t], f.v[j][t], d10, 0, 0, 0);
+                    d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f.v[j][t], d11, 0, 0, 0);
+                }
+        }
+        if constexpr (U == NJB - 1) {
+            *reinterpret_cast<f32x4*>(accq + soff0) = d00;
+            *reinterpret_cast<f32x4*>(accq + soff0 + 64) = d01;
+            if (two) {
+                *reinterpret_cast<f32x4*>(accq + soff1) = d10;
+                *reinterpret_cast<f32x4*>(accq + soff1 + 64) = d11;
             }
             g_cur = ix1_g; s_cur = ix1_s; ix1_g = g2; ix1_s = s2;
             it0 = it1; it1 = it2;
-        } else {
-            issue(nxt, g_cur, it0.k, U + 1);
-            if (two) mfma<NCH == 2>(cur);
-            else mfma<false>(cur);
         }
     }
 
@@ -269,9 +275,6 @@ struct GmmWave {
         load_idx(it0, g_cur, s_cur);
         it1 = next_of(it0);
         load_idx(it1, ix1_g, ix1_s);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) d[c][0] = d[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        init_offsets();
         Buf X, Y;
         issue(X, g_cur, it0.k, 0);
         while (true) {
@@ -286,17 +289,16 @@ struct GmmWave {
 };
 
 // 16-channel groups per unit: 128-byte row pieces (JB = 2) for 64-row tiles, 256-byte pieces for 32-row tiles when
-// the channel count allows, so that the staging image stays at 4 KB per wave
+// the channel count allows
 constexpr int gmm_jb(int cs16, int r) { return (cs16 % 4 == 0 && r == 32) ? 4 : (cs16 % 2 == 0 ? 2 : 1); }
-constexpr int gmm_stage_floats(int cs16, int r) { return (r / 2) * gmm_jb(cs16, r) * 16; }      // W rows x JB*16 floats
+constexpr int gmm_wave_lds(int cs16, int r) { return (r + 1) * GMM_ALD + 16 * gmm_jb(cs16, r) * 16; }      // floats: accumulator + staging image
 
-template <int CS16, int R, bool TR = false>
+template <int CS16, int R>
 __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
-    constexpr int WAVE_LDS = (R + 1) * GMM_ALD + gmm_stage_floats(CS16, R);      // accumulator (R rows + scratch row) + staging image
-    float* acc = smem + wave * WAVE_LDS;
+    float* acc = smem + wave * gmm_wave_lds(CS16, R);                // R rows + one scratch row, then the staging image
 
     const int64_t wid = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wave;     // neighbouring row tiles share an XCD / L2
     const int per_sub = p.n_slices * p.G;
@@ -317,11 +319,8 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         *reinterpret_cast<float4*>(acc + r * GMM_ALD + c4 * 4) = v;
     }
 
-    GmmWave<CS16, R, gmm_jb(CS16, R), TR> w(p);
-    w.stage = acc + (R + 1) * GMM_ALD;
-    const unsigned long long tw0 = TR ? __builtin_readcyclecounter() : 0;
-    if (TR) w.tr[0] = w.tr[1] = w.tr[2] = w.tr[3] = 0;
-    w.acc = acc; w.lane = lane; w.i16 = lane & 15; w.q = lane >> 4; w.slice = slice; w.row0 = row0;
+    GmmWave<CS16, R, gmm_jb(CS16, R)> w;
+    w.init(p, acc, acc + (R + 1) * GMM_ALD, lane, slice, row0);
     const int k_lo = g * p.kper;
     w.k_hi = min(p.K, k_lo + p.kper);
     // all (start, end) ranges of this wave's offsets in one round trip: lane k holds offset k's range
@@ -331,10 +330,6 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         w.ts_e = p.ts[lane * tsld + sub + 1];
     }
     w.run(k_lo);
-    if (TR && lane == 0) {
-        atomicAdd(p.trace + 0, w.tr[0]); atomicAdd(p.trace + 1, w.tr[1]); atomicAdd(p.trace + 2, w.tr[2]); atomicAdd(p.trace + 3, w.tr[3]);
-        atomicAdd(p.trace + 4, (unsigned long long)(__builtin_readcyclecounter() - tw0)); atomicAdd(p.trace + 5, 1ull);
-    }
 
     float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
     for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
@@ -371,23 +366,8 @@ static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
 
 template <int CS16, int R>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
-    const size_t lds = (size_t)4 * ((R + 1) * GMM_ALD + gmm_stage_floats(CS16, R)) * sizeof(float);
+    const size_t lds = (size_t)4 * gmm_wave_lds(CS16, R) * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
-    if constexpr (R == 64 && (CS16 == 2 || CS16 == 4)) {
-        if (getenv("U3D_GMM_TRACE")) {          // experiment: per-phase cycle breakdown of the wave program (synchronous)
-            GmmParams q = p;
-            unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
-            if (hipMalloc(&q.trace, sizeof(h)) != hipSuccess) return U3D_ELAUNCH;
-            hipMemcpy(q.trace, h, sizeof(h), hipMemcpyHostToDevice);
-            hipLaunchKernelGGL((spconv_gmm_k<CS16, R, true>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, q);
-            hipStreamSynchronize(s);
-            hipMemcpy(h, q.trace, sizeof(h), hipMemcpyDeviceToHost);
-            hipFree(q.trace);
-            fprintf(stderr, "[gmm trace CS16=%d] waves %llu items %llu | per item: issue %.0f mfma %.0f scatter %.0f clk | per wave %.0f clk\n", CS16, h[5],
-                    h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[5]);
-            return check_launch("spconv_gmm");
-        }
-    }
     hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");
 }
@@ -620,7 +600,6 @@ int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather,
     p.out = G > 1 ? (float*)ws : dst;
     p.K = K; p.cap = cap; p.Cs = Cs; p.Cd = Cd; p.n_dst = n_dst; p.n_sub = ceil_div(n_dst, R);
     p.n_slices = Cd / GMM_CDS; p.G = G; p.kper = (int)ceil_div(K, G);
-    p.trace = nullptr;
     const int cs16 = Cs / 16;
     int rc = U3D_EUNSUPPORTED;
 #define U3D_GMM_CASE(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64>(p, s) : launch_gmm<cs, 32>(p, s);

@@ -16,6 +16,7 @@ produce.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch

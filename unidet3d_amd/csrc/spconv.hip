@@ -122,7 +122,7 @@ struct GmmWave {
     int wr_off, rd_off[JB];                       // float offsets into `stage` of this lane's write / fragment reads
 
     GmmItem it0, it1;                             // item being computed / item whose first unit is fetched next
-    int s_cur, g_cur;                             // it0: scatter / gather row of pair (base + lane), lanes < W
+    int g_cur;                                    // it0: gather row of pair (base + lane), lanes < W
     int ix1_g, ix1_s;                             // it1: raw indices, lanes < W
     int soff0, soff1;                             // it0: byte offset of this lane's accumulator row, chunk 0 / 1
     f32x4 d00, d01, d10, d11;                     // accumulators [chunk][column block]; named scalars: arrays get merged into
@@ -172,13 +172,19 @@ struct GmmWave {
         g = bload32(rs_g, voff, soff_k);
         s_ = bload32(rs_s, voff, soff_k);
     }
-    __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u) const {
+    __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u, bool first = false) const {
+#if defined(U3D_EXP_NOA)       // timing experiment: gathered rows loaded once
+        if (first)
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int g = __shfl(raw_g, i * RPI + lr, 64);
             buf.a[i] = bload128(rs_src, (int)__umul24(g, cs4) + lp16, u * (JB * 64));
         }
         const int wso = ((slice * K + k) * CS16 + u * JB) * 2048;       // bytes: (j, nb) blocks of 1 KB
+#if defined(U3D_EXP_NOB)       // timing experiment: weights loaded once
+        if (first)
+#endif
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             buf.b[j][0] = bload128(rs_w, lane16, wso + j * 2048);
@@ -204,50 +210,57 @@ struct GmmWave {
         return f;
     }
 
+    // byte offsets of the accumulator rows of item `it` whose raw scatter rows are `raw_s` (lane l < W owns pair base + l)
+    __device__ __forceinline__ void row_offsets(const GmmItem& it, int raw_s, int& o0, int& o1) const {
+        const int mine = lw < it.e - it.base ? raw_s - row0 : TRASH;
+        const int mine_off = (int)__umul24(mine, GMM_ALD * 4);
+        o0 = __shfl(mine_off, i16, 64);
+        o1 = NCH == 2 ? __shfl(mine_off, 16 + i16, 64) : 0;
+    }
+
     // One unit of the current item.  Chunk 1 (pairs 16..31 of the window) exists only when the window holds more than
-    // 16 pairs (wave-uniform): its accumulator rows, fragments and MFMAs sit in their own scalar-branch blocks.
+    // 16 pairs (wave-uniform).  Order matters: a wave's critical path per item is LDS round trips + MFMAs, so ALL LDS
+    // work of the unit (accumulator reads, staging writes, fragment reads, index shuffles for the next unit) is put
+    // into the in-order LDS queue up front and waited for once, then the next unit's loads are issued and the MFMAs
+    // run back to back.
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
+        if constexpr (U == 0) {         // accumulator rows of the item -> C operands
+            d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
+            d01 = *reinterpret_cast<const f32x4*>(accq + soff0 + 64);
+            if (two) {
+                d10 = *reinterpret_cast<const f32x4*>(accq + soff1);
+                d11 = *reinterpret_cast<const f32x4*>(accq + soff1 + 64);
+            }
+        }
+        const Frag f0 = frags<0>(cur);
+        Frag f1 = f0;
+        if (two) f1 = frags<NCH - 1>(cur);
         GmmItem it2;
-        int g2 = 0, s2 = 0;
+        int g2 = 0, s2 = 0, n0 = 0, n1 = 0;
         if constexpr (U == NJB - 1) {
+            row_offsets(it1, ix1_s, n0, n1);
             it2 = next_of(it1);
             load_idx(it2, g2, s2);
             issue(nxt, ix1_g, it1.k, 0);
         } else {
             issue(nxt, g_cur, it0.k, U + 1);
         }
-        if constexpr (U == 0) {         // accumulator rows of the item -> C operands
-            const int mine = lw < it0.e - it0.base ? s_cur - row0 : TRASH;      // lane l < W owns pair base + l
-            const int mine_off = (int)__umul24(mine, GMM_ALD * 4);
-            soff0 = __shfl(mine_off, i16, 64);
-            d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
-            d01 = *reinterpret_cast<const f32x4*>(accq + soff0 + 64);
-            if (two) {
-                soff1 = __shfl(mine_off, 16 + i16, 64);
-                d10 = *reinterpret_cast<const f32x4*>(accq + soff1);
-                d11 = *reinterpret_cast<const f32x4*>(accq + soff1 + 64);
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][0][t], f0.v[j][t], d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f0.v[j][t], d01, 0, 0, 0);
             }
-        }
-        {
-            const Frag f = frags<0>(cur);
-#pragma unroll
-            for (int j = 0; j < JB; ++j)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][0][t], f.v[j][t], d00, 0, 0, 0);
-                    d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f.v[j][t], d01, 0, 0, 0);
-                }
-        }
         if (two) {
-            const Frag f = frags<NCH - 1>(cur);
 #pragma unroll
             for (int j = 0; j < JB; ++j)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][0][t], f.v[j][t], d10, 0, 0, 0);
-                    d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f.v[j][t], d11, 0, 0, 0);
+                    d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][0][t], f1.v[j][t], d10, 0, 0, 0);
+                    d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f1.v[j][t], d11, 0, 0, 0);
                 }
         }
         if constexpr (U == NJB - 1) {
@@ -257,7 +270,7 @@ struct GmmWave {
                 *reinterpret_cast<f32x4*>(accq + soff1) = d10;
                 *reinterpret_cast<f32x4*>(accq + soff1 + 64) = d11;
             }
-            g_cur = ix1_g; s_cur = ix1_s; ix1_g = g2; ix1_s = s2;
+            g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
             it0 = it1; it1 = it2;
         }
     }
@@ -272,11 +285,16 @@ struct GmmWave {
     __device__ __forceinline__ void run(int k_lo) {
         it0 = first_item(k_lo);
         if (!it0.valid) return;
-        load_idx(it0, g_cur, s_cur);
+        int s_first;
+        load_idx(it0, g_cur, s_first);
         it1 = next_of(it0);
         load_idx(it1, ix1_g, ix1_s);
+        row_offsets(it0, s_first, soff0, soff1);
         Buf X, Y;
-        issue(X, g_cur, it0.k, 0);
+#if defined(U3D_EXP_NOA) || defined(U3D_EXP_NOB)
+        issue(Y, g_cur, it0.k, 0, true);
+#endif
+        issue(X, g_cur, it0.k, 0, true);
         while (true) {
             units<0>(X, Y);
             if (!it0.valid) break;

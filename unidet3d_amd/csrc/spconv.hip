@@ -44,6 +44,9 @@ struct GmmParams {
     int n_slices;
     int G;
     int kper;
+#ifdef U3D_TRACE
+    unsigned long long* trace;   // timing experiment build only: per-phase cycle sums
+#endif
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
@@ -125,6 +128,14 @@ struct GmmWave {
     int g_cur;                                    // it0: gather row of pair (base + lane), lanes < W
     int ix1_g, ix1_s;                             // it1: raw indices, lanes < W
     int soff0, soff1;                             // it0: byte offset of this lane's accumulator row, chunk 0 / 1
+#ifdef U3D_TRACE
+    unsigned long long tr[6];
+#define U3D_T(i, a, b) tr[i] += (b) - (a)
+#define U3D_NOW() __builtin_readcyclecounter()
+#else
+#define U3D_T(i, a, b)
+#define U3D_NOW() 0
+#endif
     f32x4 d00, d01, d10, d11;                     // accumulators [chunk][column block]; named scalars: arrays get merged into
                                                   // runtime-indexed scratch by the TWO / single-chunk tail merge
 
@@ -226,6 +237,7 @@ struct GmmWave {
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
+        [[maybe_unused]] const unsigned long long t0 = U3D_NOW();
         if constexpr (U == 0) {         // accumulator rows of the item -> C operands
             d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
             d01 = *reinterpret_cast<const f32x4*>(accq + soff0 + 64);
@@ -237,6 +249,7 @@ struct GmmWave {
         const Frag f0 = frags<0>(cur);
         Frag f1 = f0;
         if (two) f1 = frags<NCH - 1>(cur);
+        [[maybe_unused]] const unsigned long long t1 = U3D_NOW();
         GmmItem it2;
         int g2 = 0, s2 = 0, n0 = 0, n1 = 0;
         if constexpr (U == NJB - 1) {
@@ -247,6 +260,7 @@ struct GmmWave {
         } else {
             issue(nxt, g_cur, it0.k, U + 1);
         }
+        [[maybe_unused]] const unsigned long long t2 = U3D_NOW();
 #pragma unroll
         for (int j = 0; j < JB; ++j)
 #pragma unroll
@@ -263,6 +277,7 @@ struct GmmWave {
                     d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f1.v[j][t], d11, 0, 0, 0);
                 }
         }
+        [[maybe_unused]] const unsigned long long t3 = U3D_NOW();
         if constexpr (U == NJB - 1) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
             *reinterpret_cast<f32x4*>(accq + soff0 + 64) = d01;
@@ -273,6 +288,7 @@ struct GmmWave {
             g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
             it0 = it1; it1 = it2;
         }
+        U3D_T(0, t0, t1); U3D_T(1, t1, t2); U3D_T(2, t2, t3); U3D_T(3, t3, U3D_NOW()); U3D_T(4, 0, 1);
     }
 
     // units U .. NJB-1 of the current item, buffers alternating
@@ -347,7 +363,17 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         w.ts_s = p.ts[lane * tsld + sub];
         w.ts_e = p.ts[lane * tsld + sub + 1];
     }
+#ifdef U3D_TRACE
+    for (int i = 0; i < 6; ++i) w.tr[i] = 0;
+    const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
     w.run(k_lo);
+#ifdef U3D_TRACE
+    if (lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(p.trace + i, w.tr[i]);
+        atomicAdd(p.trace + 5, (unsigned long long)(__builtin_readcyclecounter() - tw0)); atomicAdd(p.trace + 6, 1ull);
+    }
+#endif
 
     float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
     for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
@@ -386,6 +412,21 @@ template <int CS16, int R>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
     const size_t lds = (size_t)4 * gmm_wave_lds(CS16, R) * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
+#ifdef U3D_TRACE
+    {
+        GmmParams q = p;
+        unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (hipMalloc(&q.trace, sizeof(h)) != hipSuccess) return U3D_ELAUNCH;
+        hipMemcpy(q.trace, h, sizeof(h), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, q);
+        hipStreamSynchronize(s);
+        hipMemcpy(h, q.trace, sizeof(h), hipMemcpyDeviceToHost);
+        hipFree(q.trace);
+        fprintf(stderr, "[gmm trace CS16=%d R=%d] waves %llu units %llu | per unit: lds %.0f issue %.0f mfma %.0f store %.0f clk | per wave %.0f clk\n", CS16, R,
+                h[6], h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4], (double)h[5] / h[6]);
+        return check_launch("spconv_gmm");
+    }
+#endif
     hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");
 }
@@ -412,23 +453,20 @@ struct WgParams {
     int n_tiles;
 };
 
+// N consecutive floats of a row through raw buffer loads at byte offset voff: 16-byte loads where the strided channel
+// blocks are 16-byte aligned, dwords otherwise (this compiler lowers __builtin_amdgcn_raw_buffer_load_b64 to a ONE-dword
+// load -- checked in the ISA -- so there is no 8-byte form)
 template <int N>
-__device__ __forceinline__ void load_row_part(float (&v)[N], const float* __restrict__ p) {
+__device__ __forceinline__ void load_row_part(float (&v)[N], __amdgpu_buffer_rsrc_t r, int voff) {
     if constexpr (N % 4 == 0) {
 #pragma unroll
         for (int s = 0; s < N; s += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p + s);
-            v[s] = t.x; v[s + 1] = t.y; v[s + 2] = t.z; v[s + 3] = t.w;
-        }
-    } else if constexpr (N % 2 == 0) {
-#pragma unroll
-        for (int s = 0; s < N; s += 2) {
-            const float2 t = *reinterpret_cast<const float2*>(p + s);
-            v[s] = t.x; v[s + 1] = t.y;
+            const f32x4 t = bload128(r, voff + s * 4, 0);
+            v[s] = t[0]; v[s + 1] = t[1]; v[s + 2] = t[2]; v[s + 3] = t[3];
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < N; ++s) v[s] = p[s];
+        for (int s = 0; s < N; ++s) v[s] = __builtin_bit_cast(float, bload32(r, voff + s * 4, 0));
     }
 }
 
@@ -450,10 +488,14 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
     if (range >= p.n_tiles) return;                      // wave-uniform; the kernel has no barrier
     const int lo = p.ts[(int64_t)k * (p.n_tiles + 1) + range];
     const int hi = p.ts[(int64_t)k * (p.n_tiles + 1) + range + 1];
-    const int32_t* rx = p.rows_x + (int64_t)k * p.cap;
-    const int32_t* rg = p.rows_dy + (int64_t)k * p.cap;
-    const float* gbase = p.dy + NG * i16 + wa * NGW;
-    const float* xbase = p.x + NX * i16 + wb * NXW;
+    // VALU instructions do not overlap with fp32 MFMAs on a SIMD (tools/coissue.hip), so the loop is written for VALU
+    // count: raw buffer loads (one v_mad_u32_u24 per gathered row instead of a 64-bit address chain), the pair list
+    // read from a scalar offset with constant per-lane offsets (lane group q takes pairs 4q..4q+3 of the trip;
+    // any fixed pair <-> MFMA k-slot assignment is valid as long as x and dy use the same), and no masking in full trips.
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_g = make_rsrc(p.dy), rs_rx = make_rsrc(p.rows_x), rs_rg = make_rsrc(p.rows_dy);
+    const int ksoff = (int)(k * p.cap) * 4;
+    const int gvo = (NG * i16 + wa * NGW) * 4, xvo = (NX * i16 + wb * NXW) * 4;     // byte offset of this lane's channel block in a row
+    const int q16 = q * 16;
 
     f32x4 acc[NGW][NXW];
 #pragma unroll
@@ -461,23 +503,39 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
 #pragma unroll
         for (int b = 0; b < NXW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int base = lo; base < hi; base += 16) {        // 4 MFMA K-steps (16 pairs) per trip, all loads up front
-        int io[4], ix[4];
+    int base = lo;
+    for (; base + 16 <= hi; base += 16) {        // full trips: 4 MFMA K-steps (16 pairs), all loads up front
+        int io[4], ix[4];        // dword loads: `base` is only 4-byte aligned and 16-byte buffer loads are size-aligned by the hardware
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int pi = min(base + 4 * u + q, hi - 1);
-            io[u] = rg[pi];
-            ix[u] = rx[pi];
+            io[u] = bload32(rs_rg, q16 + u * 4, ksoff + base * 4);
+            ix[u] = bload32(rs_rx, q16 + u * 4, ksoff + base * 4);
         }
         float gv[4][NGW], xv[4][NXW];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            load_row_part<NGW>(gv[u], gbase + (int64_t)io[u] * CD);
-            load_row_part<NXW>(xv[u], xbase + (int64_t)ix[u] * CS);
+            load_row_part<NGW>(gv[u], rs_g, (int)__umul24(io[u], CD * 4) + gvo);
+            load_row_part<NXW>(xv[u], rs_x, (int)__umul24(ix[u], CS * 4) + xvo);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < NGW; ++a)
+#pragma unroll
+                for (int b = 0; b < NXW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[u][a], xv[u][b], acc[a][b], 0, 0, 0);
+    }
+    if (base < hi) {                              // last, partial trip: indices clamped into the range, masked dy
+        float gv[4][NGW], xv[4][NXW];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pi = min(base + 4 * q + u, hi - 1);
+            const int io = bload32(rs_rg, pi * 4, ksoff), ix = bload32(rs_rx, pi * 4, ksoff);
+            load_row_part<NGW>(gv[u], rs_g, (int)__umul24(io, CD * 4) + gvo);
+            load_row_part<NXW>(xv[u], rs_x, (int)__umul24(ix, CS * 4) + xvo);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool ok = base + 4 * u + q < hi;        // pairs past the end contribute exact zeros
+            const bool ok = base + 4 * q + u < hi;        // pairs past the end contribute exact zeros
 #pragma unroll
             for (int a = 0; a < NGW; ++a) {
                 const float ga = ok ? gv[u][a] : 0.f;

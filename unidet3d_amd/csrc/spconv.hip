@@ -44,9 +44,6 @@ struct GmmParams {
     int n_slices;
     int G;
     int kper;
-#ifdef U3D_TRACE
-    unsigned long long* trace;   // timing experiment build only: per-phase cycle sums
-#endif
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
@@ -128,14 +125,6 @@ struct GmmWave {
     int g_cur;                                    // it0: gather row of pair (base + lane), lanes < W
     int ix1_g, ix1_s;                             // it1: raw indices, lanes < W
     int soff0, soff1;                             // it0: byte offset of this lane's accumulator row, chunk 0 / 1
-#ifdef U3D_TRACE
-    unsigned long long tr[6];
-#define U3D_T(i, a, b) tr[i] += (b) - (a)
-#define U3D_NOW() __builtin_readcyclecounter()
-#else
-#define U3D_T(i, a, b)
-#define U3D_NOW() 0
-#endif
     f32x4 d00, d01, d10, d11;                     // accumulators [chunk][column block]; named scalars: arrays get merged into
                                                   // runtime-indexed scratch by the TWO / single-chunk tail merge
 
@@ -183,19 +172,13 @@ struct GmmWave {
         g = bload32(rs_g, voff, soff_k);
         s_ = bload32(rs_s, voff, soff_k);
     }
-    __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u, bool first = false) const {
-#if defined(U3D_EXP_NOA)       // timing experiment: gathered rows loaded once
-        if (first)
-#endif
+    __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u) const {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int g = __shfl(raw_g, i * RPI + lr, 64);
             buf.a[i] = bload128(rs_src, (int)__umul24(g, cs4) + lp16, u * (JB * 64));
         }
         const int wso = ((slice * K + k) * CS16 + u * JB) * 2048;       // bytes: (j, nb) blocks of 1 KB
-#if defined(U3D_EXP_NOB)       // timing experiment: weights loaded once
-        if (first)
-#endif
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             buf.b[j][0] = bload128(rs_w, lane16, wso + j * 2048);
@@ -237,7 +220,6 @@ struct GmmWave {
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
-        [[maybe_unused]] const unsigned long long t0 = U3D_NOW();
         if constexpr (U == 0) {         // accumulator rows of the item -> C operands
             d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
             d01 = *reinterpret_cast<const f32x4*>(accq + soff0 + 64);
@@ -249,7 +231,6 @@ struct GmmWave {
         const Frag f0 = frags<0>(cur);
         Frag f1 = f0;
         if (two) f1 = frags<NCH - 1>(cur);
-        [[maybe_unused]] const unsigned long long t1 = U3D_NOW();
         GmmItem it2;
         int g2 = 0, s2 = 0, n0 = 0, n1 = 0;
         if constexpr (U == NJB - 1) {
@@ -260,7 +241,6 @@ struct GmmWave {
         } else {
             issue(nxt, g_cur, it0.k, U + 1);
         }
-        [[maybe_unused]] const unsigned long long t2 = U3D_NOW();
 #pragma unroll
         for (int j = 0; j < JB; ++j)
 #pragma unroll
@@ -277,7 +257,6 @@ struct GmmWave {
                     d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f1.v[j][t], d11, 0, 0, 0);
                 }
         }
-        [[maybe_unused]] const unsigned long long t3 = U3D_NOW();
         if constexpr (U == NJB - 1) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
             *reinterpret_cast<f32x4*>(accq + soff0 + 64) = d01;
@@ -288,7 +267,6 @@ struct GmmWave {
             g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
             it0 = it1; it1 = it2;
         }
-        U3D_T(0, t0, t1); U3D_T(1, t1, t2); U3D_T(2, t2, t3); U3D_T(3, t3, U3D_NOW()); U3D_T(4, 0, 1);
     }
 
     // units U .. NJB-1 of the current item, buffers alternating
@@ -307,10 +285,7 @@ struct GmmWave {
         load_idx(it1, ix1_g, ix1_s);
         row_offsets(it0, s_first, soff0, soff1);
         Buf X, Y;
-#if defined(U3D_EXP_NOA) || defined(U3D_EXP_NOB)
-        issue(Y, g_cur, it0.k, 0, true);
-#endif
-        issue(X, g_cur, it0.k, 0, true);
+        issue(X, g_cur, it0.k, 0);
         while (true) {
             units<0>(X, Y);
             if (!it0.valid) break;
@@ -363,17 +338,7 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         w.ts_s = p.ts[lane * tsld + sub];
         w.ts_e = p.ts[lane * tsld + sub + 1];
     }
-#ifdef U3D_TRACE
-    for (int i = 0; i < 6; ++i) w.tr[i] = 0;
-    const unsigned long long tw0 = __builtin_readcyclecounter();
-#endif
     w.run(k_lo);
-#ifdef U3D_TRACE
-    if (lane == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(p.trace + i, w.tr[i]);
-        atomicAdd(p.trace + 5, (unsigned long long)(__builtin_readcyclecounter() - tw0)); atomicAdd(p.trace + 6, 1ull);
-    }
-#endif
 
     float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
     for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
@@ -412,21 +377,6 @@ template <int CS16, int R>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
     const size_t lds = (size_t)4 * gmm_wave_lds(CS16, R) * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
-#ifdef U3D_TRACE
-    {
-        GmmParams q = p;
-        unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (hipMalloc(&q.trace, sizeof(h)) != hipSuccess) return U3D_ELAUNCH;
-        hipMemcpy(q.trace, h, sizeof(h), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, q);
-        hipStreamSynchronize(s);
-        hipMemcpy(h, q.trace, sizeof(h), hipMemcpyDeviceToHost);
-        hipFree(q.trace);
-        fprintf(stderr, "[gmm trace CS16=%d R=%d] waves %llu units %llu | per unit: lds %.0f issue %.0f mfma %.0f store %.0f clk | per wave %.0f clk\n", CS16, R,
-                h[6], h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4], (double)h[5] / h[6]);
-        return check_launch("spconv_gmm");
-    }
-#endif
     hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");
 }

@@ -236,6 +236,19 @@ int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K);
 int u3d_transpose(const float* in /*[R,C]*/, float* out /*[C,R]*/, int R, int C, u3d_stream_t stream);
 
+/* ---- inference post-processing of one scene ------------------------------------------------
+ * u3d_nms_bev: replaces UniDet3D._single_scene_multiclass_nms with fast_nms=True (unidet3d/unidet3d.py:595-650, which
+ * calls mmcv.ops.nms3d_normal per class: greedy suppression by the IoU of the (x, y, dx, dy) rectangles).  boxes [n][6]
+ * = (cx, cy, cz, dx, dy, dz) and labels [n] must be ordered by (label ascending, score descending) -- the order the
+ * reference visits them in; keep[n] receives 1 for surviving boxes.  n <= 4096. */
+int u3d_nms_bev(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream);
+/* u3d_trim_boxes: replaces UniDet3D.trim_bboxes_by_superpoints + get_face_distances (unidet3d/unidet3d.py:540-593, :652-677)
+ * for yaw-free boxes.  points: rows of >= 3 floats with leading dimension pt_ld; (sp_list, sp_offsets[S+1]): CSR of point
+ * rows per superpoint (u3d_csr_build).  minmax [nb][6] receives (min xyz, max xyz) of the points selected for each box
+ * (+inf / -inf when none, as in the reference); centre = (max+min)/2 and size = max-min are left to the caller. */
+int u3d_trim_boxes(const float* points, int64_t pt_ld, const int32_t* sp_list, const int32_t* sp_offsets, int S,
+                   const float* boxes, int nb, float low_thr, float up_thr, float* minmax, u3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,138 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- inference post-processing of one scene.
+
+Only ``tests/`` and ``__graft_entry__.smoke()`` may import this module; nothing under
+``unidet3d_amd/`` does.
+
+What is restated, all in numpy float32 with the reference's operation order:
+  * ``predict_by_feat``               unidet3d/unidet3d.py:475-538  (softmax, top-k, labels)
+  * ``_single_scene_multiclass_nms``  unidet3d/unidet3d.py:595-650  (fast_nms=True branch)
+  * ``trim_bboxes_by_superpoints``    unidet3d/unidet3d.py:540-593
+  * ``get_face_distances``            unidet3d/unidet3d.py:652-677  (yaw = 0)
+
+PARITY UNPINNED.  The NMS arithmetic lives in a third-party dependency that is not under
+/root/reference: mmcv @ 780ffed9f3736fedadf18b51266ecbf521e64cf6 (Dockerfile:22-24), ``mmcv.ops.nms3d_normal``
+(ops/iou3d.py) -> ``iou_normal`` in ops/csrc/common/cuda/iou3d_cuda_kernel.cuh.  Its published algorithm:
+sort the boxes by descending score, then greedily keep a box and suppress every later box whose
+BEV IoU with it exceeds the threshold, where the IoU is that of the axis-aligned rectangles
+(x - dx/2 .. x + dx/2) x (y - dy/2 .. y + dy/2) -- z extent and heading are ignored -- computed as
+``inter / max(Sa + Sb - inter, 1e-8)``.  ``trim_bboxes_by_superpoints`` itself is in the reference but
+cannot be imported here (unidet3d.py imports spconv, MinkowskiEngine, torch_scatter, mmcv, mmdet3d at
+module level), and the reference has no tests or golden vectors for it; torch_scatter.scatter_mean
+(== sum / clamp(count, 1), torch-scatter 2.1.2) and mmdet3d.rotation_3d_in_axis with angle 0 (identity
+up to adding +-0) are restated from their documented behaviour.  The oracle is therefore anchored on the
+call sites above and on hand-computable cases in tests/test_postproc_cpu.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def softmax_scores(cls_preds: np.ndarray) -> np.ndarray:
+    """F.softmax(cls_preds, -1)[:, :-1]  (unidet3d.py:504)."""
+    x = cls_preds.astype(F32)
+    e = np.exp(x - x.max(axis=1, keepdims=True))
+    return (e / e.sum(axis=1, keepdims=True))[:, :-1].astype(F32)
+
+
+def topk_instances(scores: np.ndarray, topk: int):
+    """Flattened top-k over (query, class) with the class id as label (unidet3d.py:505-515).
+    Returns (scores, labels, query index), descending score (ties: lower flat index first)."""
+    n, c = scores.shape
+    flat = scores.reshape(-1)
+    order = np.argsort(-flat, kind='stable')[:min(topk, flat.size)]
+    return flat[order], (order % c).astype(np.int64), (order // c).astype(np.int64)
+
+
+def iou_normal(a: np.ndarray, b: np.ndarray) -> np.float32:
+    """mmcv iou_normal on (x, y, z, dx, dy, dz[, heading]) boxes, fp32."""
+    a = a.astype(F32); b = b.astype(F32)
+    two = F32(2)
+    left = max(a[0] - a[3] / two, b[0] - b[3] / two)
+    right = min(a[0] + a[3] / two, b[0] + b[3] / two)
+    top = max(a[1] - a[4] / two, b[1] - b[4] / two)
+    bottom = min(a[1] + a[4] / two, b[1] + b[4] / two)
+    width = max(F32(right - left), F32(0))
+    height = max(F32(bottom - top), F32(0))
+    inter = F32(width * height)
+    sa, sb = F32(a[3] * a[4]), F32(b[3] * b[4])
+    return F32(inter / max(F32(F32(sa + sb) - inter), F32(1e-8)))
+
+
+def nms3d_normal(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
+    """Indices kept by mmcv.ops.nms3d_normal, in descending-score order."""
+    order = np.argsort(-scores.astype(F32), kind='stable')
+    sup = np.zeros(len(order), bool)
+    keep = []
+    thr = F32(thr)
+    for ii, i in enumerate(order):
+        if sup[ii]:
+            continue
+        keep.append(i)
+        for jj in range(ii + 1, len(order)):
+            if not sup[jj] and iou_normal(boxes[i], boxes[order[jj]]) > thr:
+                sup[jj] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, iou_thr: float, score_thr: float):
+    """_single_scene_multiclass_nms, fast_nms branch, yaw-free boxes (unidet3d.py:611-650)."""
+    out_b, out_s, out_l = [], [], []
+    for c in np.unique(labels):
+        sel = labels == c
+        ids = scores[sel] > F32(score_thr)
+        if not ids.any():
+            continue
+        cs, cb, cl = scores[sel][ids], bboxes[sel][ids], labels[sel][ids]
+        k = nms3d_normal(cb, cs, iou_thr)
+        out_b.append(cb[k]); out_s.append(cs[k]); out_l.append(cl[k])
+    if not out_b:
+        return np.zeros((0, bboxes.shape[1]), F32), np.zeros((0,), F32), np.zeros((0,), np.int64)
+    return np.concatenate(out_b), np.concatenate(out_s), np.concatenate(out_l)
+
+
+def inside_boxes(points: np.ndarray, boxes: np.ndarray) -> np.ndarray:
+    """[n_boxes, n_points] bool: min face distance > 0 with yaw 0 (get_face_distances :652-677, :569)."""
+    p = points[:, None, :3].astype(F32)                  # [P,1,3]
+    c = boxes[None, :, :3].astype(F32)                   # [1,B,3]
+    h = (boxes[None, :, 3:6].astype(F32) / F32(2)).astype(F32)
+    shift = (p - c).astype(F32)                          # rotation by -0 is the identity
+    cen = (c + shift).astype(F32)
+    dmin = ((cen - c).astype(F32) + h).astype(F32)
+    dmax = ((c + h).astype(F32) - cen).astype(F32)
+    return (np.minimum(dmin, dmax).min(axis=-1) > 0).T
+
+
+def trim_boxes(points: np.ndarray, sp_pts_mask: np.ndarray, boxes: np.ndarray, low: float, up: float) -> np.ndarray:
+    """trim_bboxes_by_superpoints (unidet3d.py:560-590): returns [n_boxes, 6] (centre, size)."""
+    pts = points[:, :3].astype(F32)
+    inside = inside_boxes(pts, boxes)                    # [B,P]
+    S = int(sp_pts_mask.max()) + 1 if len(sp_pts_mask) else 0
+    cnt = np.bincount(sp_pts_mask, minlength=S).astype(F32)
+    sp_inside = np.stack([np.bincount(sp_pts_mask, weights=row, minlength=S) for row in inside.astype(np.float64)]) if len(boxes) else np.zeros((0, S))
+    sp_inside = (sp_inside.astype(F32) / np.maximum(cnt, F32(1))[None]).astype(F32)     # scatter_mean
+    sp_del = sp_inside < F32(low)
+    inside[sp_del[:, sp_pts_mask]] = False
+    sp_add = sp_inside > F32(up)
+    inside[sp_add[:, sp_pts_mask]] = True
+    out = np.zeros((len(boxes), 6), F32)
+    for b in range(len(boxes)):
+        sel = pts[inside[b]]
+        mx = sel.max(axis=0) if len(sel) else np.full(3, -np.inf, F32)
+        mn = sel.min(axis=0) if len(sel) else np.full(3, np.inf, F32)
+        with np.errstate(invalid='ignore'):
+            out[b, :3] = (mx + mn) / F32(2)
+            out[b, 3:] = mx - mn
+    return out
+
+
+def predict_by_feat(cls_preds, pred_bboxes, sp_pts_mask, points, test_cfg, iou_thr, use_superpoints=True):
+    """unidet3d.py:498-538 for one scene: (boxes [n,6], labels, scores)."""
+    scores = softmax_scores(cls_preds)
+    s, l, q = topk_instances(scores, test_cfg['topk_insts'])
+    b = pred_bboxes[q].astype(F32)
+    nb, ns, nl = multiclass_nms(b, s, l, iou_thr, test_cfg['score_thr'])
+    if use_superpoints:
+        nb = trim_boxes(points, sp_pts_mask, nb, test_cfg['low_sp_thr'], test_cfg['up_sp_thr'])
+    return nb, nl, ns

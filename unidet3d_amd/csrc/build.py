@@ -6,14 +6,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ['misc.hip', 'voxelize.hip', 'rulebook.hip', 'spconv.hip', 'bn.hip', 'pool.hip', 'attn.hip', 'gemm.hip']
+SOURCES = ['misc.hip', 'voxelize.hip', 'rulebook.hip', 'spconv.hip', 'bn.hip', 'pool.hip', 'attn.hip', 'gemm.hip', 'postproc.hip']
 LIB = os.path.join(HERE, 'libu3d_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-value',
          '-I', os.path.join(ROOT, 'include'), '-I', HERE]
 
 
 # per-file code generation options
-EXTRA = {'spconv.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}     # MFMA results are consumed by VALU/LDS right away
+EXTRA = {'spconv.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],     # MFMA results are consumed by VALU/LDS right away
+         'postproc.hip': ['-ffp-contract=off']}                     # bit-exact against the oracle's operation order
 
 
 def _hipcc():

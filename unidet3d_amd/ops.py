@@ -148,3 +148,42 @@ def instance_boxes(vb: VoxelBatch, instance_ids: torch.Tensor, n_inst_total: int
            n_inst_total, L.ptr(vb.stats), 12, L.ptr(vb.pt_offsets), vb.stats.shape[0], L.ptr(mm), L.ptr(ws), L.stream())
     lo, hi = mm[:, :3], mm[:, 3:]
     return torch.cat(((hi + lo) / 2, hi - lo), 1)
+
+
+# ----------------------------------------------------------------------------------------
+# inference post-processing
+# ----------------------------------------------------------------------------------------
+def nms_bev_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, iou_thr: float, score_thr: float):
+    """``UniDet3D._single_scene_multiclass_nms`` with fast_nms=True on yaw-free boxes (unidet3d/unidet3d.py:595-650):
+    class by class (ascending id), boxes above ``score_thr`` visited by descending score, greedy BEV-IoU suppression
+    (mmcv ``nms3d_normal``).  ``scores`` must already be sorted descending (they come from a sorted top-k).
+    Returns (bboxes, scores, labels) in the reference's output order."""
+    if bboxes.shape[1] != 6:
+        raise NotImplementedError('rotated boxes (mmcv nms3d) are not built')
+    sel = scores > score_thr
+    bboxes, scores, labels = bboxes[sel], scores[sel], labels[sel]
+    n = bboxes.shape[0]
+    if n == 0:
+        return bboxes.new_zeros((0, 6)), bboxes.new_zeros((0,)), labels.new_zeros((0,))
+    order = torch.sort(labels, stable=True).indices            # (label asc, score desc)
+    b = bboxes[order].contiguous().float()
+    lab = labels[order].to(torch.int32).contiguous()
+    keep = torch.empty(n, dtype=torch.uint8, device=b.device)
+    L.call('u3d_nms_bev', L.ptr(b), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+    k = order[keep.bool()]
+    return bboxes[k], scores[k], labels[k]
+
+
+def trim_boxes_by_superpoints(points: torch.Tensor, sp_offsets: torch.Tensor, sp_points: torch.Tensor, n_superpoints: int,
+                              bboxes: torch.Tensor, low_sp_thr: float, up_sp_thr: float) -> torch.Tensor:
+    """``UniDet3D.trim_bboxes_by_superpoints`` (unidet3d/unidet3d.py:540-593) for yaw-free boxes: [n,6] (centre, size) of the
+    points each box keeps after whole superpoints were deleted (< low) / added (> up).  ``(sp_offsets, sp_points)`` is the
+    CSR of point rows per superpoint (``csr_build`` / ``PoolPlan``)."""
+    nb = bboxes.shape[0]
+    mm = torch.empty(nb, 6, dtype=torch.float32, device=points.device)
+    if nb:
+        b = bboxes[:, :6].contiguous().float()
+        L.call('u3d_trim_boxes', L.ptr(points), points.stride(0), L.ptr(sp_points), L.ptr(sp_offsets), int(n_superpoints),
+               L.ptr(b), nb, float(low_sp_thr), float(up_sp_thr), L.ptr(mm), L.stream())
+    mn, mx = mm[:, :3], mm[:, 3:]
+    return torch.cat(((mx + mn) / 2, mx - mn), dim=1)

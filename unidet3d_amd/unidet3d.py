@@ -15,6 +15,7 @@ from __future__ import annotations
 from typing import List, Optional
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -204,9 +205,38 @@ class UniDet3D(nn.Module):
         feats = self.extract_feat(x, plan, vb.inverse, batch_offsets)
         return self.decoder(feats, sp_centers, names)
 
+    # ------------------------------------------------------------------ post-processing (unidet3d.py:475-538)
+    def predict_by_feat(self, out, plan, vb, n_sp0, dataset_name):
+        """Scene 0 of the batch, as in the reference (:498-502): softmax -> top-k over (query, class) -> class-wise NMS ->
+        superpoint trimming.  Returns [(DepthInstance3DBoxes, labels, scores)]."""
+        cls_preds, pred_bboxes = out['cls_preds'][0], out['bboxes'][0]
+        idx = self.decoder.datasets.index(dataset_name)
+        scores = F.softmax(cls_preds, dim=-1)[:, :-1]
+        num_classes = scores.shape[1]
+        scores, topk_idx = scores.flatten(0, 1).topk(min(self.test_cfg['topk_insts'], scores.numel()), sorted=True)
+        labels = topk_idx % num_classes
+        pred_bboxes = pred_bboxes[torch.div(topk_idx, num_classes, rounding_mode='floor')]
+        if not self.fast_nms[idx]:
+            raise NotImplementedError('aligned_3d_nms (fast_nms=False, unidet3d.py:634-636) is not built')
+        nms_bboxes, nms_scores, nms_labels = ops.nms_bev_multiclass(pred_bboxes, scores, labels, self.test_cfg['iou_thr'][idx],
+                                                                    self.test_cfg['score_thr'])
+        if self.use_superpoints[idx]:
+            nms_bboxes = ops.trim_boxes_by_superpoints(vb.points, plan.sp_offsets, plan.sp_points, n_sp0, nms_bboxes,
+                                                       self.test_cfg['low_sp_thr'], self.test_cfg['up_sp_thr'])
+        boxes = DepthInstance3DBoxes(nms_bboxes, with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5))
+        return [(boxes, nms_labels, nms_scores)]
+
     def predict(self, batch_inputs_dict, batch_data_samples, **kwargs):
-        raise NotImplementedError('predict_by_feat (top-k + NMS + superpoint trimming, unidet3d.py:475-650) is outside '
-                                  'the built hot path; use predict_raw() for logits / boxes')
+        """unidet3d.py:411-473 (the reference post-processes scene 0 only -- test batches hold one scene)."""
+        vb, plan, batch_offsets, sp_centers, names = self._front(batch_inputs_dict, batch_data_samples, False)
+        x = self._sparse_input(len(batch_data_samples))
+        feats = self.extract_feat(x, plan, vb.inverse, batch_offsets)
+        out = self.decoder(feats, sp_centers, names)
+        results = self.predict_by_feat(out, plan, vb, batch_offsets[1] - batch_offsets[0], names[0])
+        for ds, (bboxes, labels, scores) in zip(batch_data_samples, results):
+            ds.pred_instances_3d = InstanceData_(bboxes_3d=bboxes, scores_3d=scores, labels_3d=labels,
+                                                 points=batch_inputs_dict['points'][0])
+        return batch_data_samples
 
     def forward(self, inputs, data_samples=None, mode='loss', **kwargs):
         if mode == 'loss':

@@ -22,38 +22,48 @@ constexpr int GT = 128;        // macro tile (both dims)
 constexpr int GK = 16;         // K-step
 constexpr int GLD = GK + 4;    // padded LDS row of the NT tiles
 
+// TN = 128 or 64 output columns per workgroup: the decoder's GEMMs are tall and skinny (M ~ 16k, N = 256..1024), and
+// with 128x128 tiles N = 256 gives only 250 workgroups for 256 CUs (one wave per SIMD, nothing to hide the barrier
+// behind); 128x64 tiles double the workgroup count.  Global -> LDS staging uses raw buffer loads from a descriptor based
+// at the tile origin: the K offset of a step is the instruction's scalar offset, so the per-thread address is loop
+// invariant (no VALU in the K loop for addressing -- VALU time adds to MFMA time on this hardware), and rows past M / N
+// read as zeros through the descriptor's bounds check instead of a compare + select.  The epilogue stores through a
+// bounds-checked descriptor the same way (row offset scalar, column offset per lane, out-of-range lanes dropped).
+template <int TN>
 __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                                  float* __restrict__ C, int64_t M, int N, int K) {
+    constexpr int NB = TN / 64;                 // 32-column MFMA tiles per wave
     __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float Bs[2][TN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * GT;
-    const int n0 = blockIdx.y * GT;
+    const int n0 = blockIdx.y * TN;
+    const int rows_a = (int)min((int64_t)GT, M - m0), rows_b = min(TN, N - n0);
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + m0 * K, (int64_t)rows_a * K * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(W + (int64_t)n0 * K, (int64_t)rows_b * K * 4);
     // staging map: thread -> (row = tid>>2 (+64), float4 column = tid&3)
     const int srow = tid >> 2, sc4 = tid & 3;
-    float4 ra[2], rb[2];
+    const int vo = (srow * K + sc4 * 4) * 4, vstep = 64 * K * 4;
+    f32x4 ra[2], rb[NB];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t m = m0 + srow + 64 * j;
-            const int n = n0 + srow + 64 * j;
-            ra[j] = m < M ? *reinterpret_cast<const float4*>(A + m * K + kt * GK + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[j] = n < N ? *reinterpret_cast<const float4*>(W + (int64_t)n * K + kt * GK + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int j = 0; j < 2; ++j) ra[j] = bload128(rs_a, vo + j * vstep, kt * (GK * 4));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rb[j] = bload128(rs_b, vo + j * vstep, kt * (GK * 4));
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(&As[buf][(srow + 64 * j) * GLD + sc4 * 4]) = ra[j];
-            *reinterpret_cast<float4*>(&Bs[buf][(srow + 64 * j) * GLD + sc4 * 4]) = rb[j];
-        }
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&As[buf][(srow + 64 * j) * GLD + sc4 * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 64 * j) * GLD + sc4 * 4]) = rb[j];
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int nk = K / GK;
@@ -63,41 +73,43 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        float4 af[2][2], bf[2][2];
+        f32x4 af[2][2], bf[NB][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const float* ap = &As[buf][(wr * 64 + t * 32 + i32) * GLD + kh * 8];
-            const float* bp = &Bs[buf][(wc * 64 + t * 32 + i32) * GLD + kh * 8];
-            af[t][0] = *reinterpret_cast<const float4*>(ap);
-            af[t][1] = *reinterpret_cast<const float4*>(ap + 4);
-            bf[t][0] = *reinterpret_cast<const float4*>(bp);
-            bf[t][1] = *reinterpret_cast<const float4*>(bp + 4);
+            af[t][0] = *reinterpret_cast<const f32x4*>(ap);
+            af[t][1] = *reinterpret_cast<const f32x4*>(ap + 4);
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#define U3D_STEP(c)                                                   \
-    acc[0][0] = U3D_MFMA32(af[0][h].c, bf[0][h].c, acc[0][0]);        \
-    acc[0][1] = U3D_MFMA32(af[0][h].c, bf[1][h].c, acc[0][1]);        \
-    acc[1][0] = U3D_MFMA32(af[1][h].c, bf[0][h].c, acc[1][0]);        \
-    acc[1][1] = U3D_MFMA32(af[1][h].c, bf[1][h].c, acc[1][1]);
-            U3D_STEP(x) U3D_STEP(y) U3D_STEP(z) U3D_STEP(w)
-#undef U3D_STEP
+        for (int t = 0; t < NB; ++t) {
+            const float* bp = &Bs[buf][(wc * (TN / 2) + t * 32 + i32) * GLD + kh * 8];
+            bf[t][0] = *reinterpret_cast<const f32x4*>(bp);
+            bf[t][1] = *reinterpret_cast<const f32x4*>(bp + 4);
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[a][b] = U3D_MFMA32(af[a][h][c], bf[b][h][c], acc[a][b]);
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
     // D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(C + m0 * N, (int64_t)rows_a * N * 4);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wc * 64 + b * 32 + i32;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+    for (int b = 0; b < NB; ++b) {
+        const int n = n0 + wc * (TN / 2) + b * 32 + i32;
+        const float bv = (bias && n < N) ? bias[n] : 0.f;
+        const int vc = n < N ? (4 * kh * N + n) * 4 : 0x7fffffff;        // columns past N: dropped by the bounds check
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < M) C[m * N + n] = acc[a][b][r] + bv;
+                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv), rs_c, vc, row * N * 4, 0);
             }
     }
 }
@@ -232,7 +244,12 @@ int u3d_gemm_nt(const float* A, const float* W, const float* bias, float* C, int
     if (K % GK) { set_error("gemm_nt: K=%d must be a multiple of %d", K, GK); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
-    hipLaunchKernelGGL(gemm_nt_k, dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, GT)), dim3(256), 0, s, A, W, bias, C, M, N, K);
+    if ((int64_t)GT * K * 4 >= 0x7fffffffLL || (int64_t)GT * N * 4 >= 0x7fffffffLL) { set_error("gemm_nt: N=%d / K=%d too large for 32-bit tile offsets", N, K); return U3D_EUNSUPPORTED; }
+    // 128x64 tiles when 128x128 would leave the 256 CUs with fewer than two workgroups each
+    if (ceil_div(M, GT) * ceil_div(N, GT) < 512)
+        hipLaunchKernelGGL(gemm_nt_k<64>, dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, W, bias, C, M, N, K);
+    else
+        hipLaunchKernelGGL(gemm_nt_k<128>, dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, GT)), dim3(256), 0, s, A, W, bias, C, M, N, K);
     return check_launch("gemm_nt");
 }
 

@@ -26,7 +26,6 @@
 
 namespace u3d {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct GmmParams {
     const float* src;
@@ -52,18 +51,6 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 
 constexpr int GMM_CDS = 32;            // output columns per wave
 constexpr int GMM_ALD = 40;            // accumulator row stride (floats): 160 B keeps the 16-byte accesses of consecutive rows on distinct banks
-
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-
-__device__ __forceinline__ f32x4 bload128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ int bload32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);     // raw dword buffer, 2 GiB window
-}
 
 // ---- software-pipelined wave program ---------------------------------------------------------------------
 // A wave's work is a sequence of ITEMS (offset k, window of W = 16*NCH pairs of k's range in this row tile);

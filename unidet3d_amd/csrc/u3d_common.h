@@ -40,6 +40,23 @@ __device__ __forceinline__ int64_t xcd_swizzle(int64_t b, int64_t n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---- raw buffer loads (32-bit offsets from a scalar base: one VALU instruction or none per address) ------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ f32x4 bload128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ int bload32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+// raw dword buffer of `bytes` bytes (default: a 2 GiB window): loads past the end return 0, stores past the end are dropped
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64_t bytes = 0x7fffffff) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+}
+#endif
+
 // exclusive scan of n int32 values produced by a functor; out has n+1 entries (out[n] = total)
 int exclusive_scan_popc64(const uint64_t* words, int64_t n, int32_t* out, void* ws, hipStream_t s);
 int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hipStream_t s);

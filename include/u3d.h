@@ -231,7 +231,8 @@ int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, c
  * ===================================================================================== */
 int u3d_gemm_nt(const float* A /*[M,K]*/, const float* W /*[N,K]*/, const float* bias /*[N] or NULL*/, float* C /*[M,N]*/,
                 int64_t M, int N, int K /* % 16 == 0 */, double flops_hint, u3d_stream_t stream);
-int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[N,K] = A^T B*/, int64_t M, int N, int K,
+/* colsum_A (nullable, [N]): column sums of A -- the bias gradient of the Linear layer -- produced by the same pass */
+int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[N,K] = A^T B*/, float* colsum_A, int64_t M, int N, int K,
                 void* ws, double flops_hint, u3d_stream_t stream);
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K);
 int u3d_transpose(const float* in /*[R,C]*/, float* out /*[C,R]*/, int R, int C, u3d_stream_t stream);

@@ -16,7 +16,7 @@ for (N, K) in [(768, 256), (256, 256), (1024, 256), (256, 1024), (256, 32)]:
     dy = torch.randn(M, N, device=dev)
     t1 = bench(lambda: _gemm_nt(a, w, b)); t2 = bench(lambda: torch.nn.functional.linear(a, w, b))
     fl = 2.0 * M * N * K
-    dw = torch.empty(N, K, device=dev); ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, N, K), dev)
-    t3 = bench(lambda: L.call('u3d_gemm_tn', L.ptr(dy), L.ptr(a), L.ptr(dw), M, N, K, L.ptr(ws), 0.0, L.stream()))
+    dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev); ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, N, K), dev)
+    t3 = bench(lambda: L.call('u3d_gemm_tn', L.ptr(dy), L.ptr(a), L.ptr(dw), L.ptr(db), M, N, K, L.ptr(ws), 0.0, L.stream()))
     t4 = bench(lambda: dy.t() @ a)
     print(f'N={N:5d} K={K:5d}: nt own {t1*1e6:7.1f} us {fl/t1/1e12:6.1f} TF/s | torch {t2*1e6:7.1f} us {fl/t2/1e12:6.1f} TF/s || tn own {t3*1e6:7.1f} us {fl/t3/1e12:6.1f} | torch {t4*1e6:7.1f} us {fl/t4/1e12:6.1f}')

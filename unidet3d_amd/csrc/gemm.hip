@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv), rs_c, vc, row * N * 4, 0);
+                float v = acc[a][b][r] + bv;
+                asm volatile("" : "+v"(v));          // see gemm_tn_k: keeps the store builtin from mis-selecting the vector element
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, vc, row * N * 4, 0);
             }
     }
 }
@@ -118,31 +120,37 @@ constexpr int TLD = GT + 4;    // padded LDS row of the TN tiles ([16 rows][128 
 
 // partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k]
 __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
-                                                 int64_t M, int N, int K, int64_t rows_per_split) {
+                                                 float* __restrict__ colsum, int64_t M, int N, int K, int64_t rows_per_split) {
     __shared__ __attribute__((aligned(16))) float As[2][GK * TLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK * TLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
     const int n0 = blockIdx.x * GT, k0 = blockIdx.y * GT;
     const int64_t mlo = (int64_t)blockIdx.z * rows_per_split;
     const int64_t mhi = min(M, mlo + rows_per_split);
-    // staging map: thread -> (row = tid>>5 (+8), float4 column = tid&31)
+    const int rows = (int)max((int64_t)0, mhi - mlo);
+    // staging map: thread -> (row = tid>>5 (+8), float4 column = tid&31); buffer loads from descriptors based at this split's
+    // first row: the row block of a step is the scalar offset, rows past the split and columns past N / K read as zeros
     const int srow = tid >> 5, sc4 = tid & 31;
-    float4 ra[2], rb[2];
-    auto gload = [&](int64_t mb) {
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + mlo * N, (int64_t)rows * N * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + mlo * K, (int64_t)rows * K * 4);
+    const int va = n0 + sc4 * 4 < N ? (srow * N + n0 + sc4 * 4) * 4 : 0x7fffffff;
+    const int vb = k0 + sc4 * 4 < K ? (srow * K + k0 + sc4 * 4) * 4 : 0x7fffffff;
+    const bool ca = va != 0x7fffffff, cb = vb != 0x7fffffff;
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int t) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int64_t m = mb + srow + 8 * j;
-            const bool okm = m < mhi;
-            ra[j] = (okm && n0 + sc4 * 4 < N) ? *reinterpret_cast<const float4*>(A + m * N + n0 + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[j] = (okm && k0 + sc4 * 4 < K) ? *reinterpret_cast<const float4*>(B + m * K + k0 + sc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[j] = bload128(rs_a, ca ? va + j * 8 * N * 4 : va, t * (GK * N * 4));
+            rb[j] = bload128(rs_b, cb ? vb + j * 8 * K * 4 : vb, t * (GK * K * 4));
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(&As[buf][(srow + 8 * j) * TLD + sc4 * 4]) = ra[j];
-            *reinterpret_cast<float4*>(&Bs[buf][(srow + 8 * j) * TLD + sc4 * 4]) = rb[j];
+            *reinterpret_cast<f32x4*>(&As[buf][(srow + 8 * j) * TLD + sc4 * 4]) = ra[j];
+            *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 8 * j) * TLD + sc4 * 4]) = rb[j];
         }
     };
     f32x16 acc[2][2];
@@ -152,15 +160,17 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int nt = (int)((mhi - mlo + GK - 1) / GK);
+    const int nt = (rows + GK - 1) / GK;
+    const bool sums = colsum && blockIdx.y == 0 && tid < GT;       // column sums of A (the bias gradient) ride along
+    float csum = 0.f;
     if (nt > 0) {
-        gload(mlo);
+        gload(0);
         lstore(0);
     }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) gload(mlo + (int64_t)(t + 1) * GK);
+        if (t + 1 < nt) gload(t + 1);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int m = kh * 8 + s;                       // reduction index of this lane at step s
@@ -171,22 +181,40 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
             acc[1][0] = U3D_MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = U3D_MFMA32(a1, b1, acc[1][1]);
         }
+        if (sums) {
+#pragma unroll
+            for (int m = 0; m < GK; ++m) csum += As[buf][m * TLD + tid];
+        }
         if (t + 1 < nt) lstore(buf ^ 1);
         __syncthreads();
     }
-    float* out = partial + (int64_t)blockIdx.z * N * K;
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)blockIdx.z * N * K, (int64_t)N * K * 4);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int k = k0 + wc * 64 + b * 32 + i32;
-        if (k >= K) continue;
+        const int vo = k < K ? ((n0 + 4 * kh) * K + k) * 4 : 0x7fffffff;        // rows past N fall off the end of the descriptor
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (n < N) out[(int64_t)n * K + k] = acc[a][b][r];
+                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                // the element goes through an opaque VGPR copy: handed a vector element directly, this compiler's buffer-store
+                // builtin stores element 0 of the accumulator sixteen times (seen in the ISA, caught by the parity test)
+                float v = acc[a][b][r];
+                asm volatile("" : "+v"(v));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, row * K * 4, 0);
             }
     }
+    if (sums && n0 + tid < N) colsum[(int64_t)blockIdx.z * N + n0 + tid] = csum;
+}
+
+// column sums: out[n] = sum_s partial[s][n], fixed order
+__global__ void colsum_reduce_k(const float* __restrict__ partial, int S, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += partial[(int64_t)s * N + n];
+    out[n] = v;
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict__ partial, int S, int64_t n4, float* __restrict__ C) {
@@ -253,9 +281,9 @@ int u3d_gemm_nt(const float* A, const float* W, const float* bias, float* C, int
     return check_launch("gemm_nt");
 }
 
-int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K) * N * K * 4 + 256; }
+int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K) * ((int64_t)N * K + N) * 4 + 256; }
 
-int u3d_gemm_tn(const float* A, const float* B, float* C, int64_t M, int N, int K, void* ws, double flops_hint,
+int u3d_gemm_tn(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
                 u3d_stream_t stream) {
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return U3D_EINVAL;
     if (N % 4 || K % 4) { set_error("gemm_tn: N=%d, K=%d must be multiples of 4", N, K); return U3D_EUNSUPPORTED; }
@@ -263,7 +291,13 @@ int u3d_gemm_tn(const float* A, const float* B, float* C, int64_t M, int N, int 
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
     const int S = tn_splits(M, N, K);
     const int64_t rps = ceil_div(ceil_div(M, S), GK) * GK;
-    hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, M, N, K, rps);
+    if ((int64_t)(rps + GK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + GK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
+        set_error("gemm_tn: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
+        return U3D_EUNSUPPORTED;
+    }
+    float* cs_part = colsum_A ? (float*)ws + (int64_t)S * N * K : nullptr;
+    hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, cs_part, M, N, K, rps);
+    if (colsum_A) hipLaunchKernelGGL(colsum_reduce_k, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float*)cs_part, S, N, colsum_A);
     const int64_t n4 = (int64_t)N * K / 4;
     int64_t grid = ceil_div(n4, 256);
     grid = grid > 1024 ? 1024 : grid;

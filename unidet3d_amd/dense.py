@@ -55,7 +55,9 @@ class _LinearFn(torch.autograd.Function):
             dw = torch.empty(N, K, dtype=torch.float32, device=weight.device)
             if M and N % 4 == 0:
                 ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, N, K), weight.device)
-                L.call('u3d_gemm_tn', L.ptr(dy), L.ptr(x), L.ptr(dw), M, N, K, L.ptr(ws),
+                if ctx.has_bias and ctx.needs_input_grad[2]:      # the bias gradient (column sums of dy) rides along
+                    db = torch.empty(N, dtype=torch.float32, device=weight.device)
+                L.call('u3d_gemm_tn', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), M, N, K, L.ptr(ws),
                        2.0 * M * N * K if _PROFILE_FLOPS else 0.0, L.stream())
             elif M:
                 Np = (N + 3) // 4 * 4
@@ -63,11 +65,11 @@ class _LinearFn(torch.autograd.Function):
                 dyp[:, :N] = dy
                 dwp = torch.empty(Np, K, dtype=torch.float32, device=weight.device)
                 ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, Np, K), weight.device)
-                L.call('u3d_gemm_tn', L.ptr(dyp), L.ptr(x), L.ptr(dwp), M, Np, K, L.ptr(ws), 0.0, L.stream())
+                L.call('u3d_gemm_tn', L.ptr(dyp), L.ptr(x), L.ptr(dwp), None, M, Np, K, L.ptr(ws), 0.0, L.stream())
                 dw = dwp[:N].contiguous()
             else:
                 dw.zero_()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db
 

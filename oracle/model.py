@@ -287,9 +287,9 @@ class ODetector(nn.Module):
         self.output_layer = OSeq(nn.BatchNorm1d(num_channels, eps=1e-4, momentum=0.1), nn.ReLU())
         self.decoder = OEncoder(**{k: v for k, v in decoder.items() if k != 'type'})
 
-    def extract_feat(self, points: List[torch.Tensor], superpoints: List[torch.Tensor]):
-        """collate + SparseConvTensor + extract_feat (unidet3d.py:349-357)."""
-        coords, feats, inverse, shape = so.voxelize(points, self.voxel_size, self.min_spatial_shape)
+    def extract_feat(self, points: List[torch.Tensor], superpoints: List[torch.Tensor], elastic_coords=None):
+        """collate + SparseConvTensor + extract_feat (unidet3d.py:349-357); elastic_coords as in :351."""
+        coords, feats, inverse, shape = so.voxelize(points, self.voxel_size, self.min_spatial_shape, elastic_coords)
         x = OSparse(feats, coords, shape, len(points))
         x = self.input_conv(x)
         x, _ = self.unet(x)
@@ -302,5 +302,12 @@ class ODetector(nn.Module):
         pooled = so.scatter_mean(x.features[inverse], torch.cat(sp), dim_size=bias)
         return [pooled[offs[i]:offs[i + 1]] for i in range(len(points))], x
 
-    def sp_centers(self, points, superpoints):   # unidet3d.py:301-302,332-333
-        return [so.scatter_mean(p[:, :3] - p[:, :3].min(0)[0], s) for p, s in zip(points, superpoints)]
+    def train_points(self, points, elastic_coords=None):          # unidet3d.py:295-302
+        """The frame the training targets live in: (elastic - min) * voxel_size when elastic coordinates are given
+        (the reference's train pipeline always provides them), else xyz - min."""
+        if elastic_coords is not None:
+            return [(e - e.min(0)[0]) * self.voxel_size for e in elastic_coords]
+        return [p[:, :3] - p[:, :3].min(0)[0] for p in points]
+
+    def sp_centers(self, points, superpoints, elastic_coords=None):   # unidet3d.py:332-333
+        return [so.scatter_mean(p, s) for p, s in zip(self.train_points(points, elastic_coords), superpoints)]

@@ -196,3 +196,37 @@ def test_dense_linear_fwd_bwd(M, K, N):
     yg = linear(xg, wg, bg); yg.backward(go.to(DEV))
     assert _rel(yg, yo) < 1e-5 and _rel(xg.grad, xo.grad) < 1e-5
     assert _rel(wg.grad, wo.grad) < 2e-5 and _rel(bg.grad, bo.grad) < 1e-5
+
+
+# ---------------------------------------------------------------------------- elastic training frame (unidet3d.py:295-299)
+def test_loss_with_elastic_coords_matches_oracle():
+    """The reference's train pipeline always supplies ``elastic_coords`` (ElasticTransfrom sets the key with or without
+    distortion): voxelisation runs on them and the superpoint centres / GT boxes live in (elastic - min) * voxel_size."""
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    prod, orac, cfg = _build_pair(num_layers=2)
+    vs = 0.05
+    prod.voxel_size = orac.voxel_size = vs
+    scenes = [make_scene(70 + i, n_points=12_000) for i in range(2)]
+    pts = [torch.from_numpy(s.points) for s in scenes]
+    sps = [torch.from_numpy(s.superpoints) for s in scenes]
+    # a smooth distortion in voxel units on top of xyz / voxel_size, like ElasticTransfrom's output
+    els = []
+    for p in pts:
+        c = p[:, :3] / vs
+        els.append((c + 1.7 * torch.sin(c[:, [1, 2, 0]] * 0.11) + 0.9 * torch.cos(c[:, [2, 0, 1]] * 0.07)).float().contiguous())
+    orac.train(); prod.train()
+    ofeats, ox = orac.extract_feat(pts, sps, els)
+    ocent = orac.sp_centers(pts, sps, els)
+    oout = orac.decoder(ofeats, ocent, ['scannet'] * 2)
+    tp = orac.train_points(pts, els)
+    insts = [oc.gt_from_scene(t, torch.from_numpy(s.instance_mask), torch.from_numpy(s.labels), sp) for t, s, sp in zip(tp, scenes, sps)]
+    oloss = oc.criterion(oout, insts)
+    inputs, samples = make_batch_inputs(scenes, DEV)
+    inputs['elastic_coords'] = [e.to(DEV) for e in els]
+    loss = prod.loss(inputs, samples)['det_loss']
+    assert torch.equal(prod._vb.coords.cpu(), ox.indices)                       # voxelised on the elastic coordinates, bit-exact
+    for i, ds in enumerate(samples):
+        assert _rel(ds.gt_instances_3d.sp_centers, ocent[i]) < 1e-5
+        assert _rel(ds.gt_instances_3d.bboxes_3d.gravity_center, insts[i].bboxes_3d.gravity_center) < 1e-6
+    assert abs(loss.item() - oloss.item()) < 1e-3 * abs(oloss.item()), (loss.item(), oloss.item())

@@ -29,6 +29,7 @@ class VoxelBatch:
     pt_offsets: torch.Tensor      # int64 [B+1] (device)
     stats: torch.Tensor           # f32 [B, 12] min, max, mean_xyz, pad
     points: torch.Tensor          # f32 [Np, 6] concatenated
+    coord_src: Optional[torch.Tensor] = None      # f32 [Np, 3] elastic coordinates (voxel units) when the batch has them
 
 
 def voxelize(points: List[torch.Tensor], voxel_size: float, min_spatial_shape: int,
@@ -68,7 +69,7 @@ def voxelize(points: List[torch.Tensor], voxel_size: float, min_spatial_shape: i
     L.call('u3d_vox_finalize', L.ptr(pts), L.ptr(offs), B, n_pts, L.ptr(stats), L.ptr(pt_cell), L.ptr(index.bitmap),
            L.ptr(index.rank), n_vox, L.ptr(inverse), L.ptr(vox_offsets), L.ptr(vox_points), L.ptr(feats), 6,
            L.ptr(w2), L.stream())
-    return VoxelBatch(coords, feats, inverse, shape, index, vox_offsets, vox_points, offs, stats, pts)
+    return VoxelBatch(coords, feats, inverse, shape, index, vox_offsets, vox_points, offs, stats, pts, csrc)
 
 
 def csr_build(seg_ids: torch.Tensor, S: int):
@@ -137,15 +138,20 @@ def superpoint_centers(points: torch.Tensor, sp_offsets: torch.Tensor, sp_points
     return out
 
 
-def instance_boxes(vb: VoxelBatch, instance_ids: torch.Tensor, n_inst_total: int) -> torch.Tensor:
+def instance_boxes(vb: VoxelBatch, instance_ids: torch.Tensor, n_inst_total: int, voxel_size: Optional[float] = None) -> torch.Tensor:
     """[n_inst_total, 6] = (centre xyz, size xyz) of the axis-aligned box around each instance's points in the
-    scene-shifted frame (xyz - scene min); ``instance_ids`` int64 [Np] are batch-global (-1 = no instance).
-    One pass over the batch instead of the reference's per-instance boolean masks (unidet3d.py:220-256)."""
+    scene-shifted frame; ``instance_ids`` int64 [Np] are batch-global (-1 = no instance).  The frame is
+    ``xyz - scene min`` (unidet3d.py:300-301) or, when the batch carries elastic coordinates,
+    ``(elastic - scene min) * voxel_size`` (:296-297; scaling by a positive constant commutes with min / max, so it is
+    applied to the result).  One pass over the batch instead of the reference's per-instance boolean masks (:220-256)."""
     dev = vb.points.device
+    src = vb.points if vb.coord_src is None else vb.coord_src
     mm = torch.empty(n_inst_total, 6, dtype=torch.float32, device=dev)
     ws = L.scratch(n_inst_total * 24 + 64, dev)
-    L.call('u3d_segment_minmax_xyz', L.ptr(vb.points), vb.points.stride(0), L.ptr(instance_ids.contiguous()), vb.points.shape[0],
+    L.call('u3d_segment_minmax_xyz', L.ptr(src), src.stride(0), L.ptr(instance_ids.contiguous()), src.shape[0],
            n_inst_total, L.ptr(vb.stats), 12, L.ptr(vb.pt_offsets), vb.stats.shape[0], L.ptr(mm), L.ptr(ws), L.stream())
+    if vb.coord_src is not None:
+        mm = mm * float(voxel_size)
     lo, hi = mm[:, :3], mm[:, 3:]
     return torch.cat(((hi + lo) / 2, hi - lo), 1)
 

@@ -149,9 +149,13 @@ class UniDet3D(nn.Module):
             sp_list.append(sp)
         plan = ops.PoolPlan(vb, torch.cat(sp_list) if B > 1 else sp_list[0], bias)
         if elastic is not None and training:
-            raise NotImplementedError('superpoint centres on elastic coordinates (unidet3d.py:295-299) are not built')
-        centers = ops.superpoint_centers(vb.points, plan.sp_offsets, plan.sp_points, bias,
-                                         vb.stats if training else None, vb.pt_offsets if training else None)
+            # unidet3d.py:295-299: the training frame is (elastic - scene min) * voxel_size (ElasticTransfrom always provides
+            # elastic_coords in the reference's train pipeline); the mean commutes with the scaling up to rounding
+            centers = ops.superpoint_centers(vb.coord_src, plan.sp_offsets, plan.sp_points, bias, vb.stats, vb.pt_offsets)
+            centers = centers * self.voxel_size
+        else:
+            centers = ops.superpoint_centers(vb.points, plan.sp_offsets, plan.sp_points, bias,
+                                             vb.stats if training else None, vb.pt_offsets if training else None)
         sp_centers = [centers[batch_offsets[i]:batch_offsets[i + 1]] for i in range(B)]
         names = [self.get_dataset(ds.lidar_path) for ds in batch_data_samples]
         return vb, plan, batch_offsets, sp_centers, names
@@ -171,7 +175,7 @@ class UniDet3D(nn.Module):
                 ids.append(torch.where(m >= 0, m + box_off[-1], m))
                 box_off.append(box_off[-1] + len(ds.gt_instances_3d.labels_3d))
             if box_off[-1] > 0:
-                boxes_all = ops.instance_boxes(vb, torch.cat(ids) if B > 1 else ids[0], box_off[-1])
+                boxes_all = ops.instance_boxes(vb, torch.cat(ids) if B > 1 else ids[0], box_off[-1], self.voxel_size)
         for i, ds in enumerate(batch_data_samples):
             inst = ds.gt_instances_3d
             dataset = dsets[i]
@@ -179,13 +183,15 @@ class UniDet3D(nn.Module):
                 inst.bboxes_3d = DepthInstance3DBoxes(boxes_all[box_off[i]:box_off[i + 1]], with_yaw=False, box_dim=6,
                                                       origin=(0.5, 0.5, 0.5))
             elif self.bbox_by_mask[dataset]:
-                pts = batch_inputs_dict['points'][i][:, :3]
-                pts = pts - vb.stats[i, :3]
+                if vb.coord_src is not None:
+                    pts = (batch_inputs_dict['elastic_coords'][i] - vb.stats[i, :3]) * self.voxel_size
+                else:
+                    pts = batch_inputs_dict['points'][i][:, :3] - vb.stats[i, :3]
                 ids = ds.gt_pts_seg.pts_instance_mask.to(pts.device)
                 inst.bboxes_3d = self.get_bboxes_by_masks(ids, len(inst.labels_3d), pts)
             else:
                 b = inst.bboxes_3d
-                center = b.gravity_center - vb.stats[i, :3]
+                center = b.gravity_center - (vb.stats[i, :3] * self.voxel_size if vb.coord_src is not None else vb.stats[i, :3])
                 inst.bboxes_3d = DepthInstance3DBoxes(torch.cat((center, b.tensor[:, 3:]), dim=1), with_yaw=b.with_yaw,
                                                       box_dim=b.tensor.shape[1], origin=(0.5, 0.5, 0.5))
             inst.sp_centers = sp_centers[i]

@@ -137,7 +137,7 @@ class UniDet3D(nn.Module):
     # ------------------------------------------------------------------ shared front end
     def _front(self, batch_inputs_dict, batch_data_samples, training: bool):
         points = batch_inputs_dict['points']
-        elastic = batch_inputs_dict.get('elastic_coords', None)
+        elastic = batch_inputs_dict.get('elastic_coords', None) if training else None     # predict() collates xyz only (:454-455)
         B = len(points)
         self.collate(points, elastic)
         vb = self._vb

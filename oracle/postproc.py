@@ -5,7 +5,7 @@ Only ``tests/`` and ``__graft_entry__.smoke()`` may import this module; nothing 
 
 What is restated, all in numpy float32 with the reference's operation order:
   * ``predict_by_feat``               unidet3d/unidet3d.py:475-538  (softmax, top-k, labels)
-  * ``_single_scene_multiclass_nms``  unidet3d/unidet3d.py:595-650  (fast_nms=True branch)
+  * ``_single_scene_multiclass_nms``  unidet3d/unidet3d.py:595-650  (fast_nms=True: mmcv nms3d_normal; False: mmdet3d aligned_3d_nms)
   * ``trim_bboxes_by_superpoints``    unidet3d/unidet3d.py:540-593
   * ``get_face_distances``            unidet3d/unidet3d.py:652-677  (yaw = 0)
 
@@ -76,8 +76,43 @@ def nms3d_normal(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarra
     return np.asarray(keep, dtype=np.int64)
 
 
-def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, iou_thr: float, score_thr: float):
-    """_single_scene_multiclass_nms, fast_nms branch, yaw-free boxes (unidet3d.py:611-650)."""
+def bbox_to_loss(b: np.ndarray) -> np.ndarray:
+    """criterion.py:180-198: (centre, size) -> corners."""
+    half = (b[:, 3:6].astype(F32) / F32(2)).astype(F32)
+    return np.concatenate([b[:, :3].astype(F32) - half, b[:, :3].astype(F32) + half], 1).astype(F32)
+
+
+def aligned_3d_nms(corners: np.ndarray, scores: np.ndarray, classes: np.ndarray, thr: float) -> np.ndarray:
+    """mmdet3d 1.4.0 models/layers/box3d_nms.py aligned_3d_nms, restated: visit by descending score; a remaining box
+    survives a kept box only if ``iou * (same class) <= thr`` with the 3-D IoU ``inter / (vol_i + vol_j - inter)`` (no
+    epsilon: 0/0 is NaN and NaN <= thr is False, so degenerate duplicates are dropped)."""
+    c = corners.astype(F32)
+    vol = ((c[:, 3] - c[:, 0]) * (c[:, 4] - c[:, 1])).astype(F32) * (c[:, 5] - c[:, 2])
+    vol = vol.astype(F32)
+    order = list(np.argsort(-scores.astype(F32), kind='stable'))
+    pick = []
+    thr = F32(thr)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        while order:
+            i = order[0]
+            pick.append(i)
+            rest = order[1:]
+            keep = []
+            for j in rest:
+                w = max(F32(min(c[i, 3], c[j, 3]) - max(c[i, 0], c[j, 0])), F32(0))
+                h = max(F32(min(c[i, 4], c[j, 4]) - max(c[i, 1], c[j, 1])), F32(0))
+                d = max(F32(min(c[i, 5], c[j, 5]) - max(c[i, 2], c[j, 2])), F32(0))
+                inter = F32(F32(w * h) * d)
+                iou = F32(inter / F32(F32(vol[i] + vol[j]) - inter))
+                iou = F32(iou * F32(classes[i] == classes[j]))
+                if iou <= thr:
+                    keep.append(j)
+            order = keep
+    return np.asarray(pick, dtype=np.int64)
+
+
+def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, iou_thr: float, score_thr: float, fast_nms: bool = True):
+    """_single_scene_multiclass_nms on yaw-free boxes (unidet3d.py:611-650), both fast_nms branches."""
     out_b, out_s, out_l = [], [], []
     for c in np.unique(labels):
         sel = labels == c
@@ -85,7 +120,7 @@ def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, i
         if not ids.any():
             continue
         cs, cb, cl = scores[sel][ids], bboxes[sel][ids], labels[sel][ids]
-        k = nms3d_normal(cb, cs, iou_thr)
+        k = nms3d_normal(cb, cs, iou_thr) if fast_nms else aligned_3d_nms(bbox_to_loss(cb), cs, cl, iou_thr)
         out_b.append(cb[k]); out_s.append(cs[k]); out_l.append(cl[k])
     if not out_b:
         return np.zeros((0, bboxes.shape[1]), F32), np.zeros((0,), F32), np.zeros((0,), np.int64)

@@ -17,9 +17,10 @@ def _boxes(rng, n, spread=4.0):
     return np.concatenate([c, d], 1).astype(F32)
 
 
+@pytest.mark.parametrize('fast', [True, False])
 @pytest.mark.parametrize('n,n_cls,thr,score_thr', [(0, 3, 0.5, 0.0), (1, 1, 0.5, 0.0), (300, 5, 0.5, 0.0), (1000, 18, 0.5, 0.0),
                                                    (1000, 18, 0.25, 0.3), (1500, 2, 0.7, 0.0), (64, 1, 0.0, 0.0), (200, 4, 0.5, 2.0)])
-def test_multiclass_nms_matches_oracle(n, n_cls, thr, score_thr):
+def test_multiclass_nms_matches_oracle(n, n_cls, thr, score_thr, fast):
     from unidet3d_amd import ops
     rng = np.random.default_rng(n * 31 + n_cls)
     boxes = _boxes(rng, n)
@@ -28,16 +29,16 @@ def test_multiclass_nms_matches_oracle(n, n_cls, thr, score_thr):
         boxes[7, 3:5] = 0
     scores = np.sort(rng.uniform(0.01, 1.0, n).astype(F32))[::-1].copy()
     labels = rng.integers(0, n_cls, n)
-    ob, os_, ol = pp.multiclass_nms(boxes, scores, labels, thr, score_thr)
-    gb, gs, gl = ops.nms_bev_multiclass(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV),
-                                        torch.from_numpy(labels).to(DEV), thr, score_thr)
+    ob, os_, ol = pp.multiclass_nms(boxes, scores, labels, thr, score_thr, fast)
+    gb, gs, gl = ops.nms_multiclass(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV),
+                                    torch.from_numpy(labels).to(DEV), thr, score_thr, fast)
     assert gl.cpu().numpy().tolist() == ol.tolist()
     assert np.array_equal(gs.cpu().numpy(), os_) and np.array_equal(gb.cpu().numpy(), ob)
 
 
 def test_nms_rejects_too_many_boxes_and_rotated():
     from unidet3d_amd import _lib as L, ops
-    b = torch.zeros(5000, 6, device=DEV); s = torch.linspace(1, 0.1, 5000, device=DEV); l = torch.zeros(5000, dtype=torch.long, device=DEV)
+    b = torch.zeros(3000, 6, device=DEV); s = torch.linspace(1, 0.1, 3000, device=DEV); l = torch.zeros(3000, dtype=torch.long, device=DEV)
     with pytest.raises(L.U3DError):
         ops.nms_bev_multiclass(b, s, l, 0.5, 0.0)
     with pytest.raises(NotImplementedError):

@@ -73,3 +73,17 @@ def test_topk_instances_labels():
     sc = np.array([[0.1, 0.7], [0.6, 0.2], [0.3, 0.9]], F32)
     s, l, q = pp.topk_instances(sc, 4)
     assert s.tolist() == [F32(0.9), F32(0.7), F32(0.6), F32(0.3)] and l.tolist() == [1, 1, 0, 0] and q.tolist() == [2, 0, 1, 2]
+
+
+def test_aligned_3d_nms_uses_volume_iou_and_drops_degenerate_duplicates():
+    a = pp.bbox_to_loss(np.stack([_box(0, 0, 0, 1, 1, 1), _box(0.5, 0, 0, 1, 1, 1), _box(0, 0, 0.9, 1, 1, 1), _box(3, 3, 3, 0, 0, 0), _box(3, 3, 3, 0, 0, 0)]))
+    scores = np.array([0.9, 0.8, 0.7, 0.6, 0.5], F32)
+    cls = np.zeros(5, np.int64)
+    # box 1: IoU 0.5/1.5 = 0.33 with box 0; box 2 overlaps box 0 only by 0.1 in z (IoU 0.1/1.9); boxes 3/4 have zero volume:
+    # 3 survives (0/vol = 0 against the others), 4 meets 3 with 0/0 = NaN -> dropped
+    assert pp.aligned_3d_nms(a, scores, cls, 0.25).tolist() == [0, 2, 3]
+    assert pp.aligned_3d_nms(a, scores, cls, 0.5).tolist() == [0, 1, 2, 3]
+    b, s, l = pp.multiclass_nms(np.stack([_box(0, 0, 0, 1, 1, 1), _box(0, 0, 0.8, 1, 1, 1)]), np.array([0.9, 0.8], F32), np.array([2, 2]), 0.5, 0.0, fast_nms=False)
+    assert len(l) == 2                      # BEV NMS would have merged them (identical footprint), the 3-D IoU is 0.2/1.8
+    b, s, l = pp.multiclass_nms(np.stack([_box(0, 0, 0, 1, 1, 1), _box(0, 0, 0.8, 1, 1, 1)]), np.array([0.9, 0.8], F32), np.array([2, 2]), 0.5, 0.0, fast_nms=True)
+    assert len(l) == 1

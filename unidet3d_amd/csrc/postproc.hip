@@ -1,7 +1,8 @@
 // K-post: inference post-processing of one scene on the device:
-//   * class-wise greedy BEV NMS of axis-aligned boxes -- unidet3d/unidet3d.py:595-650 with fast_nms=True, i.e.
+//   * class-wise greedy NMS of axis-aligned boxes -- unidet3d/unidet3d.py:595-650: fast_nms=True is
 //     mmcv.ops.nms3d_normal (mmcv @780ffed, ops/csrc/common/cuda/iou3d_cuda_kernel.cuh `iou_normal`: IoU of the
-//     (x, y, dx, dy) rectangles, z and heading ignored), visited in descending score order inside a class;
+//     (x, y, dx, dy) rectangles, z and heading ignored), fast_nms=False is mmdet3d 1.4.0 aligned_3d_nms (3-D IoU of
+//     the corner boxes); both visit a class in descending score order;
 //   * superpoint trimming of the surviving boxes -- unidet3d/unidet3d.py:540-593 + get_face_distances :652-677:
 //     point-in-box test, per-superpoint inside ratio, delete (< low) / add (> up) whole superpoints, min/max of
 //     the selected points.
@@ -13,17 +14,27 @@
 
 namespace u3d {
 
-constexpr int NMS_MAX = 4096;
+constexpr int NMS_MAX = 2048;          // 9 LDS words per box: 72 KB would pass the 64 KB default limit of a launch beyond this
 
-__global__ __launch_bounds__(1024) void nms_bev_k(const float* __restrict__ boxes, const int32_t* __restrict__ labels, int n, float thr,
-                                                  uint8_t* __restrict__ keep) {
+// MODE 0: BEV IoU of (cx, cy, cz, dx, dy, dz) boxes, suppress when iou > thr           (mmcv nms3d_normal / iou_normal)
+// MODE 1: 3-D IoU of (x1, y1, z1, x2, y2, z2) boxes, survive only when iou <= thr       (mmdet3d aligned_3d_nms: a 0/0 IoU
+//         of two zero-volume boxes is NaN there and NaN <= thr is false, so such a box is dropped)
+template <int MODE>
+__global__ __launch_bounds__(1024) void nms_k(const float* __restrict__ boxes, const int32_t* __restrict__ labels, int n, float thr,
+                                              uint8_t* __restrict__ keep) {
     extern __shared__ float sm[];
-    float* xl = sm; float* xr = xl + n; float* yt = xr + n; float* yb = yt + n; float* ar = yb + n;
+    float* x1 = sm; float* x2 = x1 + n; float* y1 = x2 + n; float* y2 = y1 + n; float* z1 = y2 + n; float* z2 = z1 + n; float* ar = z2 + n;
     int* lab = reinterpret_cast<int*>(ar + n);
     int* sup = lab + n;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float x = boxes[i * 6 + 0], y = boxes[i * 6 + 1], dx = boxes[i * 6 + 3], dy = boxes[i * 6 + 4];
-        xl[i] = x - dx / 2; xr[i] = x + dx / 2; yt[i] = y - dy / 2; yb[i] = y + dy / 2; ar[i] = dx * dy;
+        const float* b = boxes + i * 6;
+        if (MODE == 0) {
+            x1[i] = b[0] - b[3] / 2; x2[i] = b[0] + b[3] / 2; y1[i] = b[1] - b[4] / 2; y2[i] = b[1] + b[4] / 2; z1[i] = 0.f; z2[i] = 0.f;
+            ar[i] = b[3] * b[4];
+        } else {
+            x1[i] = b[0]; y1[i] = b[1]; z1[i] = b[2]; x2[i] = b[3]; y2[i] = b[4]; z2[i] = b[5];
+            ar[i] = (b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]);
+        }
         lab[i] = labels[i]; sup[i] = 0;
         keep[i] = 0;
     }
@@ -32,16 +43,21 @@ __global__ __launch_bounds__(1024) void nms_bev_k(const float* __restrict__ boxe
         if (sup[i]) continue;                     // same LDS word for every thread: uniform
         if (threadIdx.x == 0) keep[i] = 1;
         const int li = lab[i];
-        const float axl = xl[i], axr = xr[i], ayt = yt[i], ayb = yb[i], sa = ar[i];
+        const float ax1 = x1[i], ax2 = x2[i], ay1 = y1[i], ay2 = y2[i], az1 = z1[i], az2 = z2[i], sa = ar[i];
         for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
             if (lab[j] != li) break;              // labels ascending: the class segment ended
             if (sup[j]) continue;
-            const float left = fmaxf(axl, xl[j]), right = fminf(axr, xr[j]);
-            const float top = fmaxf(ayt, yt[j]), bottom = fminf(ayb, yb[j]);
-            const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
-            const float inter = width * height;
-            const float iou = inter / fmaxf(sa + ar[j] - inter, 1e-8f);
-            if (iou > thr) sup[j] = 1;
+            const float w = fmaxf(fminf(ax2, x2[j]) - fmaxf(ax1, x1[j]), 0.f), h = fmaxf(fminf(ay2, y2[j]) - fmaxf(ay1, y1[j]), 0.f);
+            if (MODE == 0) {
+                const float inter = w * h;
+                const float iou = inter / fmaxf(sa + ar[j] - inter, 1e-8f);
+                if (iou > thr) sup[j] = 1;
+            } else {
+                const float d = fmaxf(fminf(az2, z2[j]) - fmaxf(az1, z1[j]), 0.f);
+                const float inter = w * h * d;
+                const float iou = inter / (sa + ar[j] - inter);
+                if (!(iou <= thr)) sup[j] = 1;
+            }
         }
     }
 }
@@ -105,15 +121,25 @@ using namespace u3d;
 
 extern "C" {
 
-int u3d_nms_bev(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
+static int launch_nms(int mode, const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
     if (n < 0 || (n > 0 && (!boxes || !labels || !keep))) return U3D_EINVAL;
     if (n == 0) return U3D_OK;
     if (n > NMS_MAX) {
-        set_error("nms_bev: %d boxes exceed the single-workgroup limit of %d", n, NMS_MAX);
+        set_error("nms: %d boxes exceed the single-workgroup limit of %d", n, NMS_MAX);
         return U3D_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL(nms_bev_k, dim3(1), dim3(1024), (size_t)n * 7 * sizeof(float), (hipStream_t)stream, boxes, labels, n, iou_thr, keep);
-    return check_launch("nms_bev");
+    const size_t lds = (size_t)n * 9 * sizeof(float);
+    if (mode == 0) hipLaunchKernelGGL(nms_k<0>, dim3(1), dim3(1024), lds, (hipStream_t)stream, boxes, labels, n, iou_thr, keep);
+    else hipLaunchKernelGGL(nms_k<1>, dim3(1), dim3(1024), lds, (hipStream_t)stream, boxes, labels, n, iou_thr, keep);
+    return check_launch("nms");
+}
+
+int u3d_nms_bev(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
+    return launch_nms(0, boxes, labels, n, iou_thr, keep, stream);
+}
+
+int u3d_nms_aligned3d(const float* corners, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
+    return launch_nms(1, corners, labels, n, iou_thr, keep, stream);
 }
 
 int u3d_trim_boxes(const float* points, int64_t pt_ld, const int32_t* sp_list, const int32_t* sp_offsets, int S,

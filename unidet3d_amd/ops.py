@@ -159,10 +159,12 @@ def instance_boxes(vb: VoxelBatch, instance_ids: torch.Tensor, n_inst_total: int
 # ----------------------------------------------------------------------------------------
 # inference post-processing
 # ----------------------------------------------------------------------------------------
-def nms_bev_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, iou_thr: float, score_thr: float):
-    """``UniDet3D._single_scene_multiclass_nms`` with fast_nms=True on yaw-free boxes (unidet3d/unidet3d.py:595-650):
-    class by class (ascending id), boxes above ``score_thr`` visited by descending score, greedy BEV-IoU suppression
-    (mmcv ``nms3d_normal``).  ``scores`` must already be sorted descending (they come from a sorted top-k).
+def nms_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, iou_thr: float, score_thr: float,
+                   fast_nms: bool = True):
+    """``UniDet3D._single_scene_multiclass_nms`` on yaw-free boxes (unidet3d/unidet3d.py:595-650): class by class
+    (ascending id), boxes above ``score_thr`` visited by descending score, greedy suppression by the BEV IoU
+    (``fast_nms``: mmcv ``nms3d_normal``) or by the 3-D IoU of the corner boxes (mmdet3d ``aligned_3d_nms`` on
+    ``_bbox_to_loss(boxes)``).  ``scores`` must already be sorted descending (they come from a sorted top-k).
     Returns (bboxes, scores, labels) in the reference's output order."""
     if bboxes.shape[1] != 6:
         raise NotImplementedError('rotated boxes (mmcv nms3d) are not built')
@@ -175,9 +177,18 @@ def nms_bev_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch
     b = bboxes[order].contiguous().float()
     lab = labels[order].to(torch.int32).contiguous()
     keep = torch.empty(n, dtype=torch.uint8, device=b.device)
-    L.call('u3d_nms_bev', L.ptr(b), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+    if fast_nms:
+        L.call('u3d_nms_bev', L.ptr(b), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+    else:
+        half = b[:, 3:] / 2                                      # _bbox_to_loss (criterion.py:180-198)
+        corners = torch.cat((b[:, :3] - half, b[:, :3] + half), dim=1).contiguous()
+        L.call('u3d_nms_aligned3d', L.ptr(corners), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
     k = order[keep.bool()]
     return bboxes[k], scores[k], labels[k]
+
+
+def nms_bev_multiclass(bboxes, scores, labels, iou_thr, score_thr):
+    return nms_multiclass(bboxes, scores, labels, iou_thr, score_thr, True)
 
 
 def trim_boxes_by_superpoints(points: torch.Tensor, sp_offsets: torch.Tensor, sp_points: torch.Tensor, n_superpoints: int,

@@ -222,10 +222,8 @@ class UniDet3D(nn.Module):
         scores, topk_idx = scores.flatten(0, 1).topk(min(self.test_cfg['topk_insts'], scores.numel()), sorted=True)
         labels = topk_idx % num_classes
         pred_bboxes = pred_bboxes[torch.div(topk_idx, num_classes, rounding_mode='floor')]
-        if not self.fast_nms[idx]:
-            raise NotImplementedError('aligned_3d_nms (fast_nms=False, unidet3d.py:634-636) is not built')
-        nms_bboxes, nms_scores, nms_labels = ops.nms_bev_multiclass(pred_bboxes, scores, labels, self.test_cfg['iou_thr'][idx],
-                                                                    self.test_cfg['score_thr'])
+        nms_bboxes, nms_scores, nms_labels = ops.nms_multiclass(pred_bboxes, scores, labels, self.test_cfg['iou_thr'][idx],
+                                                                self.test_cfg['score_thr'], bool(self.fast_nms[idx]))
         if self.use_superpoints[idx]:
             nms_bboxes = ops.trim_boxes_by_superpoints(vb.points, plan.sp_offsets, plan.sp_points, n_sp0, nms_bboxes,
                                                        self.test_cfg['low_sp_thr'], self.test_cfg['up_sp_thr'])

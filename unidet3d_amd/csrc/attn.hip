@@ -14,7 +14,7 @@
 
 namespace u3d {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
 #define U3D_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int ATT_LD = 36;   // 32 + 4 pad floats per staged row
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
     for (int d = 0; d < 2; ++d) {
         qf[d] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (qrow < len) qf[d] = *reinterpret_cast<const float4*>(base + (int64_t)qrow * ld + d * 16 + qd * 4);
-        qf[d].x *= scale; qf[d].y *= scale; qf[d].z *= scale; qf[d].w *= scale;
+        // scores in log2 units: q carries scale * log2(e), so the softmax needs v_exp_f32 only (VALU instructions add to the
+        // MFMA time on this hardware -- the loop is written for VALU count)
+        qf[d].x *= scale * LOG2E; qf[d].y *= scale * LOG2E; qf[d].z *= scale * LOG2E; qf[d].w *= scale * LOG2E;
     }
     float m = -INFINITY, l = 0.f;
     f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -89,25 +91,28 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
                 st[kb] = U3D_MFMA(a.w, qf[d].w, st[kb]);
             }
         }
+        if (kt == ntiles - 1 && (len & 63)) {          // only the last tile can hold keys past the end (wave-uniform)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 64 + kb * 16 + qd * 4 + r >= len) st[kb][r] = -INFINITY;
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 64 + kb * 16 + qd * 4 + r;
-                if (key >= len) st[kb][r] = -INFINITY;
-                mx = fmaxf(mx, st[kb][r]);
-            }
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);
-        const float alpha = __expf(m - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         float ps = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(st[kb][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
                 st[kb][r] = p;
                 ps += p;
             }
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
             op[16] = o[1][r] * inv;
         }
     }
-    if (qd == 0 && qrow < len) lse[(int64_t)h * n_total + start + qrow] = m + __logf(l);
+    if (qd == 0 && qrow < len) lse[(int64_t)h * n_total + start + qrow] = m * LN2 + __logf(l);      // natural-log units
 }
 
 // delta[h][i] = sum_d dO[i][h*32+d] * O[i][h*32+d]
@@ -185,9 +190,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
             qf[d] = *reinterpret_cast<const float4*>(base + (int64_t)qrow * ld + d * 16 + qd * 4);
             dof[d] = *reinterpret_cast<const float4*>(dout + (int64_t)(start + qrow) * D + h * 32 + d * 16 + qd * 4);
         }
-        qf[d].x *= scale; qf[d].y *= scale; qf[d].z *= scale; qf[d].w *= scale;
+        qf[d].x *= scale * LOG2E; qf[d].y *= scale * LOG2E; qf[d].z *= scale * LOG2E; qf[d].w *= scale * LOG2E;
     }
-    const float lse_q = qok ? lse[(int64_t)h * n_total + start + qrow] : 0.f;
+    // log2 units; rows past the end get +inf so that exp2(s - lse) = 0 masks them without a select per element
+    const float lse_q = qok ? lse[(int64_t)h * n_total + start + qrow] * LOG2E : INFINITY;
     const float del_q = qok ? delta[(int64_t)h * n_total + start + qrow] : 0.f;
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
         stage_tile(base + D, ld, kt * 64, len, 1.f, Ks, tid);
         stage_tile(base + 2 * D, ld, kt * 64, len, 1.f, Vs, tid);
         __syncthreads();
+        const bool last = kt == ntiles - 1 && (len & 63);          // wave-uniform
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
@@ -211,8 +218,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
             float ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * 64 + kb * 16 + qd * 4 + r;
-                const float p = (qok && key < len) ? __expf(s4[r] - lse_q) : 0.f;
+                float p = __builtin_amdgcn_exp2f(s4[r] - lse_q);
+                if (last && kt * 64 + kb * 16 + qd * 4 + r >= len) p = 0.f;        // zero-padded keys of the last tile
                 ds[r] = p * (dp4[r] - del_q);
             }
 #pragma unroll
@@ -264,11 +271,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
     const int ntiles = (len + 63) >> 6;
     for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
-        stage_tile(base, ld, qt * 64, len, scale, Qs, tid);
+        stage_tile(base, ld, qt * 64, len, scale * LOG2E, Qs, tid);        // log2 units; dK is rescaled by ln 2 at the end
         stage_tile(dobase, D, qt * 64, len, 1.f, Os, tid);
         if (tid < 64) {
             const int q = qt * 64 + tid;
-            lse_s[tid] = q < len ? lse[(int64_t)h * n_total + start + q] : INFINITY;   // exp(s - inf) = 0 masks the row
+            lse_s[tid] = q < len ? lse[(int64_t)h * n_total + start + q] * LOG2E : INFINITY;   // exp2(s - inf) = 0 masks the row
             del_s[tid] = q < len ? delta[(int64_t)h * n_total + start + q] : 0.f;
         }
         __syncthreads();
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qq = qb * 16 + qd * 4 + r;
-                p[r] = __expf(s4[r] - lse_s[qq]);
+                p[r] = __builtin_amdgcn_exp2f(s4[r] - lse_s[qq]);
                 ds[r] = p[r] * (dp4[r] - del_s[qq]);
             }
 #pragma unroll
@@ -307,8 +314,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
         const int row = k0 + wave * 16 + qd * 4 + r;
         if (row < len) {
             float* op = dqkv + (int64_t)(start + row) * ld + h * 32 + i16;
-            op[D] = dk[0][r];
-            op[D + 16] = dk[1][r];
+            op[D] = dk[0][r] * LN2;
+            op[D + 16] = dk[1][r] * LN2;
             op[2 * D] = dv[0][r];
             op[2 * D + 16] = dv[1][r];
         }

@@ -120,7 +120,7 @@ constexpr int TLD = GT + 4;    // padded LDS row of the TN tiles ([16 rows][128 
 
 // partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k]
 __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
-                                                 float* __restrict__ colsum, int64_t M, int N, int K, int64_t rows_per_split) {
+                                                 int colsum, int64_t M, int N, int K, int64_t rows_per_split) {
     __shared__ __attribute__((aligned(16))) float As[2][GK * TLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK * TLD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
         if (t + 1 < nt) lstore(buf ^ 1);
         __syncthreads();
     }
-    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)blockIdx.z * N * K, (int64_t)N * K * 4);
+    const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)blockIdx.z * pstride, (int64_t)N * K * 4);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int k = k0 + wc * 64 + b * 32 + i32;
@@ -205,19 +206,12 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, row * K * 4, 0);
             }
     }
-    if (sums && n0 + tid < N) colsum[(int64_t)blockIdx.z * N + n0 + tid] = csum;
+    if (sums && n0 + tid < N) partial[(int64_t)blockIdx.z * pstride + (int64_t)N * K + n0 + tid] = csum;
 }
 
-// column sums: out[n] = sum_s partial[s][n], fixed order
-__global__ void colsum_reduce_k(const float* __restrict__ partial, int S, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float v = 0.f;
-    for (int s = 0; s < S; ++s) v += partial[(int64_t)s * N + n];
-    out[n] = v;
-}
-
-__global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict__ partial, int S, int64_t n4, float* __restrict__ C) {
+// sums the splits in a fixed order; float4 i < n4_main goes to C, the rest (the column sums) to C2
+__global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict__ partial, int S, int64_t n4, int64_t n4_main, float* __restrict__ C,
+                                                        float* __restrict__ C2) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         // four independent partial sums (loads in flight), combined in a fixed order
         float4 v[4];
@@ -235,7 +229,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict_
             const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + i];
             v[0].x += t.x; v[0].y += t.y; v[0].z += t.z; v[0].w += t.w;
         }
-        reinterpret_cast<float4*>(C)[i] = make_float4((v[0].x + v[1].x) + (v[2].x + v[3].x), (v[0].y + v[1].y) + (v[2].y + v[3].y),
+        float4* dst = i < n4_main ? reinterpret_cast<float4*>(C) + i : reinterpret_cast<float4*>(C2) + (i - n4_main);
+        *dst = make_float4((v[0].x + v[1].x) + (v[2].x + v[3].x), (v[0].y + v[1].y) + (v[2].y + v[3].y),
                                                       (v[0].z + v[1].z) + (v[2].z + v[3].z), (v[0].w + v[1].w) + (v[2].w + v[3].w));
     }
 }
@@ -295,13 +290,11 @@ int u3d_gemm_tn(const float* A, const float* B, float* C, float* colsum_A, int64
         set_error("gemm_tn: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
         return U3D_EUNSUPPORTED;
     }
-    float* cs_part = colsum_A ? (float*)ws + (int64_t)S * N * K : nullptr;
-    hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, cs_part, M, N, K, rps);
-    if (colsum_A) hipLaunchKernelGGL(colsum_reduce_k, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float*)cs_part, S, N, colsum_A);
-    const int64_t n4 = (int64_t)N * K / 4;
+    hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
+    const int64_t n4_main = (int64_t)N * K / 4, n4 = n4_main + (colsum_A ? N / 4 : 0);
     int64_t grid = ceil_div(n4, 256);
     grid = grid > 1024 ? 1024 : grid;
-    hipLaunchKernelGGL(gemm_tn_reduce_k, dim3((unsigned)grid), dim3(256), 0, s, (const float*)ws, S, n4, C);
+    hipLaunchKernelGGL(gemm_tn_reduce_k, dim3((unsigned)grid), dim3(256), 0, s, (const float*)ws, S, n4, n4_main, C, colsum_A);
     return check_launch("gemm_tn");
 }
 

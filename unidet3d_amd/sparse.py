@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
+from . import dense
 
 
 # ----------------------------------------------------------------------------------------
@@ -438,8 +439,9 @@ class SubMConv3d(_ConvBase):
 
     def forward(self, x: SparseConvTensor, addend: Optional[torch.Tensor] = None) -> SparseConvTensor:
         if self.kernel_size == 1:
-            # plain [N, Cin] x [Cin, Cout] library GEMM (hipBLASLt), no rulebook (K5)
-            y = F.linear(x.features, self.weight.view(self.out_channels, self.in_channels))
+            # 1x1 skip convolution = [N, Cin] x [Cin, Cout] GEMM, no rulebook (K5): the decoder's fp32 MFMA GEMM kernels (the
+            # library picked a 0.6 ms kernel for the level-1 weight gradient, a [64 x 356k] x [356k x 32] product)
+            y = dense.linear(x.features, self.weight.view(self.out_channels, self.in_channels))
             return x.replace_feature(y if addend is None else y + addend)
         return x.replace_feature(sparse_conv(_pad16(x.features), self._w16(), self.geometry(x), 'fwd', addend))
 

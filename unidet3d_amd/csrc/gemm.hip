@@ -1,10 +1,10 @@
 // Dense fp32 GEMMs of the decoder (nn.Linear forward / input-gradient / weight-gradient,
 // unidet3d/encoder.py:19-21,55-61,138-140,153-155,163) on v_mfma_f32_32x32x2_f32.
 // The query decoder runs over ~16k packed rows with K, N in {32, 256, 768, 1024}: tall-skinny fp32
-// problems.  Measured on MI355X (tools/prof_gemm.py, M = 16000): this plain 128x128x16 LDS-tiled kernel
-// (one barrier per K-step, no software pipelining yet) reaches 65-93 TF/s, hipBLASLt 83-126 TF/s in
-// isolation; inside the training step both deliver ~55 TF/s, so the decoder runs on these kernels and
-// keeps the whole Linear path (forward, dX, dW) behind the C ABI.
+// problems.  Measured on MI355X (tools/prof_gemm.py, M = 16000): the NT kernel (128x128 or 128x64 LDS tiles,
+// buffer-load staging, one barrier per 16-deep K-step) reaches 76-103 TF/s, the TN kernel 32-75 TF/s; hipBLASLt
+// 82-121 / 24-95 TF/s in isolation.  The decoder and the 1x1 skip convolutions run on these kernels, which keeps the
+// whole Linear path (forward, dX, dW + bias gradient) behind the C ABI.
 //
 //   gemm_nt:  C[M,N] = A[M,K] . W[N,K]^T (+ bias[N])            (forward; dX = dY . (W^T)^T with W^T from u3d_transpose)
 //   gemm_tn:  C[N,K] = A[M,N]^T . B[M,K]                        (weight gradient; reduction over the M rows is

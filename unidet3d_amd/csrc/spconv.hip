@@ -5,20 +5,19 @@
 //
 // Forward / dgrad (spconv_gmm_k), wave-independent design (no workgroup barriers at all):
 //   * every wave64 owns R (32 or 64) consecutive DST rows x a 32-column slice of the output and,
-//     optionally, one of G groups of kernel offsets; its fp32 accumulator tile [R][36] is private
+//     optionally, one of G groups of kernel offsets; its fp32 accumulator tile [R+1][40] is private
 //     LDS, so dst is written exactly once per (row, column) -- no global atomics, no per-pair
 //     feature round trip through HBM (algorithmic traffic N*(Cs+Cd)*4 + pair indices + weights).
 //   * the canonical rulebook is the working structure: for offset k the wave's pairs are the
 //     contiguous range tile_starts[k][t] .. tile_starts[k][t+1] of the ascending scatter list;
-//     offsets without a pair in the tile cost two scalar loads, absent neighbours cost nothing.
-//   * per offset the wave takes 16-pair chunks two at a time: gathers the src rows straight into
-//     MFMA A fragments (one float4 per lane, K-permuted so a 16-byte load feeds four
-//     v_mfma_f32_16x16x4_f32), reads the B fragments W_k[n][c..c+3] with one float4 per lane from
-//     L2 (weights are [n][k][c], so the fragment is contiguous) shared by both chunks, accumulates
-//     over all source channels in registers and adds the 16x32 results into LDS with ds_add_f32.
-//   * 4 independent waves per workgroup, 16-18 KB LDS per wave-tile -> up to 16 waves per CU hide the
-//     gather latency; deep U-Net levels (a few thousand rows) get their parallelism from column
-//     slices and offset groups (partials summed by a small deterministic reduce kernel).
+//     offsets without a pair in the tile cost two lane reads, absent neighbours cost nothing.
+//   * per offset the wave takes windows of 16 or 32 pairs: whole source rows are loaded with buffer
+//     loads, transposed to MFMA fragments through a private LDS image, multiplied with the packed
+//     weight fragments (u3d_weight_pack) by v_mfma_f32_16x16x4_f32 in the TRANSPOSED orientation
+//     and accumulated straight through the MFMA C operand into the LDS tile (see GmmWave below).
+//   * 4 independent waves per workgroup, ~12 KB LDS per wave; deep U-Net levels (a few thousand
+//     rows) get their parallelism from column slices and offset groups (partials summed by a small
+//     deterministic reduce kernel).
 //   * fp32 in / fp32 accumulate MFMA (exact fp32, 157 TF peak) -- BASELINE config 2 is fp32.
 #include <stdlib.h>
 
@@ -44,10 +43,6 @@ struct GmmParams {
     int G;
     int kper;
 };
-
-__device__ __forceinline__ void lds_add(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 constexpr int GMM_CDS = 32;            // output columns per wave
 constexpr int GMM_ALD = 40;            // accumulator row stride (floats): 160 B keeps the 16-byte accesses of consecutive rows on distinct banks

@@ -237,6 +237,18 @@ int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K);
 int u3d_transpose(const float* in /*[R,C]*/, float* out /*[C,R]*/, int R, int C, u3d_stream_t stream);
 
+/* =====================================================================================
+ * K15 LayerNorm of the decoder (unidet3d/encoder.py:21,38-40,61,78-79,140,167) with the preceding residual add fused in.
+ *      forward: s = x (+ res), y = (s - mean) * rstd * gamma + beta; sum_out receives s when res != NULL (the tensor
+ *      the backward needs), stats [M][2] = (mean, rstd).  backward: dx (= gradient of both x and res), dgamma, dbeta
+ *      (per-workgroup partials in ws, fixed-order sum).  C % 4 == 0, C <= 1024.
+ * ===================================================================================== */
+int u3d_layer_norm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int64_t M, int C, float eps,
+                       float* sum_out, float* y, float* stats, u3d_stream_t stream);
+int u3d_layer_norm_bwd(const float* s, const float* dy, const float* gamma, const float* stats, int64_t M, int C, float* dx,
+                       float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
+int64_t u3d_layer_norm_ws_bytes(int64_t M, int C);
+
 /* ---- inference post-processing of one scene ------------------------------------------------
  * u3d_nms_bev: replaces UniDet3D._single_scene_multiclass_nms with fast_nms=True (unidet3d/unidet3d.py:595-650, which
  * calls mmcv.ops.nms3d_normal per class: greedy suppression by the IoU of the (x, y, dx, dy) rectangles).  boxes [n][6]

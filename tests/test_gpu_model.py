@@ -230,3 +230,20 @@ def test_loss_with_elastic_coords_matches_oracle():
         assert _rel(ds.gt_instances_3d.sp_centers, ocent[i]) < 1e-5
         assert _rel(ds.gt_instances_3d.bboxes_3d.gravity_center, insts[i].bboxes_3d.gravity_center) < 1e-6
     assert abs(loss.item() - oloss.item()) < 1e-3 * abs(oloss.item()), (loss.item(), oloss.item())
+
+
+# ---------------------------------------------------------------------------- K15 LayerNorm (+ residual)
+@pytest.mark.parametrize('M,C,with_res', [(1000, 256, True), (16001, 256, True), (333, 256, False), (1, 256, True), (77, 32, True), (50, 1024, False), (0, 256, True)])
+def test_layer_norm_fwd_bwd(M, C, with_res):
+    from unidet3d_amd.dense import layer_norm
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5; r = torch.randn(M, C, generator=g); w = torch.randn(C, generator=g); b = torch.randn(C, generator=g)
+    go = torch.randn(M, C, generator=g)
+    xo, ro, wo, bo = [t.clone().double().requires_grad_() for t in (x, r, w, b)]
+    yo = torch.nn.functional.layer_norm(xo + ro if with_res else xo, (C,), wo, bo, 1e-5); yo.backward(go.double())
+    xg, rg, wg, bg = [t.clone().to(DEV).requires_grad_() for t in (x, r, w, b)]
+    yg = layer_norm(xg, wg, bg, 1e-5, rg if with_res else None); yg.backward(go.to(DEV))
+    assert _rel(yg, yo) < 1e-5 and _rel(xg.grad, xo.grad) < 1e-5
+    if with_res:
+        assert _rel(rg.grad, ro.grad) < 1e-5
+    assert _rel(wg.grad, wo.grad) < 2e-5 and _rel(bg.grad, bo.grad) < 2e-5

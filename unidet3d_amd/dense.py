@@ -77,3 +77,53 @@ class _LinearFn(torch.autograd.Function):
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     """y = x W^T + b for 2-D x [M, K] (K % 16 == 0)."""
     return _LinearFn.apply(x, weight, bias)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + res) over the last dimension (include/u3d.h K15); the gradient of x and res is the same tensor."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        x = x.contiguous()
+        M, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        s = x
+        if res is not None:
+            res = res.contiguous()
+            s = torch.empty_like(x)
+        if M:
+            L.call('u3d_layer_norm_fwd', L.ptr(x), L.ptr(res), L.ptr(weight), L.ptr(bias), M, C, float(eps),
+                   L.ptr(s) if res is not None else None, L.ptr(y), L.ptr(stats), L.stream())
+        ctx.save_for_backward(s, weight, stats)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, weight, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, C = s.shape
+        dx = torch.empty_like(s)
+        dg = torch.empty(C, dtype=torch.float32, device=s.device)
+        db = torch.empty(C, dtype=torch.float32, device=s.device)
+        if M:
+            ws = L.scratch(L.lib().u3d_layer_norm_ws_bytes(M, C), s.device)
+            L.call('u3d_layer_norm_bwd', L.ptr(s), L.ptr(dy), L.ptr(weight), L.ptr(stats), M, C, L.ptr(dx), L.ptr(dg), L.ptr(db),
+                   L.ptr(ws), L.stream())
+        else:
+            dg.zero_(); db.zero_()
+        return dx, (dx if ctx.has_res else None), dg, db, None
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, res: torch.Tensor = None) -> torch.Tensor:
+    """LayerNorm(x + res) for 2-D x [M, C] (C % 4 == 0, C <= 1024)."""
+    return _LayerNormFn.apply(x, res, weight, bias, eps)
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    """``nn.LayerNorm(d_model)`` of the reference (same parameters / state_dict keys) on the HIP kernels, optionally fused with the
+    residual add in front of it."""
+
+    def forward(self, x, res=None):
+        return layer_norm(x, self.weight, self.bias, self.eps, res)

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
-from .dense import linear
+from .dense import LayerNorm, linear
 from .registry import MODELS
 
 
@@ -89,10 +89,10 @@ class SelfAttentionLayer(nn.Module):          # encoder.py:8-41
         if dropout != 0.0:
             raise NotImplementedError('the reference configs use dropout=0.0; dropout is not built')
         self.attn = _MHA(d_model, num_heads)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
 
     def forward(self, x, cu_seqlens, max_len):
-        return self.norm(self.attn(x, cu_seqlens, max_len) + x)
+        return self.norm(self.attn(x, cu_seqlens, max_len), x)           # LayerNorm(attn + x), add fused
 
 
 class FFN(nn.Module):                         # encoder.py:43-80
@@ -100,12 +100,12 @@ class FFN(nn.Module):                         # encoder.py:43-80
         super().__init__()
         self.net = nn.Sequential(nn.Linear(d_model, hidden_dim), nn.ReLU() if activation_fn == 'relu' else nn.GELU(),
                                  nn.Dropout(dropout), nn.Linear(hidden_dim, d_model), nn.Dropout(dropout))
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
 
     def forward(self, x):
         h = linear(x, self.net[0].weight, self.net[0].bias)
         h = self.net[1](h)
-        return self.norm(linear(h, self.net[3].weight, self.net[3].bias) + x)
+        return self.norm(linear(h, self.net[3].weight, self.net[3].bias), x)
 
 
 class PredBBox(nn.Module):                    # encoder.py:82-111
@@ -147,7 +147,7 @@ class UniDet3DEncoder(nn.Module):
         self.input_proj = nn.Sequential(nn.Linear(in_channels, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
         self.self_attn_layers = nn.ModuleList(SelfAttentionLayer(d_model, num_heads, dropout) for _ in range(num_layers))
         self.ffn_layers = nn.ModuleList(FFN(d_model, hidden_dim, dropout, activation_fn) for _ in range(num_layers))
-        self.out_norm = nn.LayerNorm(d_model)
+        self.out_norm = LayerNorm(d_model)
         unique_cls = sorted(set(itertools.chain.from_iterable(datasets_classes))) + ['no_obj']
         self.outs_cls = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, len(unique_cls)))
         self.datasets_cls_idxs = [[unique_cls.index(c) for c in dc] + [-1] for dc in datasets_classes]

@@ -155,10 +155,11 @@ int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, void* ws, u3d_s
 int64_t u3d_bn_ws_bytes(int C);
 /* mean/var from sums/count; scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place
  * (momentum, unbiased var) when running_mean != NULL.  count <= 0: the row count is read from sums[2C]
- * (it then travels through the SyncBatchNorm all-reduce with the sums: no host read-back). */
+ * (it then travels through the SyncBatchNorm all-reduce with the sums: no host read-back).
+ * num_batches_tracked (nullable, device int64 scalar) is incremented by one. */
 int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, int C, float* mean, float* invstd,
-                    float* scale, float* shift, u3d_stream_t stream);
+                    float* scale, float* shift, int64_t* num_batches_tracked, u3d_stream_t stream);
 int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y,
                  u3d_stream_t stream);
 /* backward of y = relu(x*scale+shift): sums[0..C) = sum dy', sums[C..2C) = sum dy'*xhat  (dy' = dy*[y>0]);
@@ -175,10 +176,11 @@ int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const f
 /* Single-call forms for the non-distributed case (stats -> finalize -> apply; bwd_stats -> bwd_apply).
  * st float [4C] = mean, invstd, scale, shift (saved for backward); sums double [2C+1]. */
 int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum,
-                   float* running_mean, float* running_var, int relu, float* y, float* st, double* sums, void* ws,
-                   u3d_stream_t stream);
-int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, double* sums, int64_t n, int C,
-                    float* dx, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st,
+                   double* sums, void* ws, u3d_stream_t stream);
+/* fwd_sums: the forward call's sums vector (its entry [2C] is the row count the backward divides by) */
+int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n,
+                    int C, float* dx, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
 
 /* =====================================================================================
  * K11/K12  superpoint pooling -- replaces x.features[inverse_mapping] + torch_scatter.scatter_mean

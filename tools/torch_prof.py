@@ -22,7 +22,7 @@ def step():
 for _ in range(2): step()
 torch.cuda.synchronize()
 N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(N): step()
     torch.cuda.synchronize()
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 45
@@ -32,3 +32,14 @@ tot = sum(e.self_device_time_total for e in ev)
 print(f'device time in torch-launched kernels: {tot / N / 1e3:.2f} ms/step')
 for e in ev[:rows]:
     print(f'{e.self_device_time_total / N / 1e3:8.3f} ms/step {e.count / N:7.0f} calls  {e.key[:90]}')
+
+# shapes behind the small aten ops
+by = {}
+for e in prof.key_averages(group_by_input_shape=True):
+    if e.key in ('aten::add_', 'aten::copy_', 'aten::fill_', 'aten::mul', 'aten::sum') and e.self_device_time_total > 0:
+        by.setdefault(e.key, []).append((e.self_device_time_total / N / 1e3, e.count / N, str(e.input_shapes)[:90]))
+for k, v in by.items():
+    v.sort(reverse=True)
+    print(k)
+    for t, c, sh in v[:7]:
+        print(f'   {t:7.3f} ms/step {c:6.0f} calls  {sh}')

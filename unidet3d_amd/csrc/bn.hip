@@ -100,10 +100,14 @@ __global__ __launch_bounds__(256) void bn_sum_partials_k(const double* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0 && set_rows) sums[C2] = rows;
 }
 
+__global__ void bn_copy_count_k(const double* __restrict__ from, double* __restrict__ to, int i) { to[i] = from[i]; }
+
 __global__ void bn_finalize_k(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float eps, float momentum, float* running_mean,
-                              float* running_var, int C, float* mean, float* invstd, float* scale, float* shift) {
+                              float* running_var, int C, float* mean, float* invstd, float* scale, float* shift,
+                              int64_t* num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (c >= C) return;
     if (!(count > 0.0)) count = sums[2 * C];      // count travels with the (all-reduced) sums
     const double m = sums[c] / count;
@@ -210,10 +214,10 @@ int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, void* ws, u3d_s
 
 int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, int C, float* mean, float* invstd, float* scale,
-                    float* shift, u3d_stream_t stream) {
+                    float* shift, int64_t* num_batches_tracked, u3d_stream_t stream) {
     if (!sums || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0) return U3D_EINVAL;
     hipLaunchKernelGGL(bn_finalize_k, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, gamma, beta, eps,
-                       momentum, running_mean, running_var, C, mean, invstd, scale, shift);
+                       momentum, running_mean, running_var, C, mean, invstd, scale, shift, num_batches_tracked);
     return check_launch("bn_finalize");
 }
 
@@ -251,21 +255,23 @@ int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const f
 }
 
 int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum,
-                   float* running_mean, float* running_var, int relu, float* y, float* st, double* sums, void* ws,
-                   u3d_stream_t stream) {
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st, double* sums,
+                   void* ws, u3d_stream_t stream) {
     int rc = u3d_bn_stats(x, n, C, sums, ws, stream);
     if (rc) return rc;
     rc = u3d_bn_finalize(sums, -1.0, gamma, beta, eps, momentum, running_mean, running_var, C, st, st + C, st + 2 * C,
-                         st + 3 * C, stream);
+                         st + 3 * C, num_batches_tracked, stream);
     if (rc) return rc;
     return u3d_bn_apply(x, st + 2 * C, st + 3 * C, relu, n, C, y, stream);
 }
 
-int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, double* sums, int64_t n, int C, float* dx,
-                    float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
-    // sums[2C] must hold the forward row count; sums[0..2C) are overwritten
+int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n, int C,
+                    float* dx, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
+    // sums[0..2C) are overwritten; sums[2C] (the row count) is taken from the forward pass's vector
+    if (!fwd_sums) return U3D_EINVAL;
     int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, stream);
     if (rc) return rc;
+    hipLaunchKernelGGL(bn_copy_count_k, dim3(1), dim3(1), 0, (hipStream_t)stream, fwd_sums, sums, 2 * C);
     return u3d_bn_bwd_apply(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, sums, -1.0, n, C, dx, dgamma, dbeta, stream);
 }
 

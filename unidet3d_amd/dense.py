@@ -65,8 +65,11 @@ class _LinearFn(torch.autograd.Function):
                 dyp[:, :N] = dy
                 dwp = torch.empty(Np, K, dtype=torch.float32, device=weight.device)
                 ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, Np, K), weight.device)
-                L.call('u3d_gemm_tn', L.ptr(dyp), L.ptr(x), L.ptr(dwp), None, M, Np, K, L.ptr(ws), 0.0, L.stream())
+                dbp = torch.empty(Np, dtype=torch.float32, device=weight.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+                L.call('u3d_gemm_tn', L.ptr(dyp), L.ptr(x), L.ptr(dwp), L.ptr(dbp), M, Np, K, L.ptr(ws), 0.0, L.stream())
                 dw = dwp[:N].contiguous()
+                if dbp is not None:
+                    db = dbp[:N].contiguous()
             else:
                 dw.zero_()
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:

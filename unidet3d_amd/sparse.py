@@ -267,7 +267,7 @@ def allreduce_bn_sums(sums: torch.Tensor, group=None):
 
 class _BNReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync, nbt=None):
         x = x.contiguous()
         n, C = x.shape
         dev = x.device
@@ -282,11 +282,11 @@ class _BNReLUFn(torch.autograd.Function):
                 allreduce_bn_sums(sums)          # rows ride along: no host read-back on the critical path
                 L.call('u3d_bn_finalize', L.ptr(sums), -1.0, L.ptr(gamma), L.ptr(beta), eps, momentum,
                        L.ptr(running_mean), L.ptr(running_var), C, L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]),
-                       L.ptr(st[3]), L.stream())
+                       L.ptr(st[3]), L.ptr(nbt), L.stream())
                 L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
             else:                                # one call: stats -> finalize -> apply
                 L.call('u3d_bn_forward', L.ptr(x), n, C, L.ptr(gamma), L.ptr(beta), eps, momentum, L.ptr(running_mean),
-                       L.ptr(running_var), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
+                       L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
         else:
             st[0] = running_mean
             st[1] = torch.rsqrt(running_var + eps)
@@ -305,14 +305,15 @@ class _BNReLUFn(torch.autograd.Function):
         n, C = x.shape
         dev = x.device
         dx = torch.empty_like(x)
-        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)       # dgamma, dbeta (local sums: DDP averages later)
+        # dgamma, dbeta (local sums: DDP averages later); separate tensors so that autograd can adopt them as .grad without a copy
+        dgb = [torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)]
         if not n:
-            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None
+            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
         if ctx.training and fsums is not None:
-            sums[2 * C:] = fsums[2 * C:]             # global row count of the forward pass
             if ctx.sync and _dist_on():
+                sums[2 * C:] = fsums[2 * C:]         # global row count of the forward pass
                 L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
                        int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
                 dgb[1] = sums[:C].to(torch.float32)
@@ -321,7 +322,7 @@ class _BNReLUFn(torch.autograd.Function):
                 L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
                        int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.stream())
             else:                                    # one call: bwd_stats -> bwd_apply (+ dgamma / dbeta)
-                L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(sums), n, C, L.ptr(dx),
+                L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(fsums), L.ptr(sums), n, C, L.ptr(dx),
                        L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(ws), L.stream())
         else:                                        # eval: statistics are constants -> dx = scale * dy'
             L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
@@ -332,7 +333,7 @@ class _BNReLUFn(torch.autograd.Function):
             sums[2 * C] = 1.0
             L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
                    int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.stream())
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
 class SparseBatchNorm(nn.Module):
@@ -351,10 +352,10 @@ class SparseBatchNorm(nn.Module):
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
     def forward(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
-        if self.training:
-            self.num_batches_tracked += 1
+        # num_batches_tracked is incremented by the statistics kernel (one launch less per layer)
         return _BNReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, relu, self.training, self.sync)
+                               self.momentum, relu, self.training, self.sync,
+                               self.num_batches_tracked if self.training and x.shape[0] else None)
 
 
 # ----------------------------------------------------------------------------------------

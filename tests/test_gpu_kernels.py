@@ -198,6 +198,7 @@ def test_batchnorm_relu_fwd_bwd(C, relu):
     assert _rel(yg, yo) < 1e-5 and _rel(xg.grad, xo.grad) < 1e-4
     assert _rel(bn_g.weight.grad, bn_o.weight.grad) < 1e-4 and _rel(bn_g.bias.grad, bn_o.bias.grad) < 1e-4
     assert _rel(bn_g.running_mean, bn_o.running_mean) < 1e-5 and _rel(bn_g.running_var, bn_o.running_var) < 1e-5
+    assert int(bn_g.num_batches_tracked) == int(bn_o.num_batches_tracked) == 1       # incremented inside the statistics kernel
     bn_o.eval(); bn_g.eval()
     with torch.no_grad():
         ye = bn_o(x); ye = torch.relu(ye) if relu else ye

@@ -119,7 +119,7 @@ int u3d_tile_starts(const int32_t* rows, const int32_t* counts, int K, int64_t c
  * (fuses the residual add of ResidualBlock.forward, spconv_unet.py:88-89).
  * Replaces SubMConv3d / SparseConv3d / SparseInverseConv3d forward and their input-gradients.
  * ===================================================================================== */
-int u3d_spconv_gmm(const float* src, const float* w_packed, const int32_t* gather, const int32_t* scatter,
+int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_packed, const int32_t* gather, const int32_t* scatter,
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst,
                    int tile_rows, int k_groups, const float* addend, float* dst, void* ws, double flops_hint,
                    u3d_stream_t stream);
@@ -131,8 +131,10 @@ int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k
 /* dW[(n*K+k)*Cs + c] = sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]   (dW is overwritten).
  * The pairs of offset k are processed per tile of dy rows: tile_starts = u3d_tile_starts(rows_dy, ..., tile_rows =
  * u3d_spconv_wgrad_tile_rows(...)); per-tile partial blocks go through ws and are summed in a fixed order
- * (deterministic, no atomics). */
-int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
+ * (deterministic, no atomics).
+ * Both conv entry points address through 32-bit buffer offsets: row counts < 2^24, feature matrices and pair lists < 2 GiB
+ * (U3D_EUNSUPPORTED otherwise). */
+int u3d_spconv_wgrad(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
                      const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
                      float* dW, void* ws, double flops_hint, u3d_stream_t stream);
 int u3d_spconv_wgrad_tile_rows(int K, int64_t n_rows_dy, int Cs, int Cd);

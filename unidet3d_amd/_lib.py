@@ -37,9 +37,9 @@ PROTOTYPES = {
     'u3d_down_rulebook': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_down_rulebook_ws_bytes': (_i64, [_i64]),
     'u3d_tile_starts': (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp]),
-    'u3d_spconv_gmm': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _f64, _vp]),
+    'u3d_spconv_gmm': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _f64, _vp]),
     'u3d_spconv_plan': (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
-    'u3d_spconv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
+    'u3d_spconv_wgrad': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
     'u3d_spconv_wgrad_tile_rows': (_i32, [_i32, _i64, _i32, _i32]),
     'u3d_spconv_wgrad_ws_bytes': (_i64, [_i32, _i64, _i32, _i32]),
     'u3d_layer_norm_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),

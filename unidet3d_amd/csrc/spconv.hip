@@ -592,10 +592,16 @@ int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k
     return U3D_OK;
 }
 
-int u3d_spconv_gmm(const float* src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
+int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
                    int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
-    if (!src || !w_rows || !gather || !scatter || !tile_starts || !dst || K <= 0 || K > 32 || n_dst <= 0) return U3D_EINVAL;
+    if (!src || !w_rows || !gather || !scatter || !tile_starts || !dst || K <= 0 || K > 32 || n_dst <= 0 || n_src <= 0 || cap <= 0) return U3D_EINVAL;
+    // the kernel addresses through 32-bit buffer offsets and multiplies row indices with v_mul_u32_u24
+    if (n_src >= (1 << 24) || n_dst >= (1 << 24) || n_src * Cs * 4 >= 0x7fffffffLL || (int64_t)K * cap * 4 >= 0x7fffffffLL) {
+        set_error("spconv_gmm: %lld source rows x %d channels / %lld pairs per offset exceed the kernel's 32-bit addressing",
+                  (long long)n_src, Cs, (long long)cap);
+        return U3D_EUNSUPPORTED;
+    }
     int R = 0, G = 0;
     if (u3d_spconv_plan(Cs, Cd, K, n_dst, &R, &G) != U3D_OK || R != tile_rows || G != k_groups || (G > 1 && !ws)) {
         set_error("spconv_gmm: unsupported Cs=%d Cd=%d or plan mismatch (tile %d/%d groups %d/%d)", Cs, Cd, tile_rows, R, k_groups, G);
@@ -635,10 +641,15 @@ int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd) {
     return (int64_t)K * ceil_div(n_rows_dy, T) * Cs * Cd * 4 + 256;
 }
 
-int u3d_spconv_wgrad(const float* x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
+int u3d_spconv_wgrad(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
                      const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
                      float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
-    if (!x || !dy || !rows_x || !rows_dy || !tile_starts || !dW || !ws || K <= 0 || cap <= 0 || n_rows_dy <= 0) return U3D_EINVAL;
+    if (!x || !dy || !rows_x || !rows_dy || !tile_starts || !dW || !ws || K <= 0 || cap <= 0 || n_rows_dy <= 0 || n_rows_x <= 0) return U3D_EINVAL;
+    if (n_rows_x >= (1 << 24) || n_rows_dy >= (1 << 24) || n_rows_x * Cs * 4 >= 0x7fffffffLL || n_rows_dy * Cd * 4 >= 0x7fffffffLL ||
+        (int64_t)K * cap * 4 >= 0x7fffffffLL) {
+        set_error("spconv_wgrad: %lld / %lld rows exceed the kernel's 32-bit addressing", (long long)n_rows_x, (long long)n_rows_dy);
+        return U3D_EUNSUPPORTED;
+    }
     if (tile_rows != plan_wgrad_rows(K, n_rows_dy, Cs, Cd)) {
         set_error("spconv_wgrad: tile_rows %d does not match the plan", tile_rows);
         return U3D_EINVAL;

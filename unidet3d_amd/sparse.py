@@ -162,7 +162,7 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
         wp = torch.empty(weight.numel(), dtype=torch.float32, device=src.device)       # MFMA-fragment order
         L.call('u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
-        L.call('u3d_spconv_gmm', L.ptr(src), L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
+        L.call('u3d_spconv_gmm', L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
                rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
     return dst
 
@@ -231,10 +231,10 @@ class _SparseConvFn(torch.autograd.Function):
                 side = _side_stream(weight.device)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    L.call('u3d_spconv_wgrad', L.ptr(src), L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
+                    L.call('u3d_spconv_wgrad', L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                            rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
             else:
-                L.call('u3d_spconv_wgrad', L.ptr(src), L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
+                L.call('u3d_spconv_wgrad', L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                        rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
         if ctx.needs_input_grad[0]:
             if mode == 'fwd':

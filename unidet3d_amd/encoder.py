@@ -19,7 +19,6 @@ import math
 from typing import List
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L

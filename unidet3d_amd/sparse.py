@@ -17,7 +17,7 @@ produce.
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist

@@ -14,7 +14,7 @@
 
 namespace u3d {
 
-constexpr int NMS_MAX = 2048;          // 9 LDS words per box: 72 KB would pass the 64 KB default limit of a launch beyond this
+constexpr int NMS_MAX = 1800;          // 9 LDS words per box: 64.8 KB, just inside the 64 KB a launch may request without opting in
 
 // MODE 0: BEV IoU of (cx, cy, cz, dx, dy, dz) boxes, suppress when iou > thr           (mmcv nms3d_normal / iou_normal)
 // MODE 1: 3-D IoU of (x1, y1, z1, x2, y2, z2) boxes, survive only when iou <= thr       (mmdet3d aligned_3d_nms: a 0/0 IoU

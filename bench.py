@@ -140,6 +140,8 @@ def main():
     broadcast_params(model)
     params = [p for p in model.parameters() if p.requires_grad]
     bucket = FlatGradBucket(params, attach=False)
+    if world > 1:
+        bucket.enable_overlap()              # 16 MB buckets, all-reduced over RCCL as backward completes them
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)      # configs/unidet3d_1xb8_scannet.py:712
 
     log(f'rank {rank}/{world}: model built, generating {args.batch} scenes')
@@ -149,9 +151,8 @@ def main():
     def step():
         bucket.clear_grads()                 # backward writes fresh grads: no accumulate kernels
         loss = model.loss(inputs, samples)['det_loss']
-        loss.backward()
-        bucket.pack()                        # one multi-tensor copy into the flat buffer ...
-        bucket.allreduce_mean()              # ... one RCCL all-reduce of all gradients (no-op at N = 1)
+        loss.backward()                      # N > 1: hooks copy finished buckets into the flat buffer and start their all-reduce
+        bucket.sync()                        # N > 1: wait + average; N = 1: one multi-tensor copy into the flat buffer
         if not args.no_optimizer:
             bucket.clip_grad_norm_(10.0)     # clip_grad max_norm=10, norm_type=2 (configs :713) on the flat buffer
             opt.step()

@@ -38,6 +38,16 @@ def _worker(rank, world, port, q):
         bucket.pack()
     assert bucket.check_views()
     bucket.allreduce_mean()
+    # the bucketed, backward-overlapped exchange must give the same averaged gradients
+    net2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    net2.load_state_dict(net.state_dict())
+    ov = FlatGradBucket(net2.parameters(), attach=False).enable_overlap(bucket_bytes=64)      # 3 buckets for 4 tensors
+    assert len(ov.buckets) == 3
+    for _ in range(2):                                # hooks re-arm for the next step
+        ov.clear_grads()
+        ((net2(xs) - ys) ** 2).mean().backward()
+        ov.finish()
+        assert ov.check_views() and torch.allclose(ov.flat, bucket.flat, atol=1e-7)
     # SyncBN statistics: per-rank partial sums of different row counts -> global mean / var
     C = 4
     xr = torch.randn(10 + 7 * rank, C, generator=torch.Generator().manual_seed(rank)).double()

@@ -1,10 +1,12 @@
 """Data-parallel harness: one process per GPU, replicated weights, one scene batch per rank.
 
 The reference gets this from mmengine's DDP wrapper + ``nn.SyncBatchNorm``.
-Here: all parameter gradients live in ONE flat fp32 buffer (``p.grad`` are views into it), so the
-gradient exchange is a single RCCL all-reduce of 63.5 MB over xGMI with no pack/unpack copies, and
-batch-norm statistics are exchanged by ``sparse.allreduce_bn_sums``.  Works unchanged on CPU tensors
-with the gloo backend (tests/test_dist_cpu.py).
+Here: all parameter gradients live in ONE flat fp32 buffer (``p.grad`` are views into it).  The buffer is cut
+into a few contiguous buckets (default 16 MB: xGMI rings are per-link bound, a handful of large collectives beats
+many small ones); a bucket is all-reduced asynchronously (RCCL over xGMI) as soon as backward has produced the last
+of its gradients, so the exchange of the decoder's gradients overlaps with the backbone's backward
+(``enable_overlap()`` / ``finish()``).  Batch-norm statistics are exchanged by ``sparse.allreduce_bn_sums``.
+Works unchanged on CPU tensors with the gloo backend (tests/test_dist_cpu.py).
 """
 from __future__ import annotations
 
@@ -72,6 +74,84 @@ class FlatGradBucket:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
+
+    # ---- bucketed exchange overlapped with backward ---------------------------------------
+    def enable_overlap(self, bucket_bytes: int = 16 << 20, group=None):
+        """Cut the flat buffer into contiguous buckets and hook every parameter: when backward has accumulated the
+        last gradient of a bucket, its gradients are copied into the buffer (one multi-tensor copy) and the bucket's
+        all-reduce is launched asynchronously.  Use with ``clear_grads()`` before and ``finish()`` after backward.
+        Assumes every parameter receives at most one gradient per backward (true for this model); ``finish()`` raises
+        if a second accumulation hit a bucket that was already launched."""
+        self.group = group
+        self.buckets = []
+        i0, o0, o = 0, 0, 0
+        for i, p in enumerate(self.params):
+            o += p.numel()
+            if (o - o0) * self.flat.element_size() >= bucket_bytes or i == len(self.params) - 1:
+                self.buckets.append(dict(lo=i0, hi=i + 1, flat=self.flat[o0:o], pending=i + 1 - i0, launched=False, dirty=False, work=None))
+                i0, o0 = i + 1, o
+        self._bucket_of = {}
+        for b in self.buckets:
+            for i in range(b['lo'], b['hi']):
+                self._bucket_of[id(self.params[i])] = b
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        self._overlap = True
+        return self
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        if b['launched']:
+            b['dirty'] = True
+            return
+        b['pending'] -= 1
+        if b['pending'] == 0:
+            self._launch(b)
+
+    def _launch(self, b, sync: bool = False):
+        src, dst = [], []
+        for i in range(b['lo'], b['hi']):
+            p, v = self.params[i], self.views[i]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+        b['launched'] = True
+        if self._world() > 1:
+            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=not sync)
+
+    def finish(self):
+        """Call after backward: launches the buckets that never completed (unused parameters), waits for the
+        collectives, averages, and re-arms the hooks' counters for the next step."""
+        for b in self.buckets:
+            if not b['launched']:
+                self._launch(b)
+        for b in self.buckets:
+            if b['work'] is not None and b['work'] is not True:
+                b['work'].wait()
+            if b['dirty']:                       # a gradient was accumulated into a bucket that was already being reduced
+                raise RuntimeError('FlatGradBucket: a parameter received a second gradient after its bucket was launched; '
+                                   'use pack() + allreduce_mean() for graphs that reuse parameters')
+        w = self._world()
+        if w > 1:
+            self.flat.div_(w)
+        for b in self.buckets:
+            b.update(pending=b['hi'] - b['lo'], launched=False, dirty=False, work=None)
+
+    def sync(self):
+        """After backward: the overlapped form when ``enable_overlap()`` was called, else one copy + one all-reduce."""
+        if getattr(self, '_overlap', False):
+            self.finish()
+        else:
+            self.pack()
+            self.allreduce_mean()
 
     def check_views(self) -> bool:
         """True while every p.grad still aliases the flat buffer (autograd accumulates in place)."""

@@ -82,6 +82,10 @@ class FlatGradBucket:
         all-reduce is launched asynchronously.  Use with ``clear_grads()`` before and ``finish()`` after backward.
         Assumes every parameter receives at most one gradient per backward (true for this model); ``finish()`` raises
         if a second accumulation hit a bucket that was already launched."""
+        if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # a communicator of its own: the (blocking) SyncBatchNorm all-reduces of the backbone's backward would otherwise
+            # queue behind a 16 MB bucket on the shared one.  Collective call: every rank reaches enable_overlap().
+            group = dist.new_group()
         self.group = group
         self.buckets = []
         i0, o0, o = 0, 0, 0

@@ -67,3 +67,31 @@ def test_decoder_box_decode_and_structures():
     assert torch.allclose(b.tensor[0, 2], torch.tensor(3.0 - 0.4))
     assert torch.allclose(b.gravity_center[0], torch.tensor([1.0, 2.0, 3.0]))
     assert len(b[torch.tensor([0, 0])]) == 2
+
+
+def test_rotated_boxes_take_the_rotated_loss_in_matcher_and_layer_loss():
+    """7-dof ground truth (ARKitScenes, angles=True): the loop path matches by the rotated DIoU cost and sums the rotated DIoU
+    loss (criterion.py:127-128, 264-265).  Checked against a hand evaluation with the rotated oracle on one scene / one layer."""
+    from oracle import rotated_iou as ri
+    g = torch.Generator().manual_seed(4)
+    n, ng = 30, 3
+    gt7 = torch.cat((torch.rand(ng, 3, generator=g) * 2, torch.rand(ng, 3, generator=g) * 0.6 + 0.2, (torch.rand(ng, 1, generator=g) - 0.5) * 3), 1)
+    labels = torch.randint(0, 18, (ng,), generator=g)
+    qm = torch.rand(ng, n, generator=g) < 0.3
+    inst = InstanceData_(labels_3d=labels, bboxes_3d=DepthInstance3DBoxes(gt7, with_yaw=True, box_dim=7), query_masks=qm, sp_masks=qm)
+    cls = torch.randn(n, 19, generator=g).requires_grad_()
+    box = torch.cat((torch.rand(n, 3, generator=g) * 2, torch.rand(n, 3, generator=g) * 0.6 + 0.2, (torch.rand(n, 1, generator=g) - 0.5) * 3), 1).requires_grad_()
+    crit = _crit()
+    loss = crit.get_layer_loss(dict(cls_preds=[cls], bboxes=[box]), [inst], ['scannet'])
+    # hand evaluation: cost = -0.5 * softmax(cls)[:, label] + 2.0 * (1 - DIoU); each GT keeps its 6 cheapest allowed queries
+    gtb = torch.cat((inst.bboxes_3d.gravity_center, gt7[:, 3:]), 1)
+    cost = -0.5 * cls.softmax(-1)[:, labels] + 2.0 * torch.stack([ri.rotated_diou_3d_loss(box, gtb[j:j + 1].expand(n, 7)) for j in range(ng)], 1)
+    cost = torch.where(qm.T, cost, torch.tensor(1e8)).detach()
+    kth = torch.topk(cost, 7, dim=0, largest=False).values[-1:]
+    ids = torch.argwhere(cost < kth)
+    target = torch.full((n,), 18); target[ids[:, 0]] = labels[ids[:, 1]]
+    w = torch.ones(19); w[-1] = 0.1
+    want = 0.5 * torch.nn.functional.cross_entropy(cls, target, w) + 1.0 * ri.rotated_diou_3d_loss(box[ids[:, 0]], gtb[ids[:, 1]]).mean()
+    assert len(ids) > 0 and abs(float(loss) - float(want)) < 1e-5 * abs(float(want))
+    loss.backward()
+    assert torch.isfinite(box.grad).all() and box.grad[ids[:, 0]].abs().sum() > 0

@@ -4,8 +4,8 @@ Same registry names, constructor arguments and call signatures as the reference
 (unidet3d/criterion.py:7-178 ``UniDet3DCriterion``; :200-320 ``QueryClassificationCost``,
 ``BboxCostJointTraining``, ``UniMatcher``; unidet3d/axis_aligned_iou_loss.py:14-116
 ``UniDet3DAxisAlignedIoULoss``).  The tensors here are [n_queries, n_gt] -- tiny next to the
-backbone -- so this stays on torch ops on the device; the rotated
-DIoU (ARKitScenes only) is not built and raises.
+backbone -- so this stays on torch ops on the device, including the rotated
+IoU / DIoU of ARKitScenes boxes (unidet3d/rotated_iou_loss.py; mmcv's polygon intersection as batched tensor ops).
 """
 from __future__ import annotations
 
@@ -62,16 +62,104 @@ class UniDet3DAxisAlignedIoULoss(nn.Module):
         return loss * self.loss_weight
 
 
+# ---- rotated boxes (ARKitScenes, angles=True): unidet3d/rotated_iou_loss.py -------------------------------------
+# The BEV polygon intersection of mmcv.ops.diff_iou_rotated (box2corners, box_intersection, box1_in_box2,
+# build_vertices, sort_indices + calculate_area) as batched tensor ops on whatever device the boxes live on: the 24
+# candidate vertices are ordered by angle around their mean with one argsort (invalid candidates last, then overwritten
+# by the first vertex so that they add nothing to the shoelace sum) instead of mmcv's per-box comparison-sort kernel.
+def _box2corners(box):
+    x, y, w, h, a = box.unbind(-1)
+    x4 = torch.stack((0.5 * w, -0.5 * w, -0.5 * w, 0.5 * w), -1)
+    y4 = torch.stack((0.5 * h, 0.5 * h, -0.5 * h, -0.5 * h), -1)
+    c, s = torch.cos(a)[..., None], torch.sin(a)[..., None]
+    return torch.stack((x4 * c - y4 * s + x[..., None], x4 * s + y4 * c + y[..., None]), -1)
+
+
+def _corners_inside(c1, c2):
+    a, b, d = c2[..., 0:1, :], c2[..., 1:2, :], c2[..., 3:4, :]
+    ab, ad, am = b - a, d - a, c1 - a
+    pab, pad = (ab * am).sum(-1) / (ab * ab).sum(-1), (ad * am).sum(-1) / (ad * ad).sum(-1)
+    return (pab > -1e-6) & (pab < 1 + 1e-6) & (pad > -1e-6) & (pad < 1 + 1e-6)
+
+
+def _oriented_box_intersection_2d(c1, c2):
+    a1, a2 = c1[..., :, None, :], c1[..., [1, 2, 3, 0], :][..., :, None, :]
+    b1, b2 = c2[..., None, :, :], c2[..., [1, 2, 3, 0], :][..., None, :, :]
+    x1, y1, x2, y2 = a1[..., 0], a1[..., 1], a2[..., 0], a2[..., 1]
+    x3, y3, x4, y4 = b1[..., 0], b1[..., 1], b2[..., 0], b2[..., 1]
+    num = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
+    den_t = (x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4)
+    den_u = (x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3)
+    par = num == 0
+    safe = torch.where(par, torch.ones_like(num), num)
+    t = torch.where(par, -torch.ones_like(num), den_t / safe)
+    u = torch.where(par, -torch.ones_like(num), -den_u / safe)
+    m_int = ((t > 0) & (t < 1) & (u > 0) & (u < 1)).flatten(-2, -1)
+    t2 = den_t / (num + 1e-8)
+    pts = torch.stack((x1 + t2 * (x2 - x1), y1 + t2 * (y2 - y1)), -1).flatten(-3, -2)
+    verts = torch.cat((c1, c2, pts), -2)                                                    # (..., 24, 2)
+    mask = torch.cat((_corners_inside(c1, c2), _corners_inside(c2, c1), m_int), -1)       # (..., 24)
+    with torch.no_grad():
+        nv = mask.sum(-1, keepdim=True).clamp(min=1)
+        mean = (verts * mask[..., None]).sum(-2, keepdim=True) / nv[..., None]
+        d = verts - mean
+        ang = torch.where(mask, torch.atan2(d[..., 1], d[..., 0]), torch.full_like(d[..., 0], float('inf')))
+        order = torch.argsort(ang, dim=-1)
+    sv = torch.gather(verts, -2, order[..., None].expand(*order.shape, 2))
+    sm = torch.gather(mask, -1, order)
+    sv = torch.where(sm[..., None], sv, sv[..., :1, :])
+    nx = torch.roll(sv, -1, -2)
+    area = (sv[..., 0] * nx[..., 1] - sv[..., 1] * nx[..., 0]).sum(-1).abs() / 2
+    return torch.where(mask.sum(-1) >= 3, area, torch.zeros_like(area))
+
+
+def diff_iou_rotated_3d(box3d1, box3d2, diou: bool):
+    """(..., 7) (x, y, z, w, h, l, alpha) pairs -> (...,) IoU, or DIoU as ``diff_diou_rotated_3d`` computes it
+    (rotated_iou_loss.py:14-60; its centre term is over the first three entries of the BEV vectors, (dx, dy, dw), :58)."""
+    box1, box2 = box3d1[..., [0, 1, 3, 4, 6]], box3d2[..., [0, 1, 3, 4, 6]]
+    c1, c2 = _box2corners(box1), _box2corners(box2)
+    inter = _oriented_box_intersection_2d(c1, c2)
+    zmax1, zmin1 = box3d1[..., 2] + box3d1[..., 5] * 0.5, box3d1[..., 2] - box3d1[..., 5] * 0.5
+    zmax2, zmin2 = box3d2[..., 2] + box3d2[..., 5] * 0.5, box3d2[..., 2] - box3d2[..., 5] * 0.5
+    inter3d = inter * (torch.min(zmax1, zmax2) - torch.max(zmin1, zmin2)).clamp(min=0.)
+    union3d = box3d1[..., 3] * box3d1[..., 4] * box3d1[..., 5] + box3d2[..., 3] * box3d2[..., 4] * box3d2[..., 5] - inter3d
+    iou = inter3d / union3d
+    if not diou:
+        return iou
+    x_max = torch.max(c1[..., 0].max(-1)[0], c2[..., 0].max(-1)[0]); x_min = torch.min(c1[..., 0].min(-1)[0], c2[..., 0].min(-1)[0])
+    y_max = torch.max(c1[..., 1].max(-1)[0], c2[..., 1].max(-1)[0]); y_min = torch.min(c1[..., 1].min(-1)[0], c2[..., 1].min(-1)[0])
+    z_max, z_min = torch.max(zmax1, zmax2), torch.min(zmin1, zmin2)
+    r2 = ((box1[..., :3] - box2[..., :3]) ** 2).sum(-1)
+    c2_ = (x_min - x_max) ** 2 + (y_min - y_max) ** 2 + (z_min - z_max) ** 2
+    return iou - r2 / c2_
+
+
 @MODELS.register_module()
 class UniDet3DRotatedIoU3DLoss(nn.Module):
-    """Placeholder with the reference's name (rotated_iou_loss.py): only ARKitScenes
-    (angles=True) reaches it; not built in this round -> fails loudly."""
+    """1 - IoU ('iou', mmdet3d ``rotated_iou_3d_loss``) or 1 - DIoU ('diou') of rotated boxes, with the weight / reduction
+    handling of mmdet's ``weighted_loss`` (rotated_iou_loss.py:85-151)."""
 
     def __init__(self, mode='iou', reduction='mean', loss_weight=1.0):
         super().__init__()
+        assert mode in ('iou', 'diou') and reduction in ('none', 'sum', 'mean')
+        self.mode, self.reduction, self.loss_weight = mode, reduction, loss_weight
 
-    def forward(self, *a, **k):
-        raise NotImplementedError('rotated DIoU (ARKitScenes, 7-dof boxes) is outside the built hot path')
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        if weight is not None and not torch.any(weight > 0):
+            return pred.sum() * weight.sum()
+        reduction = reduction_override if reduction_override else self.reduction
+        if weight is not None and weight.dim() > 1:
+            weight = weight.mean(-1)
+        loss = 1 - diff_iou_rotated_3d(pred, target, self.mode == 'diou')
+        if weight is not None:
+            loss = loss * weight
+        if avg_factor is None:
+            loss = loss.mean() if reduction == 'mean' else (loss.sum() if reduction == 'sum' else loss)
+        elif reduction == 'mean':
+            loss = loss.sum() / (avg_factor + torch.finfo(torch.float32).eps)
+        elif reduction != 'none':
+            raise ValueError('avg_factor can not be used with reduction="sum"')
+        return loss * self.loss_weight
 
 
 def _bbox_to_loss(bbox):                       # criterion.py:180-198

@@ -89,3 +89,20 @@ def test_flat_grad_allreduce_and_syncbn_stats_world2():
     n = s[8]
     assert n == len(allx)
     assert np.allclose(s[:4] / n, allx.mean(0).numpy()) and np.allclose(s[4:8] / n - (s[:4] / n) ** 2, allx.var(0, unbiased=False).numpy())
+
+
+def test_overlap_buckets_with_unused_parameters_single_process():
+    """A parameter that receives no gradient must not hold its bucket back: finish() closes it with zeros."""
+    from unidet3d_amd.dist import FlatGradBucket
+    torch.manual_seed(0)
+    used, unused = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+    params = list(used.parameters()) + list(unused.parameters())
+    b = FlatGradBucket(params, attach=False).enable_overlap(bucket_bytes=32)
+    for _ in range(2):
+        b.clear_grads()
+        used(torch.ones(2, 4)).sum().backward()
+        b.finish()
+        assert b.check_views()
+        assert torch.equal(used.weight.grad, torch.full((3, 4), 2.0)) and torch.equal(used.bias.grad, torch.full((3,), 2.0))
+        assert float(unused.weight.grad.abs().sum()) == 0.0 and float(unused.bias.grad.abs().sum()) == 0.0
+    assert float(b.clip_grad_norm_(1.0)) > 1.0 and abs(float(b.flat.norm()) - 1.0) < 1e-5

@@ -111,6 +111,35 @@ def aligned_3d_nms(corners: np.ndarray, scores: np.ndarray, classes: np.ndarray,
     return np.asarray(pick, dtype=np.int64)
 
 
+def nms3d_rotated(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
+    """mmcv.ops.nms3d restated (PARITY UNPINNED like nms3d_normal): boxes (x, y, z, dx, dy, dz, heading); greedy, descending
+    score; a later box is suppressed when its BEV IoU with a kept box -- intersection area of the two rotated rectangles
+    / max(area_a + area_b - inter, 1e-8) -- exceeds thr.  The intersection comes from oracle.rotated_iou's polygon code
+    (exact geometry, checked against an independent clipper), in float64."""
+    import torch
+    from . import rotated_iou as ri
+    b5 = torch.from_numpy(np.ascontiguousarray(boxes[:, [0, 1, 3, 4, 6]])).double()
+    cor = ri.box2corners(b5)
+    area = (b5[:, 2] * b5[:, 3]).numpy()
+    order = np.argsort(-scores.astype(F32), kind='stable')
+    sup = np.zeros(len(order), bool)
+    keep = []
+    for ii, i in enumerate(order):
+        if sup[ii]:
+            continue
+        keep.append(i)
+        rest = [jj for jj in range(ii + 1, len(order)) if not sup[jj]]
+        if not rest:
+            continue
+        js = order[rest]
+        inter = ri.oriented_box_intersection_2d(cor[i][None].expand(len(js), 4, 2), cor[js]).numpy()
+        iou = inter / np.maximum(area[i] + area[js] - inter, 1e-8)
+        for jj, v in zip(rest, iou):
+            if v > thr:
+                sup[jj] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
 def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, iou_thr: float, score_thr: float, fast_nms: bool = True):
     """_single_scene_multiclass_nms on yaw-free boxes (unidet3d.py:611-650), both fast_nms branches."""
     out_b, out_s, out_l = [], [], []
@@ -120,7 +149,10 @@ def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, i
         if not ids.any():
             continue
         cs, cb, cl = scores[sel][ids], bboxes[sel][ids], labels[sel][ids]
-        k = nms3d_normal(cb, cs, iou_thr) if fast_nms else aligned_3d_nms(bbox_to_loss(cb), cs, cl, iou_thr)
+        if cb.shape[1] == 7:                # with_yaw (unidet3d.py:625-626)
+            k = nms3d_rotated(cb, cs, iou_thr)
+        else:
+            k = nms3d_normal(cb, cs, iou_thr) if fast_nms else aligned_3d_nms(bbox_to_loss(cb), cs, cl, iou_thr)
         out_b.append(cb[k]); out_s.append(cs[k]); out_l.append(cl[k])
     if not out_b:
         return np.zeros((0, bboxes.shape[1]), F32), np.zeros((0,), F32), np.zeros((0,), np.int64)

@@ -87,3 +87,14 @@ def test_aligned_3d_nms_uses_volume_iou_and_drops_degenerate_duplicates():
     assert len(l) == 2                      # BEV NMS would have merged them (identical footprint), the 3-D IoU is 0.2/1.8
     b, s, l = pp.multiclass_nms(np.stack([_box(0, 0, 0, 1, 1, 1), _box(0, 0, 0.8, 1, 1, 1)]), np.array([0.9, 0.8], F32), np.array([2, 2]), 0.5, 0.0, fast_nms=True)
     assert len(l) == 1
+
+
+def test_rotated_nms_uses_the_rotated_footprints():
+    b7 = lambda x, y, dx, dy, a: np.array([x, y, 0.0, dx, dy, 1.0, a], F32)
+    long_a, long_b = b7(0, 0, 4, 1, 0.0), b7(0, 0, 4, 1, np.pi / 2)            # a cross: intersection 1, IoU 1/7
+    boxes = np.stack([long_a, long_b, b7(0.1, 0, 4, 1, 0.02), b7(9, 9, 1, 1, 0.3)])
+    scores = np.array([0.9, 0.8, 0.7, 0.6], F32)
+    assert pp.nms3d_rotated(boxes, scores, 0.5).tolist() == [0, 1, 3]           # the nearly parallel box 2 is suppressed by box 0
+    assert pp.nms3d_rotated(boxes, scores, 0.1).tolist() == [0, 3]              # at 0.1 the crossing box (IoU 0.143) goes too
+    b, s, l = pp.multiclass_nms(boxes, scores, np.array([1, 1, 2, 2]), 0.5, 0.0)
+    assert l.tolist() == [1, 1, 2, 2] and b.shape == (4, 7)                     # different classes never suppress each other

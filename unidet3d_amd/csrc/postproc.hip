@@ -62,6 +62,82 @@ __global__ __launch_bounds__(1024) void nms_k(const float* __restrict__ boxes, c
     }
 }
 
+// ---- rotated boxes: mmcv.ops.nms3d (unidet3d.py:626, with_yaw) -- greedy suppression by the BEV IoU of the rotated
+// rectangles (x, y, dx, dy, heading).  The intersection area is summed edge by edge (no vertex sorting, no arrays): every
+// edge of A is clipped to the inside of B (closed), every edge of B to the strict inside of A (so an edge shared by both
+// outlines counts once), and a clipped piece P0->P1 of a counter-clockwise outline contributes cross(P0, P1) / 2.
+__device__ __forceinline__ float clipped_edges_area(const float (&pa)[8], const float (&pb)[8], bool strict) {
+    float area = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float px = pa[2 * e], py = pa[2 * e + 1];
+        const float dx = pa[2 * ((e + 1) & 3)] - px, dy = pa[2 * ((e + 1) & 3) + 1] - py;
+        float t0 = 0.f, t1 = 1.f;
+        bool alive = true;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float ax = pb[2 * f], ay = pb[2 * f + 1];
+            const float ex = pb[2 * ((f + 1) & 3)] - ax, ey = pb[2 * ((f + 1) & 3) + 1] - ay;
+            const float n0 = ex * (py - ay) - ey * (px - ax);       // side of the edge's start, > 0 = inside
+            const float m = ex * dy - ey * dx;                       // change of the side along the edge
+            if (m == 0.f) {
+                alive = alive && (strict ? n0 > 0.f : n0 >= 0.f);
+            } else {
+                const float tc = -n0 / m;
+                if (m > 0.f) t0 = fmaxf(t0, tc); else t1 = fminf(t1, tc);
+            }
+        }
+        if (alive && t0 < t1) {
+            const float x0 = px + t0 * dx, y0 = py + t0 * dy, x1 = px + t1 * dx, y1 = py + t1 * dy;
+            area += 0.5f * (x0 * y1 - x1 * y0);
+        }
+    }
+    return area;
+}
+
+__global__ __launch_bounds__(1024) void nms_rot_k(const float* __restrict__ boxes, const int32_t* __restrict__ labels, int n, float thr,
+                                                  uint8_t* __restrict__ keep) {
+    extern __shared__ float sm[];
+    float* cor = sm;                     // [n][8] corners, counter-clockwise
+    float* ar = cor + 8 * n;
+    int* lab = reinterpret_cast<int*>(ar + n);
+    int* sup = lab + n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float* b = boxes + i * 7;
+        const float c = cosf(b[6]), s = sinf(b[6]), hx = 0.5f * b[3], hy = 0.5f * b[4];
+        const float sx[4] = {hx, -hx, -hx, hx}, sy[4] = {hy, hy, -hy, -hy};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            cor[i * 8 + 2 * v] = sx[v] * c - sy[v] * s + b[0];
+            cor[i * 8 + 2 * v + 1] = sx[v] * s + sy[v] * c + b[1];
+        }
+        ar[i] = b[3] * b[4];
+        lab[i] = labels[i]; sup[i] = 0;
+        keep[i] = 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        __syncthreads();
+        if (sup[i]) continue;
+        if (threadIdx.x == 0) keep[i] = 1;
+        const int li = lab[i];
+        const float ox = cor[i * 8], oy = cor[i * 8 + 1];           // coordinates relative to a corner of box i
+        float pa[8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { pa[2 * v] = cor[i * 8 + 2 * v] - ox; pa[2 * v + 1] = cor[i * 8 + 2 * v + 1] - oy; }
+        const float sa = ar[i];
+        for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+            if (lab[j] != li) break;
+            if (sup[j]) continue;
+            float pb[8];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { pb[2 * v] = cor[j * 8 + 2 * v] - ox; pb[2 * v + 1] = cor[j * 8 + 2 * v + 1] - oy; }
+            const float inter = fmaxf(clipped_edges_area(pa, pb, false) + clipped_edges_area(pb, pa, true), 0.f);
+            const float iou = inter / fmaxf(sa + ar[j] - inter, 1e-8f);
+            if (iou > thr) sup[j] = 1;
+        }
+    }
+}
+
 __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
     if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
     else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
@@ -136,6 +212,17 @@ static int launch_nms(int mode, const float* boxes, const int32_t* labels, int n
 
 int u3d_nms_bev(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
     return launch_nms(0, boxes, labels, n, iou_thr, keep, stream);
+}
+
+int u3d_nms_rotated(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
+    if (n < 0 || (n > 0 && (!boxes || !labels || !keep))) return U3D_EINVAL;
+    if (n == 0) return U3D_OK;
+    if (n > 1400) {
+        set_error("nms_rotated: %d boxes exceed the single-workgroup limit of 1400", n);
+        return U3D_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(nms_rot_k, dim3(1), dim3(1024), (size_t)n * 11 * sizeof(float), (hipStream_t)stream, boxes, labels, n, iou_thr, keep);
+    return check_launch("nms_rotated");
 }
 
 int u3d_nms_aligned3d(const float* corners, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {

@@ -161,23 +161,26 @@ def instance_boxes(vb: VoxelBatch, instance_ids: torch.Tensor, n_inst_total: int
 # ----------------------------------------------------------------------------------------
 def nms_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, iou_thr: float, score_thr: float,
                    fast_nms: bool = True):
-    """``UniDet3D._single_scene_multiclass_nms`` on yaw-free boxes (unidet3d/unidet3d.py:595-650): class by class
+    """``UniDet3D._single_scene_multiclass_nms`` (unidet3d/unidet3d.py:595-650): class by class
     (ascending id), boxes above ``score_thr`` visited by descending score, greedy suppression by the BEV IoU
     (``fast_nms``: mmcv ``nms3d_normal``) or by the 3-D IoU of the corner boxes (mmdet3d ``aligned_3d_nms`` on
-    ``_bbox_to_loss(boxes)``).  ``scores`` must already be sorted descending (they come from a sorted top-k).
+    ``_bbox_to_loss(boxes)``); 7-dof boxes go through mmcv ``nms3d`` (rotated BEV IoU) whatever ``fast_nms`` says.
+    ``scores`` must already be sorted descending (they come from a sorted top-k).
     Returns (bboxes, scores, labels) in the reference's output order."""
-    if bboxes.shape[1] != 6:
-        raise NotImplementedError('rotated boxes (mmcv nms3d) are not built')
+    if bboxes.shape[1] not in (6, 7):
+        raise ValueError('boxes must be (cx, cy, cz, dx, dy, dz[, heading])')
     sel = scores > score_thr
     bboxes, scores, labels = bboxes[sel], scores[sel], labels[sel]
     n = bboxes.shape[0]
     if n == 0:
-        return bboxes.new_zeros((0, 6)), bboxes.new_zeros((0,)), labels.new_zeros((0,))
+        return bboxes.new_zeros((0, bboxes.shape[1])), bboxes.new_zeros((0,)), labels.new_zeros((0,))
     order = torch.sort(labels, stable=True).indices            # (label asc, score desc)
     b = bboxes[order].contiguous().float()
     lab = labels[order].to(torch.int32).contiguous()
     keep = torch.empty(n, dtype=torch.uint8, device=b.device)
-    if fast_nms:
+    if b.shape[1] == 7:                                           # with_yaw: mmcv nms3d on the rotated BEV rectangles (:625-626)
+        L.call('u3d_nms_rotated', L.ptr(b), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+    elif fast_nms:
         L.call('u3d_nms_bev', L.ptr(b), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
     else:
         half = b[:, 3:] / 2                                      # _bbox_to_loss (criterion.py:180-198)

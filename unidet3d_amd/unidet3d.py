@@ -224,10 +224,14 @@ class UniDet3D(nn.Module):
         pred_bboxes = pred_bboxes[torch.div(topk_idx, num_classes, rounding_mode='floor')]
         nms_bboxes, nms_scores, nms_labels = ops.nms_multiclass(pred_bboxes, scores, labels, self.test_cfg['iou_thr'][idx],
                                                                 self.test_cfg['score_thr'], bool(self.fast_nms[idx]))
+        with_yaw = nms_bboxes.shape[1] == 7
         if self.use_superpoints[idx]:
+            if with_yaw:
+                raise NotImplementedError('superpoint trimming of rotated boxes (get_face_distances with yaw) is not built; '
+                                          'the reference configs pair angles=True with use_superpoints=False')
             nms_bboxes = ops.trim_boxes_by_superpoints(vb.points, plan.sp_offsets, plan.sp_points, n_sp0, nms_bboxes,
                                                        self.test_cfg['low_sp_thr'], self.test_cfg['up_sp_thr'])
-        boxes = DepthInstance3DBoxes(nms_bboxes, with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5))
+        boxes = DepthInstance3DBoxes(nms_bboxes, with_yaw=with_yaw, box_dim=nms_bboxes.shape[1], origin=(0.5, 0.5, 0.5))
         return [(boxes, nms_labels, nms_scores)]
 
     def predict(self, batch_inputs_dict, batch_data_samples, **kwargs):

@@ -266,11 +266,12 @@ int u3d_nms_aligned3d(const float* corners, const int32_t* labels, int n, float 
  * of the rotated rectangles; same ordering contract, n <= 1400. */
 int u3d_nms_rotated(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream);
 /* u3d_trim_boxes: replaces UniDet3D.trim_bboxes_by_superpoints + get_face_distances (unidet3d/unidet3d.py:540-593, :652-677)
- * for yaw-free boxes.  points: rows of >= 3 floats with leading dimension pt_ld; (sp_list, sp_offsets[S+1]): CSR of point
- * rows per superpoint (u3d_csr_build).  minmax [nb][6] receives (min xyz, max xyz) of the points selected for each box
+ * points: rows of >= 3 floats with leading dimension pt_ld; (sp_list, sp_offsets[S+1]): CSR of point rows per superpoint
+ * (u3d_csr_build).  boxes [nb][box_dim], box_dim = 6 (cx, cy, cz, dx, dy, dz) or 7 (+ heading: the point shift is rotated by
+ * -heading about z before the six face tests, as get_face_distances does).  minmax [nb][6] receives (min xyz, max xyz) of the points selected for each box
  * (+inf / -inf when none, as in the reference); centre = (max+min)/2 and size = max-min are left to the caller. */
 int u3d_trim_boxes(const float* points, int64_t pt_ld, const int32_t* sp_list, const int32_t* sp_offsets, int S,
-                   const float* boxes, int nb, float low_thr, float up_thr, float* minmax, u3d_stream_t stream);
+                   const float* boxes, int nb, int box_dim, float low_thr, float up_thr, float* minmax, u3d_stream_t stream);
 
 #ifdef __cplusplus
 }

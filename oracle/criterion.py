@@ -16,14 +16,14 @@ import torch.nn.functional as F
 
 
 class OBoxes:
-    """DepthInstance3DBoxes stand-in (axis-aligned, box_dim=6)."""
+    """DepthInstance3DBoxes stand-in: [n, 6] axis-aligned or [n, 7] with a heading (``with_yaw``)."""
 
-    def __init__(self, centers_sizes: torch.Tensor):
+    def __init__(self, centers_sizes: torch.Tensor, with_yaw: bool = False):
         t = centers_sizes.clone()
         if t.numel():
             t[:, 2] = t[:, 2] - t[:, 5] * 0.5       # origin (.5,.5,.5) -> (.5,.5,0)
         self.tensor = t
-        self.with_yaw = False
+        self.with_yaw = with_yaw
 
     @property
     def gravity_center(self):
@@ -37,7 +37,7 @@ class OBoxes:
     def __getitem__(self, idx):
         b = OBoxes.__new__(OBoxes)
         b.tensor = self.tensor[idx]
-        b.with_yaw = False
+        b.with_yaw = self.with_yaw
         return b
 
 
@@ -82,6 +82,15 @@ def bbox_to_loss(bbox):                        # criterion.py:180-198
                         bbox[..., 1] + bbox[..., 4] / 2, bbox[..., 2] + bbox[..., 5] / 2), dim=-1)
 
 
+def box_cost_loss(pred, target):
+    """bbox loss / cost on _bbox_to_loss boxes: axis-aligned DIoU (6 columns) or the rotated DIoU of
+    unidet3d/rotated_iou_loss.py:14-82 (7 columns; [..., 7] inputs are flattened to the [N, 7] form it takes)."""
+    if pred.shape[-1] == 7:
+        from . import rotated_iou as ri
+        return ri.rotated_diou_3d_loss(pred.reshape(-1, 7), target.reshape(-1, 7)).reshape(pred.shape[:-1])
+    return axis_aligned_diou_loss(pred, target)
+
+
 @torch.no_grad()
 def uni_matcher(scores, bboxes, gt_labels, gt_bboxes, query_masks, topk,
                 w_cls=0.5, w_box=2.0, inf=1e8):   # criterion.py:272-320
@@ -91,7 +100,7 @@ def uni_matcher(scores, bboxes, gt_labels, gt_bboxes, query_masks, topk,
     c_cls = -scores.softmax(-1)[:, gt_labels] * w_cls                       # :222-224
     pb = bboxes.unsqueeze(1).repeat(1, n_gts, 1)
     gb = gt_bboxes.unsqueeze(0).repeat(bboxes.shape[0], 1, 1)
-    c_box = axis_aligned_diou_loss(bbox_to_loss(pb), bbox_to_loss(gb)) * w_box   # :256-270
+    c_box = box_cost_loss(bbox_to_loss(pb), bbox_to_loss(gb)) * w_box      # :256-270
     cost = torch.stack([c_cls, c_box]).sum(0)
     cost = torch.where(query_masks.T, cost, torch.tensor(inf, dtype=cost.dtype))
     values = torch.topk(cost, topk + 1, dim=0, sorted=True, largest=False).values[-1:, :]
@@ -99,29 +108,35 @@ def uni_matcher(scores, bboxes, gt_labels, gt_bboxes, query_masks, topk,
     return ids[:, 0], ids[:, 1]
 
 
+def _gt_box_rows(b):
+    """criterion.py:87-91 / :117-122: gravity centre + (size[, heading])."""
+    return torch.cat((b.gravity_center, b.tensor[:, 3:] if b.with_yaw else b.tensor[:, 3:6]), dim=1)
+
+
 def layer_loss(cls_preds, pred_bboxes, insts, topk=6, loss_weight=(0.5, 1.0),
                non_object_weight=0.1, dataset_weight=1.0):   # criterion.py:44-143
+    """``topk`` / ``dataset_weight``: one value, or one per scene (the reference looks them up by dataset name :82,:104-105)."""
+    n = len(insts)
+    topk = list(topk) if isinstance(topk, (list, tuple)) else [topk] * n
+    dw = list(dataset_weight) if isinstance(dataset_weight, (list, tuple)) else [dataset_weight] * n
     indices = []
     for i, inst in enumerate(insts):
-        gtb = torch.cat((inst.bboxes_3d.gravity_center, inst.bboxes_3d.tensor[:, 3:6]), dim=1)
-        indices.append(uni_matcher(cls_preds[i], pred_bboxes[i], inst.labels_3d, gtb,
-                                   inst.query_masks, topk))
+        indices.append(uni_matcher(cls_preds[i], pred_bboxes[i], inst.labels_3d, _gt_box_rows(inst.bboxes_3d),
+                                   inst.query_masks, topk[i]))
     cls_losses = []
-    for cls_pred, inst, (iq, ig) in zip(cls_preds, insts, indices):
+    for w, cls_pred, inst, (iq, ig) in zip(dw, cls_preds, insts, indices):
         nc = cls_pred.shape[1] - 1
         tgt = cls_pred.new_full((len(cls_pred),), nc, dtype=torch.long)
         tgt[iq] = inst.labels_3d[ig]
-        cls_losses.append(dataset_weight * F.cross_entropy(
+        cls_losses.append(w * F.cross_entropy(
             cls_pred, tgt, cls_pred.new_tensor([1] * nc + [non_object_weight])))
     cls_loss = torch.mean(torch.stack(cls_losses))
     box_losses = []
-    for bbox, inst, (iq, ig) in zip(pred_bboxes, insts, indices):
+    for w, bbox, inst, (iq, ig) in zip(dw, pred_bboxes, insts, indices):
         if len(inst) == 0 or len(iq) == 0:
             continue
-        tb = inst.bboxes_3d[ig]
-        tb = torch.cat((tb.gravity_center, tb.tensor[:, 3:6]), dim=1)
-        box_losses.append(dataset_weight * axis_aligned_diou_loss(
-            bbox_to_loss(bbox[iq]), bbox_to_loss(tb)).mean())
+        tb = _gt_box_rows(inst.bboxes_3d[ig])
+        box_losses.append(w * box_cost_loss(bbox_to_loss(bbox[iq]), bbox_to_loss(tb)).mean())
     box_loss = torch.stack(box_losses).mean() if box_losses else 0
     return loss_weight[0] * cls_loss + loss_weight[1] * box_loss
 
@@ -131,6 +146,19 @@ def criterion(pred, insts, **kw):              # criterion.py:145-178 (iter_matc
     for aux in pred['aux_outputs']:
         loss = loss + layer_loss(aux['cls_preds'], aux['bboxes'], insts, **kw)
     return loss
+
+
+def get_targets(points, gt_centers, topk):     # unidet3d.py:371-409
+    """[n_boxes, n_points] bool: every point goes to its nearest box centre among the boxes that count it among their
+    ``topk`` nearest points (strictly closer than the (topk+1)-th)."""
+    float_max = points.new_tensor(1e8)
+    n_boxes = len(gt_centers)
+    d = torch.sum(torch.pow(gt_centers[None].expand(len(points), n_boxes, 3) - points[:, None].expand(len(points), n_boxes, 3), 2), dim=-1)
+    kth = torch.topk(d, min(topk + 1, len(d)), largest=False, dim=0).values[-1]
+    d = torch.where(d < kth.unsqueeze(0), d, float_max)
+    min_values, min_ids = d.min(dim=1)
+    min_inds = torch.where(min_values < float_max, min_ids, n_boxes)
+    return F.one_hot(min_inds, num_classes=n_boxes + 1)[:, :-1].bool().T
 
 
 # ---- GT preparation (unidet3d.py:220-275, transforms_3d.py:197-215) -------------

@@ -152,7 +152,11 @@ def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, i
         if cb.shape[1] == 7:                # with_yaw (unidet3d.py:625-626)
             k = nms3d_rotated(cb, cs, iou_thr)
         else:
-            k = nms3d_normal(cb, cs, iou_thr) if fast_nms else aligned_3d_nms(bbox_to_loss(cb), cs, cl, iou_thr)
+            if fast_nms:                    # :629-633: a zero heading is appended and the 7-column boxes are what is returned
+                cb = np.concatenate((cb, np.zeros_like(cb[:, :1])), 1)
+                k = nms3d_normal(cb, cs, iou_thr)
+            else:
+                k = aligned_3d_nms(bbox_to_loss(cb), cs, cl, iou_thr)
         out_b.append(cb[k]); out_s.append(cs[k]); out_l.append(cl[k])
     if not out_b:
         return np.zeros((0, bboxes.shape[1]), F32), np.zeros((0,), F32), np.zeros((0,), np.int64)
@@ -160,11 +164,19 @@ def multiclass_nms(bboxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, i
 
 
 def inside_boxes(points: np.ndarray, boxes: np.ndarray) -> np.ndarray:
-    """[n_boxes, n_points] bool: min face distance > 0 with yaw 0 (get_face_distances :652-677, :569)."""
+    """[n_boxes, n_points] bool: min face distance > 0 (get_face_distances :652-677, :569).  7-column boxes carry a heading:
+    the shift p - c is rotated by -yaw about z (mmdet3d rotation_3d_in_axis: x' = x cos a - y sin a, y' = x sin a + y cos a,
+    a = -yaw); a zero heading leaves the shift bit-identical."""
     p = points[:, None, :3].astype(F32)                  # [P,1,3]
     c = boxes[None, :, :3].astype(F32)                   # [1,B,3]
     h = (boxes[None, :, 3:6].astype(F32) / F32(2)).astype(F32)
-    shift = (p - c).astype(F32)                          # rotation by -0 is the identity
+    shift = (p - c).astype(F32)
+    if boxes.shape[1] == 7:
+        a = (-boxes[:, 6]).astype(F32)
+        cs, sn = np.cos(a).astype(F32)[None], np.sin(a).astype(F32)[None]
+        sx = (shift[..., 0] * cs).astype(F32) - (shift[..., 1] * sn).astype(F32)
+        sy = (shift[..., 0] * sn).astype(F32) + (shift[..., 1] * cs).astype(F32)
+        shift = np.stack((sx.astype(F32), sy.astype(F32), shift[..., 2]), -1)
     cen = (c + shift).astype(F32)
     dmin = ((cen - c).astype(F32) + h).astype(F32)
     dmax = ((c + h).astype(F32) - cen).astype(F32)
@@ -183,7 +195,7 @@ def trim_boxes(points: np.ndarray, sp_pts_mask: np.ndarray, boxes: np.ndarray, l
     inside[sp_del[:, sp_pts_mask]] = False
     sp_add = sp_inside > F32(up)
     inside[sp_add[:, sp_pts_mask]] = True
-    out = np.zeros((len(boxes), 6), F32)
+    out = np.zeros((len(boxes), 6), F32)      # always axis-aligned (centre, size), :583-592
     for b in range(len(boxes)):
         sel = pts[inside[b]]
         mx = sel.max(axis=0) if len(sel) else np.full(3, -np.inf, F32)

@@ -1,0 +1,376 @@
+"""Generate tests/golden/ref_*.{npz,json} by running the REAL reference files (build container only; needs /root/reference).
+
+What is executed is the reference's own code: ``unidet3d/criterion.py`` (UniDet3DCriterion, UniMatcher, both cost classes,
+_bbox_to_loss), ``axis_aligned_iou_loss.py``, ``rotated_iou_loss.py``, ``indoor_eval.py``, ``transforms_3d.py``,
+``spconv_unet.py`` (module tree only) and -- by AST extraction, because ``unidet3d.py`` imports spconv / MinkowskiEngine at
+module level -- ``UniDet3D.get_targets``, ``_select_queries``, ``_init_layers``, ``trim_bboxes_by_superpoints``,
+``_single_scene_multiclass_nms`` is NOT covered (mmcv NMS kernels).  Imports of packages that are not installed are satisfied
+by tools/ref_stubs.py; each fixture carries a ``stubs`` entry naming the restated third-party arithmetic its values passed
+through (empty = none: the values are the reference's own arithmetic only).
+
+Fixtures hold arrays / key lists only -- no reference source text.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, '..', 'tests'))
+import ref_stubs as RS  # noqa: E402
+
+GOLD = os.path.join(HERE, '..', 'tests', 'golden')
+RS.install()
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+# ------------------------------------------------------------------------------------------------ criterion
+SCANNET_CRIT = dict(
+    type='UniDet3DCriterion', datasets=['scannet'], datasets_weights=[1],
+    bbox_loss_simple=dict(type='UniDet3DAxisAlignedIoULoss', mode='diou', reduction='none'),
+    bbox_loss_rotated=dict(type='UniDet3DRotatedIoU3DLoss', mode='diou', reduction='none'),
+    matcher=dict(type='UniMatcher', costs=[
+        dict(type='QueryClassificationCost', weight=0.5),
+        dict(type='BboxCostJointTraining', weight=2.0,
+             loss_simple=dict(type='UniDet3DAxisAlignedIoULoss', mode='diou', reduction='none'),
+             loss_rotated=dict(type='UniDet3DRotatedIoU3DLoss', mode='diou', reduction='none'))]),
+    loss_weight=[0.5, 1.0], non_object_weight=0.1, topk=[6], iter_matcher=True)
+
+
+def _rand_boxes(n, dof, g):
+    c = torch.rand(n, 3, generator=g) * 3
+    s = torch.rand(n, 3, generator=g) * 1.2 + 0.2
+    if dof == 7:
+        return torch.cat((c, s, (torch.rand(n, 1, generator=g) - 0.5) * 3.0), 1)
+    return torch.cat((c, s), 1)
+
+
+def _scene(n, gts, n_cls, dof, g, sparse_gt=None):
+    """Random predictions near random GT so that IoUs are non-trivial; returns dict of tensors."""
+    gtb = _rand_boxes(gts, dof, g)
+    labels = torch.randint(0, n_cls, (gts,), generator=g)
+    qm = torch.rand(gts, n, generator=g) < 0.45
+    if gts:
+        qm[0, :] = False
+        qm[0, :3] = True                       # a GT that allows fewer queries than topk + 1
+        if gts > 1:
+            qm[1] = qm[min(2, gts - 1)]        # two GTs competing for the same queries (duplicate idx_q)
+    if sparse_gt is not None:
+        qm[sparse_gt] = False                  # a GT no query may take
+    return dict(gtb=gtb, labels=labels, qm=qm)
+
+
+def _preds(n, n_cls, dof, gtb, g, L):
+    cls, box = [], []
+    for _ in range(L):
+        cls.append(torch.randn(n, n_cls + 1, generator=g) * 1.5)
+        b = _rand_boxes(n, dof, g)
+        if len(gtb):                            # half of the queries sit near a GT box
+            pick = torch.randint(0, len(gtb), (n,), generator=g)
+            near = gtb[pick] + torch.randn(n, dof, generator=g) * 0.08
+            near[:, 3:6] = near[:, 3:6].abs() + 0.05
+            use = torch.rand(n, generator=g) < 0.5
+            b = torch.where(use[:, None], near, b)
+        box.append(b)
+    return cls, box
+
+
+def gen_criterion(out):
+    crit_mod = RS.ref('criterion')
+    RS.ref('axis_aligned_iou_loss')
+    RS.ref('rotated_iou_loss')
+    Inst = RS.ref('structures').InstanceData_
+    g = torch.Generator().manual_seed(2025)
+
+    # ---- M0: UniMatcher with the class cost only: no stubbed arithmetic at all ---------------------------
+    m = crit_mod.UniMatcher(costs=[dict(type='QueryClassificationCost', weight=0.5)])
+    sc = _scene(37, 6, 18, 6, g)
+    scores = torch.randn(37, 19, generator=g)
+    iq, ig = m(Inst(scores=scores), Inst(labels=sc['labels'], query_masks=sc['qm']), 6)
+    out.update({'M0.scores': _np(scores), 'M0.labels': _np(sc['labels']), 'M0.qm': _np(sc['qm']), 'M0.iq': _np(iq), 'M0.ig': _np(ig)})
+    cost = crit_mod.QueryClassificationCost(0.5)(Inst(scores=scores), Inst(labels=sc['labels']))
+    out['M0.cost'] = _np(cost)
+
+    def run(tag, cfg, names, specs, L):
+        crit = RS.MODELS.build(cfg)
+        rec = []
+        orig = crit.matcher.__call__
+
+        class Spy:
+            costs, inf = crit.matcher.costs, crit.matcher.inf
+
+            def __call__(self, p, gt, topk, **kw):
+                r = orig(p, gt, topk, **kw)
+                rec.append((r[0].clone(), r[1].clone()))
+                return r
+        crit.matcher = Spy()
+        scenes, cls_l, box_l = [], [[] for _ in range(L)], [[] for _ in range(L)]
+        insts = []
+        for i, (n, gts, dof, sparse) in enumerate(specs):
+            idx = cfg['datasets'].index(names[i])
+            n_cls = specs_ncls[names[i]]
+            s = _scene(n, gts, n_cls, dof, g, sparse)
+            c, b = _preds(n, n_cls, dof, s['gtb'], g, L)
+            for l in range(L):
+                cls_l[l].append(c[l].requires_grad_())
+                box_l[l].append(b[l].requires_grad_())
+            bx = RS.Boxes(s['gtb'], box_dim=dof, with_yaw=dof == 7, origin=(0.5, 0.5, 0.5))
+            insts.append(Inst(labels_3d=s['labels'], bboxes_3d=bx, query_masks=s['qm']))
+            scenes.append(s)
+            out[f'{tag}.s{i}.gtb'] = _np(s['gtb']); out[f'{tag}.s{i}.labels'] = _np(s['labels']); out[f'{tag}.s{i}.qm'] = _np(s['qm'])
+        pred = dict(cls_preds=cls_l[0], bboxes=box_l[0],
+                    aux_outputs=[dict(cls_preds=cls_l[l], bboxes=box_l[l]) for l in range(1, L)])
+        loss = crit(pred, insts, names)['det_loss']
+        loss.backward()
+        out[f'{tag}.loss'] = np.float64(loss.item())
+        out[f'{tag}.names'] = np.array(names)
+        k = 0
+        for l in range(L):
+            for i in range(len(specs)):
+                out[f'{tag}.L{l}.cls{i}'] = _np(cls_l[l][i]); out[f'{tag}.L{l}.box{i}'] = _np(box_l[l][i])
+                out[f'{tag}.L{l}.gcls{i}'] = _np(cls_l[l][i].grad)
+                out[f'{tag}.L{l}.gbox{i}'] = _np(box_l[l][i].grad) if box_l[l][i].grad is not None else np.zeros_like(_np(box_l[l][i]))
+                out[f'{tag}.L{l}.iq{i}'] = _np(rec[k][0]); out[f'{tag}.L{l}.ig{i}'] = _np(rec[k][1])
+                k += 1
+        assert k == len(rec)
+        # per-layer loss of the final layer alone (get_layer_loss), for finer-grained checks
+        out[f'{tag}.layer0_loss'] = np.float64(crit.get_layer_loss(
+            dict(cls_preds=[t.detach() for t in cls_l[0]], bboxes=[t.detach() for t in box_l[0]]), insts, names).item())
+
+    specs_ncls = {'scannet': 18, 'arkitscenes': 17, 's3dis': 5}
+    # C1: the ScanNet criterion of configs/unidet3d_1xb8_scannet.py:60-88; scene 1 has no GT, scene 2 has a GT nobody may take
+    run('C1', SCANNET_CRIT, ['scannet'] * 3, [(40, 5, 6, None), (25, 0, 6, None), (33, 7, 6, 4)], 3)
+    # C2: joint criterion: per-dataset weights / topk, 6-dof S3DIS + 7-dof ARKitScenes scenes (rotated DIoU through the mmcv stub)
+    joint = dict(SCANNET_CRIT, datasets=['scannet', 's3dis', 'arkitscenes'], datasets_weights=[1, 0.7, 2.5], topk=[6, 4, 3])
+    run('C2', joint, ['arkitscenes', 'scannet', 's3dis', 'arkitscenes'], [(21, 4, 7, None), (30, 3, 6, None), (18, 2, 6, None), (16, 0, 7, None)], 2)
+    # C3: no scene of the batch has a match -> bbox_loss is the Python int 0 (criterion.py:137-138)
+    run('C3', SCANNET_CRIT, ['scannet'] * 2, [(12, 0, 6, None), (9, 0, 6, None)], 2)
+    out['stubs'] = np.array(['mmdet3d.AxisAlignedBboxOverlaps3D', 'mmdet.weighted_loss', 'mmcv.diff_iou_rotated (C2 only)',
+                             'M0.*: none'])
+
+    # ---- pure loss functions of the reference's own files ------------------------------------------------
+    aal = RS.ref('axis_aligned_iou_loss')
+    p = RS.ref('criterion')._bbox_to_loss(_rand_boxes(50, 6, g)); t = RS.ref('criterion')._bbox_to_loss(_rand_boxes(50, 6, g) * 0.9)
+    out['F.diou_p'] = _np(p); out['F.diou_t'] = _np(t)
+    out['F.diou'] = _np(aal.axis_aligned_diou_loss(p, t, reduction='none'))
+    pm = p[:, None].expand(50, 4, 6); tm = t[None, :4].expand(50, 4, 6)
+    out['F.diou_matrix'] = _np(aal.axis_aligned_diou_loss(pm, tm, reduction='none'))      # the [:, 0] broadcast quirk
+    rl = RS.ref('rotated_iou_loss')
+    b1 = _rand_boxes(40, 7, g); b2 = b1 + torch.randn(40, 7, generator=g) * 0.15; b2[:, 3:6] = b2[:, 3:6].abs() + 0.05
+    out['F.rot_b1'] = _np(b1); out['F.rot_b2'] = _np(b2)
+    out['F.rot_diou'] = _np(rl.diff_diou_rotated_3d(b1[None], b2[None])[0])
+
+
+# ------------------------------------------------------------------------------------------------ detector methods (AST)
+def gen_detector(out):
+    g = torch.Generator().manual_seed(77)
+    path = os.path.join(RS.REF, 'unidet3d.py')
+    ns = {'torch': torch, 'scatter_mean': RS.scatter_mean, 'DepthInstance3DBoxes': RS.Boxes, 'Tensor': torch.Tensor,
+          'rotation_3d_in_axis': RS.rotation_3d_in_axis}
+    RS.extract_defs(path, ['get_face_distances'], ns)
+    RS.extract_defs(path, ['get_targets', '_select_queries', 'trim_bboxes_by_superpoints', 'get_bboxes_by_masks'], ns, cls='UniDet3D')
+
+    class Self:
+        query_thr = 30
+
+        class test_cfg:
+            low_sp_thr, up_sp_thr = 0.18, 0.81
+    s = Self()
+    # get_targets (unidet3d.py:371-409): [g, n] bool; case b has fewer points than topk + 1
+    for tag, n, gts, topk in (('T0', 60, 7, 6), ('T1', 5, 3, 6), ('T2', 40, 1, 6)):
+        pts = torch.rand(n, 3, generator=g) * 4
+        gb = RS.Boxes(_rand_boxes(gts, 6, g) * torch.tensor([1.3, 1.3, 1.3, 1, 1, 1.0]), box_dim=6, with_yaw=False, origin=(0.5, 0.5, 0.5))
+        out[f'{tag}.pts'] = _np(pts); out[f'{tag}.centers'] = _np(gb.gravity_center); out[f'{tag}.sizes'] = _np(gb.tensor[:, 3:6])
+        out[f'{tag}.topk'] = np.int64(topk)
+        out[f'{tag}.targets'] = _np(ns['get_targets'](s, pts, gb, topk))
+    # _select_queries (unidet3d.py:182-218) with the permutation recorded
+    Inst = RS.ref('structures').InstanceData_
+    sizes, gts = [50, 20, 31], [4, 2, 3]
+    x = [torch.randn(n, 32, generator=g) for n in sizes]
+    insts = [Inst(sp_centers=torch.randn(n, 3, generator=g), sp_masks=torch.rand(k, n, generator=g) < 0.3) for n, k in zip(sizes, gts)]
+    for i in range(3):
+        out[f'Q.x{i}'] = _np(x[i]); out[f'Q.centers{i}'] = _np(insts[i].sp_centers); out[f'Q.sp_masks{i}'] = _np(insts[i].sp_masks)
+    perms = []
+    real = torch.randperm
+
+    def fake(n, **kw):
+        p = real(n, generator=g)
+        perms.append(p)
+        return p
+    torch.randperm = fake
+    try:
+        q, c, gi = ns['_select_queries'](s, x, insts)
+    finally:
+        torch.randperm = real
+    out['Q.query_thr'] = np.int64(s.query_thr)
+    pi = iter(perms)
+    for i in range(3):
+        out[f'Q.perm{i}'] = _np(next(pi)[:s.query_thr]) if sizes[i] > s.query_thr else np.zeros(0, np.int64)
+        out[f'Q.q{i}'] = _np(q[i]); out[f'Q.c{i}'] = _np(c[i]); out[f'Q.qm{i}'] = _np(gi[i].query_masks)
+    # get_bboxes_by_masks (unidet3d.py:220-256)
+    pts = torch.rand(500, 3, generator=g) * 5
+    masks = torch.nn.functional.one_hot(torch.randint(0, 6, (500,), generator=g), 6).T.bool()[:5]
+    bb = ns['get_bboxes_by_masks'](s, masks, pts)
+    out['B.pts'] = _np(pts); out['B.masks'] = _np(masks); out['B.centers'] = _np(bb.gravity_center); out['B.sizes'] = _np(bb.tensor[:, 3:6])
+    # trim_bboxes_by_superpoints + get_face_distances (unidet3d.py:540-593, :652-677), yaw-free and rotated boxes.
+    # Points within 1e-4 of a box face and superpoints whose inside ratio is within 0.02 of a threshold are removed so that
+    # the discrete decisions do not depend on the last bit of sin / cos.
+    for tag, dof in (('P6', 6), ('P7', 7)):
+        n_pts, n_sp, n_box = 3000, 60, 24
+        pts = torch.rand(n_pts, 3, generator=g) * 3
+        sp = (pts[:, 0] // 0.6).long() * 12 + (pts[:, 1] // 0.6).long() * 2 + (pts[:, 2] > 1.5).long()
+        sp = torch.unique(sp, return_inverse=True)[1]
+        boxes = _rand_boxes(n_box, dof, g)
+        boxes[:, :3] = torch.rand(n_box, 3, generator=g) * 3
+        boxes[-1, 3:6] = 0.01                                # a box no point falls into
+        b7 = boxes if dof == 7 else torch.cat((boxes, torch.zeros(n_box, 1)), 1)
+        fd = ns['get_face_distances'](pts.double()[:, None].expand(n_pts, n_box, 3), b7.double()[None].expand(n_pts, n_box, 7))
+        keep = (fd.min(-1).values.abs() > 1e-4).all(1)
+        pts, sp = pts[keep], torch.unique(sp[keep], return_inverse=True)[1]
+        inside = (ns['get_face_distances'](pts.double()[:, None].expand(len(pts), n_box, 3), b7.double()[None].expand(len(pts), n_box, 7)).min(-1).values > 0).T
+        ratio = RS.scatter_mean(inside.double(), sp, dim=-1)
+        bad = ((ratio - 0.18).abs() < 0.02) | ((ratio - 0.81).abs() < 0.02)
+        okb = ~bad.any(1)
+        boxes = boxes[okb]
+        (bx, lab, scr), = ns['trim_bboxes_by_superpoints'](s, sp, pts, boxes, torch.arange(len(boxes)), torch.ones(len(boxes)))
+        out[f'{tag}.pts'] = _np(pts); out[f'{tag}.sp'] = _np(sp); out[f'{tag}.boxes'] = _np(boxes)
+        out[f'{tag}.centers'] = _np(bx.gravity_center); out[f'{tag}.sizes'] = _np(bx.tensor[:, 3:6])
+        b7 = boxes if dof == 7 else torch.cat((boxes, torch.zeros(len(boxes), 1)), 1)
+        out[f'{tag}.face'] = _np(ns['get_face_distances'](pts[:64, None].expand(64, len(boxes), 3), b7[None].expand(64, len(boxes), 7)))
+    out['stubs'] = np.array(['torch_scatter.scatter_mean (P6, P7)', 'mmdet3d.rotation_3d_in_axis (P6, P7)', 'T*, Q*, B*: none'])
+
+
+# ------------------------------------------------------------------------------------------------ module trees
+def gen_keys():
+    """state_dict key -> shape of the reference's module tree (spconv_unet.py:108-203, unidet3d.py:95-111, encoder.py:131-163)."""
+    from torch import nn
+    unet = RS.ref('spconv_unet').SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True)
+    enc = RS.ref('encoder').UniDet3DEncoder(
+        num_layers=6, datasets_classes=[['c%d' % i for i in range(18)]], in_channels=32, d_model=256, num_heads=8, hidden_dim=1024,
+        dropout=0.0, activation_fn='gelu', datasets=['scannet'], angles=[False])
+    import spconv.pytorch as spconv
+    import functools
+    ns = {'spconv': spconv, 'nn': nn, 'functools': functools, 'torch': torch}
+    RS.extract_defs(os.path.join(RS.REF, 'unidet3d.py'), ['_init_layers'], ns, cls='UniDet3D')
+
+    class Det(nn.Module):
+        use_sync_bn = True
+    det = Det()
+    ns['_init_layers'](det, 6, 32)
+    det.unet, det.decoder = unet, enc
+    keys = {k: list(v.shape) for k, v in det.state_dict().items()}
+    tree = {'keys': keys, 'n_params': int(sum(p.numel() for p in det.parameters())),
+            'norm_types': sorted({type(m).__name__ for m in det.modules() if 'Norm' in type(m).__name__}),
+            'stubs': ['spconv.weight_shape']}
+    json.dump(tree, open(os.path.join(GOLD, 'ref_state_dict_keys.json'), 'w'), indent=0, sort_keys=True)
+    print('state_dict keys:', len(keys), 'params:', tree['n_params'])
+
+
+# ------------------------------------------------------------------------------------------------ evaluation
+def gen_eval(out):
+    ie = RS.ref('indoor_eval')
+    rng = np.random.default_rng(5)
+    n_img, n_cls = 6, 5
+    gt_annos, dt_annos = [], []
+    for i in range(n_img):
+        ng = int(rng.integers(0, 6))
+        gc = rng.uniform(0, 4, (ng, 3)); gs = rng.uniform(0.3, 1.2, (ng, 3))
+        gl = rng.integers(0, n_cls, ng)
+        gt = RS.Boxes(np.concatenate((gc, gs, np.zeros((ng, 1))), 1), box_dim=7, with_yaw=False, origin=(0.5, 0.5, 0.5))
+        nd = int(rng.integers(0, 14))
+        pick = rng.integers(0, max(ng, 1), nd)
+        dc = (gc[pick] if ng else rng.uniform(0, 4, (nd, 3))) + rng.normal(0, 0.15, (nd, 3))
+        dsz = (gs[pick] if ng else rng.uniform(0.3, 1.2, (nd, 3))) * rng.uniform(0.7, 1.3, (nd, 3))
+        dl = np.where(rng.random(nd) < 0.75, gl[pick] if ng else rng.integers(0, n_cls, nd), rng.integers(0, n_cls, nd))
+        dscore = rng.random(nd).astype(np.float32)
+        dt = RS.Boxes(np.concatenate((dc, dsz, np.zeros((nd, 1))), 1), box_dim=7, with_yaw=False, origin=(0.5, 0.5, 0.5))
+        gt_annos.append(dict(gt_bboxes_3d=gt, gt_labels_3d=gl.tolist()))
+        dt_annos.append(dict(labels_3d=torch.from_numpy(dl.astype(np.int64)), bboxes_3d=dt, scores_3d=torch.from_numpy(dscore)))
+        out[f'E.gt_box{i}'] = np.concatenate((gc, gs), 1).astype(np.float32); out[f'E.gt_lab{i}'] = gl.astype(np.int64)
+        out[f'E.dt_box{i}'] = np.concatenate((dc, dsz), 1).astype(np.float32); out[f'E.dt_lab{i}'] = dl.astype(np.int64)
+        out[f'E.dt_score{i}'] = dscore
+    label2cat = {i: f'cls{i}' for i in range(n_cls)}
+    ret = ie.indoor_eval(gt_annos, dt_annos, [0.25, 0.5], label2cat, box_mode_3d=None)
+    out['E.n_img'] = np.int64(n_img); out['E.n_cls'] = np.int64(n_cls)
+    out['E.ret_keys'] = np.array(sorted(ret.keys())); out['E.ret_vals'] = np.array([ret[k] for k in sorted(ret.keys())], np.float64)
+    rec = np.array([0.1, 0.1, 0.4, 0.4, 0.7, 0.9]); prec = np.array([1.0, 0.5, 0.66, 0.5, 0.6, 0.4])
+    out['E.ap_rec'] = rec; out['E.ap_prec'] = prec
+    out['E.ap_area'] = ie.average_precision(rec, prec); out['E.ap_11'] = ie.average_precision(rec, prec, mode='11points')
+    out['stubs'] = np.array(['mmdet3d.boxes.overlaps'])
+
+
+# ------------------------------------------------------------------------------------------------ transforms
+def gen_transforms(out):
+    T = RS.ref('transforms_3d')
+    rng = np.random.default_rng(11)
+
+    class Pts:
+        def __init__(self, a):
+            self.tensor = torch.from_numpy(a)
+
+        def __len__(self):
+            return len(self.tensor)
+
+        def __getitem__(self, idx):
+            return Pts(self.tensor[idx].numpy())
+
+        @property
+        def shape(self):
+            return self.tensor.shape
+    n = 4000
+    xyz = rng.uniform(-2, 3, (n, 3)).astype(np.float32)
+    pts = np.concatenate((xyz, rng.uniform(0, 255, (n, 3)).astype(np.float32)), 1)
+    out['X.points'] = pts
+    # ElasticTransfrom (transforms_3d.py:12-83), config values configs/unidet3d_1xb8_scannet.py (gran [6, 20], mag [40, 160], voxel 0.02)
+    for tag, p in (('X.elastic', 1.0), ('X.elastic_off', 0.0)):
+        np.random.seed(1234)
+        et = T.ElasticTransfrom(gran=[6, 20], mag=[40, 160], voxel_size=0.02, p=p)
+        out[tag] = et.transform(dict(points=Pts(pts.copy())))['elastic_coords']
+    # PointDetClassMappingScanNet (transforms_3d.py:148-228)
+    sem = rng.integers(0, 21, n)                # 0, 1 = wall, floor (stuff); 20 = unlabeled (num_classes)
+    inst = rng.integers(0, 9, n) * 3 + 2        # non-contiguous instance ids
+    sem = np.array([0, 5, 1, 7, 20, 3, 9, 12, 4])[(inst - 2) // 3]      # one semantic label per instance (wall, floor, unlabeled included)
+    sp = rng.integers(0, 150, n)
+    sp = np.unique(sp, return_inverse=True)[1]
+    d = T.PointDetClassMappingScanNet(num_classes=20, stuff_classes=[0, 1]).transform(
+        dict(pts_instance_mask=inst.copy(), pts_semantic_mask=sem.copy(), sp_pts_mask=sp.copy()))
+    out['X.sn.inst'] = inst; out['X.sn.sem'] = sem; out['X.sn.sp'] = sp
+    out['X.sn.out_inst'] = d['pts_instance_mask']; out['X.sn.out_labels'] = d['gt_labels_3d']; out['X.sn.out_sp_masks'] = _np(d['gt_sp_masks'])
+    # PointDetClassMappingS3DIS (transforms_3d.py:86-146)
+    inst3 = rng.integers(1, 8, n)
+    sem3 = np.array([0, 7, 2, 9, 10, 7, 12, 11])[inst3]
+    d3 = T.PointDetClassMappingS3DIS(classes=[7, 8, 9, 10, 11]).transform(
+        dict(pts_instance_mask=inst3.copy(), pts_semantic_mask=sem3.copy(), sp_pts_mask=sp.copy()))
+    out['X.s3.inst'] = inst3; out['X.s3.sem'] = sem3
+    out['X.s3.out_inst'] = d3['pts_instance_mask']; out['X.s3.out_labels'] = _np(d3['gt_labels_3d']); out['X.s3.out_sp_masks'] = _np(d3['gt_sp_masks'])
+    # PointSample_ (transforms_3d.py:231-295)
+    np.random.seed(99)
+    ps = T.PointSample_(num_points=1500)
+    inst_s = d['pts_instance_mask'].copy()
+    dd = ps.transform(dict(points=Pts(pts.copy()), pts_instance_mask=inst_s, pts_semantic_mask=sem.copy(), sp_pts_mask=sp.copy()))
+    out['X.ps.in_inst'] = d['pts_instance_mask']
+    out['X.ps.points'] = _np(dd['points'].tensor); out['X.ps.inst'] = dd['pts_instance_mask']; out['X.ps.sem'] = dd['pts_semantic_mask']
+    out['X.ps.sp'] = dd['sp_pts_mask']
+    out['stubs'] = np.array(['torch_scatter.scatter_mean (sn / s3 sp_masks)'])
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    for name, fn in (('ref_criterion', gen_criterion), ('ref_detector', gen_detector), ('ref_eval', gen_eval),
+                     ('ref_transforms', gen_transforms)):
+        out = {}
+        fn(out)
+        path = os.path.join(GOLD, name + '.npz')
+        np.savez_compressed(path, **out)
+        print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays')
+    gen_keys()
+
+
+if __name__ == '__main__':
+    main()

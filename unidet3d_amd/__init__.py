@@ -10,5 +10,6 @@ from .criterion import (UniDet3DCriterion, UniDet3DAxisAlignedIoULoss, UniDet3DR
                         UniMatcher, QueryClassificationCost, BboxCostJointTraining)
 from .unidet3d import UniDet3D  # noqa: F401
 from .structures import InstanceData_  # noqa: F401
+from . import transforms, evaluation  # noqa: F401  (registers the pipeline transforms)
 
 __version__ = '0.1.0'

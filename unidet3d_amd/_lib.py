@@ -48,7 +48,7 @@ PROTOTYPES = {
     'u3d_nms_bev': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     'u3d_nms_aligned3d': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     'u3d_nms_rotated': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
-    'u3d_trim_boxes': (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp]),
+    'u3d_trim_boxes': (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _f32, _vp, _vp]),
     'u3d_weight_pack': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_weight_transpose': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),

@@ -256,7 +256,10 @@ class UniDet3DCriterion:
             loss_fn = self.bbox_loss_rotated if tgt.shape[1] == 7 else self.bbox_loss_simple
             bbox_losses.append(weight * loss_fn(_bbox_to_loss(bbox[idx_q]), _bbox_to_loss(tgt)).mean())
         cls_loss = torch.mean(torch.stack(cls_losses))
-        bbox_loss = torch.stack(bbox_losses).mean() if bbox_losses else 0
+        # no match anywhere in the batch: the reference adds the Python int 0 (criterion.py:137-138).  Same value here, but
+        # connected to the graph so that every parameter receives a gradient on every rank (the data-parallel bucket
+        # schedule relies on it)
+        bbox_loss = torch.stack(bbox_losses).mean() if bbox_losses else sum(b.sum() for b in pred_bboxes) * 0
         return self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss
 
     # ---- packed fast path ---------------------------------------------------------------------

@@ -156,12 +156,17 @@ __global__ void trim_init_k(float* __restrict__ mm, int nb) {
 // so the wave knows the inside ratio of (box, s) after one pass and can apply the delete / add rule right away.
 __global__ __launch_bounds__(64) void trim_k(const float* __restrict__ points, int64_t ld, const int32_t* __restrict__ list,
                                              const int32_t* __restrict__ offsets, int nbt, const float* __restrict__ boxes, int nb,
-                                             float low, float up, float* __restrict__ mm) {
+                                             int box_dim, float low, float up, float* __restrict__ mm) {
     const int s = blockIdx.x / nbt, b = (blockIdx.x % nbt) * 64 + threadIdx.x;
     const int o0 = offsets[s], o1 = offsets[s + 1];
     if (o0 >= o1 || b >= nb) return;
-    const float cx = boxes[b * 6 + 0], cy = boxes[b * 6 + 1], cz = boxes[b * 6 + 2];
-    const float hx = boxes[b * 6 + 3] / 2, hy = boxes[b * 6 + 4] / 2, hz = boxes[b * 6 + 5] / 2;
+    const float cx = boxes[b * box_dim + 0], cy = boxes[b * box_dim + 1], cz = boxes[b * box_dim + 2];
+    const float hx = boxes[b * box_dim + 3] / 2, hy = boxes[b * box_dim + 4] / 2, hz = boxes[b * box_dim + 5] / 2;
+    // heading (7-dof boxes): the shift p - c is rotated by -yaw about z before the face test (get_face_distances :666-668,
+    // mmdet3d rotation_3d_in_axis: x' = x cos a - y sin a, y' = x sin a + y cos a with a = -yaw)
+    const bool rot = box_dim == 7;
+    float rs = 0.f, rc = 1.f;
+    if (rot) { rs = sinf(-boxes[b * 7 + 6]); rc = cosf(-boxes[b * 7 + 6]); }
     float imin[3] = {INFINITY, INFINITY, INFINITY}, imax[3] = {-INFINITY, -INFINITY, -INFINITY};     // inside points
     float amin[3] = {INFINITY, INFINITY, INFINITY}, amax[3] = {-INFINITY, -INFINITY, -INFINITY};     // all points of s
     int cnt_in = 0;
@@ -169,7 +174,9 @@ __global__ __launch_bounds__(64) void trim_k(const float* __restrict__ points, i
         const float* p = points + (int64_t)list[o] * ld;
         const float px = p[0], py = p[1], pz = p[2];
         // get_face_distances with yaw 0: shift = p - c; centre' = c + shift; distances to the six faces
-        const float ex = cx + (px - cx), ey = cy + (py - cy), ez = cz + (pz - cz);
+        float sx = px - cx, sy = py - cy;
+        if (rot) { const float tx = sx * rc - sy * rs; sy = sx * rs + sy * rc; sx = tx; }
+        const float ex = cx + sx, ey = cy + sy, ez = cz + (pz - cz);
         const bool in = ((ex - cx) + hx > 0.f) && ((cx + hx) - ex > 0.f) && ((ey - cy) + hy > 0.f) && ((cy + hy) - ey > 0.f) &&
                         ((ez - cz) + hz > 0.f) && ((cz + hz) - ez > 0.f);
         amin[0] = fminf(amin[0], px); amin[1] = fminf(amin[1], py); amin[2] = fminf(amin[2], pz);
@@ -230,15 +237,15 @@ int u3d_nms_aligned3d(const float* corners, const int32_t* labels, int n, float 
 }
 
 int u3d_trim_boxes(const float* points, int64_t pt_ld, const int32_t* sp_list, const int32_t* sp_offsets, int S,
-                   const float* boxes, int nb, float low_thr, float up_thr, float* minmax, u3d_stream_t stream) {
-    if (nb < 0 || S < 0 || pt_ld < 3 || (nb > 0 && (!boxes || !minmax)) || (S > 0 && (!points || !sp_list || !sp_offsets))) return U3D_EINVAL;
+                   const float* boxes, int nb, int box_dim, float low_thr, float up_thr, float* minmax, u3d_stream_t stream) {
+    if (nb < 0 || S < 0 || pt_ld < 3 || (box_dim != 6 && box_dim != 7) || (nb > 0 && (!boxes || !minmax)) || (S > 0 && (!points || !sp_list || !sp_offsets))) return U3D_EINVAL;
     if (nb == 0) return U3D_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(trim_init_k, dim3((unsigned)ceil_div(nb * 6, 256)), dim3(256), 0, s, minmax, nb);
     if (S > 0) {
         const int nbt = (int)ceil_div(nb, 64);
-        hipLaunchKernelGGL(trim_k, dim3((unsigned)((int64_t)S * nbt)), dim3(64), 0, s, points, pt_ld, sp_list, sp_offsets, nbt, boxes, nb, low_thr,
-                           up_thr, minmax);
+        hipLaunchKernelGGL(trim_k, dim3((unsigned)((int64_t)S * nbt)), dim3(64), 0, s, points, pt_ld, sp_list, sp_offsets, nbt, boxes, nb, box_dim,
+                           low_thr, up_thr, minmax);
     }
     return check_launch("trim_boxes");
 }

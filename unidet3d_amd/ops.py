@@ -187,7 +187,10 @@ def nms_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Ten
         corners = torch.cat((b[:, :3] - half, b[:, :3] + half), dim=1).contiguous()
         L.call('u3d_nms_aligned3d', L.ptr(corners), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
     k = order[keep.bool()]
-    return bboxes[k], scores[k], labels[k]
+    out = bboxes[k]
+    if fast_nms and out.shape[1] == 6:        # the reference appends a zero heading for nms3d_normal and returns those 7-column boxes (:629-638)
+        out = torch.cat((out, torch.zeros_like(out[:, :1])), dim=1)
+    return out, scores[k], labels[k]
 
 
 def nms_bev_multiclass(bboxes, scores, labels, iou_thr, score_thr):
@@ -196,14 +199,17 @@ def nms_bev_multiclass(bboxes, scores, labels, iou_thr, score_thr):
 
 def trim_boxes_by_superpoints(points: torch.Tensor, sp_offsets: torch.Tensor, sp_points: torch.Tensor, n_superpoints: int,
                               bboxes: torch.Tensor, low_sp_thr: float, up_sp_thr: float) -> torch.Tensor:
-    """``UniDet3D.trim_bboxes_by_superpoints`` (unidet3d/unidet3d.py:540-593) for yaw-free boxes: [n,6] (centre, size) of the
-    points each box keeps after whole superpoints were deleted (< low) / added (> up).  ``(sp_offsets, sp_points)`` is the
-    CSR of point rows per superpoint (``csr_build`` / ``PoolPlan``)."""
+    """``UniDet3D.trim_bboxes_by_superpoints`` (unidet3d/unidet3d.py:540-593): [n,6] (centre, size) of the axis-aligned box
+    around the points each box keeps after whole superpoints were deleted (< low) / added (> up).  ``bboxes`` [n,6] or [n,7]
+    (heading: the inside test rotates the point shift by -yaw, ``get_face_distances`` :652-677).  ``(sp_offsets, sp_points)``
+    is the CSR of point rows per superpoint (``csr_build`` / ``PoolPlan``)."""
     nb = bboxes.shape[0]
     mm = torch.empty(nb, 6, dtype=torch.float32, device=points.device)
     if nb:
-        b = bboxes[:, :6].contiguous().float()
+        if bboxes.shape[1] == 7 and not bool((bboxes[:, 6] != 0).any()):
+            bboxes = bboxes[:, :6]            # zero heading appended by the fast-NMS branch: the exact yaw-free path
+        b = bboxes.contiguous().float()
         L.call('u3d_trim_boxes', L.ptr(points), points.stride(0), L.ptr(sp_points), L.ptr(sp_offsets), int(n_superpoints),
-               L.ptr(b), nb, float(low_sp_thr), float(up_sp_thr), L.ptr(mm), L.stream())
+               L.ptr(b), nb, int(b.shape[1]), float(low_sp_thr), float(up_sp_thr), L.ptr(mm), L.stream())
     mn, mx = mm[:, :3], mm[:, 3:]
     return torch.cat(((mx + mn) / 2, mx - mn), dim=1)

@@ -40,9 +40,10 @@ class _Registry:
 
 
 try:  # pragma: no cover - mmdet3d is not installed in the build image
-    from mmdet3d.registry import MODELS, TASK_UTILS  # type: ignore
+    from mmdet3d.registry import MODELS, TASK_UTILS, TRANSFORMS  # type: ignore
     HAVE_MMDET3D = True
 except Exception:  # noqa: BLE001
     MODELS = _Registry('models')
     TASK_UTILS = _Registry('task util')
+    TRANSFORMS = _Registry('transform')
     HAVE_MMDET3D = False

@@ -4,8 +4,8 @@ Drop-in for the hot part of the reference's ``UniDet3D`` (unidet3d/unidet3d.py:2
 registry name, constructor arguments (:59-76), parameter names (``input_conv.0.weight``,
 ``unet.*``, ``output_layer.0.*``, ``decoder.*``), ``collate`` (:136-176), ``extract_feat``
 (:113-134), ``_select_queries`` (:182-218), ``loss`` (:277-364) and the feature / decoder part of
-``predict`` (:411-462).  The NMS / superpoint-trimming post-processing (:475-650) is outside the
-built hot path and raises.
+``predict`` (:411-462), and the NMS / superpoint-trimming post-processing (:475-650, SURVEY.md section 8f
+rank 1) through ``ops.nms_multiclass`` / ``ops.trim_boxes_by_superpoints``.
 
 Batches are lists of per-scene tensors exactly as the reference receives them from its data
 preprocessor: ``batch_inputs_dict['points']`` = List[Tensor[N_i, 6]] on the device.
@@ -224,13 +224,10 @@ class UniDet3D(nn.Module):
         pred_bboxes = pred_bboxes[torch.div(topk_idx, num_classes, rounding_mode='floor')]
         nms_bboxes, nms_scores, nms_labels = ops.nms_multiclass(pred_bboxes, scores, labels, self.test_cfg['iou_thr'][idx],
                                                                 self.test_cfg['score_thr'], bool(self.fast_nms[idx]))
-        with_yaw = nms_bboxes.shape[1] == 7
-        if self.use_superpoints[idx]:
-            if with_yaw:
-                raise NotImplementedError('superpoint trimming of rotated boxes (get_face_distances with yaw) is not built; '
-                                          'the reference configs pair angles=True with use_superpoints=False')
+        if self.use_superpoints[idx]:       # trimmed boxes are axis-aligned whatever went in (:585-592)
             nms_bboxes = ops.trim_boxes_by_superpoints(vb.points, plan.sp_offsets, plan.sp_points, n_sp0, nms_bboxes,
                                                        self.test_cfg['low_sp_thr'], self.test_cfg['up_sp_thr'])
+        with_yaw = nms_bboxes.shape[1] == 7   # without trimming: 7 columns (zero heading after the fast-NMS branch, :629-636)
         boxes = DepthInstance3DBoxes(nms_bboxes, with_yaw=with_yaw, box_dim=nms_bboxes.shape[1], origin=(0.5, 0.5, 0.5))
         return [(boxes, nms_labels, nms_scores)]
 

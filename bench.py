@@ -144,10 +144,8 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     bucket = FlatGradBucket(params, attach=False)
     if world > 1:
-        try:
-            bucket.enable_overlap()          # 16 MB buckets, all-reduced over RCCL as backward completes them
-        except Exception as e:  # noqa: BLE001  (a communicator that cannot be split: keep the single all-reduce after backward)
-            log(f'rank {rank}: overlapped gradient exchange unavailable ({type(e).__name__}: {e}); using one all-reduce per step')
+        bucket.enable_overlap()              # 16 MB buckets, all-reduced over RCCL as backward completes them (a collective
+                                             # call: every rank takes the same path, a failure is fatal on all of them)
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)      # configs/unidet3d_1xb8_scannet.py:712
 
     log(f'rank {rank}/{world}: model built, generating {args.batch} scenes')

@@ -257,13 +257,13 @@ int64_t u3d_layer_norm_ws_bytes(int64_t M, int C);
  * u3d_nms_bev: replaces UniDet3D._single_scene_multiclass_nms with fast_nms=True (unidet3d/unidet3d.py:595-650, which
  * calls mmcv.ops.nms3d_normal per class: greedy suppression by the IoU of the (x, y, dx, dy) rectangles).  boxes [n][6]
  * = (cx, cy, cz, dx, dy, dz) and labels [n] must be ordered by (label ascending, score descending) -- the order the
- * reference visits them in; keep[n] receives 1 for surviving boxes.  n <= 1800 (the configs use top-k = 1000). */
+ * reference visits them in; keep[n] receives 1 for surviving boxes.  n <= 4400 (one workgroup holds the boxes in LDS; the configs use top-k = 1000). */
 int u3d_nms_bev(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream);
 /* fast_nms=False branch (unidet3d.py:634-636): mmdet3d aligned_3d_nms on corner boxes (x1,y1,z1,x2,y2,z2) = _bbox_to_loss(boxes);
  * same ordering contract; a box survives only while its 3-D IoU with every kept box of its class is <= iou_thr. */
 int u3d_nms_aligned3d(const float* corners, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream);
 /* rotated boxes (unidet3d.py:625-626, mmcv.ops.nms3d): boxes [n][7] = (cx, cy, cz, dx, dy, dz, heading); suppression by the BEV IoU
- * of the rotated rectangles; same ordering contract, n <= 1400. */
+ * of the rotated rectangles; same ordering contract, n <= 3600. */
 int u3d_nms_rotated(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream);
 /* u3d_trim_boxes: replaces UniDet3D.trim_bboxes_by_superpoints + get_face_distances (unidet3d/unidet3d.py:540-593, :652-677)
  * points: rows of >= 3 floats with leading dimension pt_ld; (sp_list, sp_offsets[S+1]): CSR of point rows per superpoint

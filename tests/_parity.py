@@ -1,0 +1,142 @@
+"""Shared harness of the GPU end-to-end parity tests: run the product path (HIP kernels, cuda:0) and the CPU oracle on the
+same scenes and weights and collect relative errors of everything the north star names -- voxel coordinates (bit-exact),
+per-superpoint features, class logits and box parameters of all decoder heads, loss, parameter gradients.
+Measured errors are appended to ``gpurun_out/parity_errors.jsonl`` (copied to ``profiles/`` by hand for the record)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import criterion as oc
+from oracle import model as om
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda:0'
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def log_errors(name: str, rec: dict):
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_errors.jsonl'), 'a') as f:
+            f.write(json.dumps(dict(test=name, **rec)) + '\n')
+    except OSError:
+        pass
+
+
+def build_pair(cfg, tag0=3000, scale=0.06):
+    """Product model (cuda:0) and oracle model (CPU) with identical deterministic weights."""
+    from _detw import fill_state_dict
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd.config import build_model
+    prod = build_model(cfg)
+    fill_state_dict(prod, tag0=tag0, scale=scale)
+    orac = om.ODetector(backbone=cfg['backbone'], decoder=cfg['decoder'], voxel_size=cfg['voxel_size'])
+    res = orac.load_state_dict(prod.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return prod.to(DEV).train(), orac.train()
+
+
+def scene_boxes(sc):
+    """Axis-aligned GT boxes (centre, size) [n_inst, 6] of a synthetic scene in its ORIGINAL frame (what a dataset with
+    box annotations stores); instances without points are dropped together with their labels."""
+    xyz = sc.points[:, :3]
+    boxes, keep = [], []
+    for j in range(len(sc.labels)):
+        m = sc.instance_mask == j
+        if m.any():
+            lo, hi = xyz[m].min(0), xyz[m].max(0)
+            boxes.append(np.concatenate(((lo + hi) / 2, hi - lo)))
+            keep.append(j)
+    return np.stack(boxes).astype(np.float32), np.asarray(keep)
+
+
+def oracle_forward(orac, scenes, names, crit_cfg=None, det_cfg=None, gt_boxes=None, train_topk=6):
+    """-> dict(feats, out, loss, coords, centers, insts).  ``gt_boxes[i]``: None (boxes from the instance masks,
+    bbox_by_mask) or a [g, 6/7] float array in the original frame (+ target_by_distance assignment)."""
+    pts = [torch.from_numpy(s.points) for s in scenes]
+    sps = [torch.from_numpy(s.superpoints) for s in scenes]
+    feats, x = orac.extract_feat(pts, sps)
+    cent = orac.sp_centers(pts, sps)
+    out = orac.decoder(feats, cent, names)
+    insts = []
+    for i, (p, s, sp) in enumerate(zip(pts, scenes, sps)):
+        mn = p[:, :3].min(0)[0]
+        if gt_boxes is None or gt_boxes[i] is None:
+            insts.append(oc.gt_from_scene(p[:, :3] - mn, torch.from_numpy(s.instance_mask), torch.from_numpy(s.labels), sp))
+        else:
+            b, lab = gt_boxes[i]
+            b = torch.from_numpy(b).clone()
+            b[:, :3] -= mn                                                   # unidet3d.py:318-330
+            masks = oc.get_targets(cent[i], b[:, :3], train_topk)         # target_by_distance (:340-343)
+            insts.append(oc.OInst(labels_3d=torch.from_numpy(lab), bboxes_3d=oc.OBoxes(b, with_yaw=b.shape[1] == 7),
+                                  sp_masks=masks, query_masks=masks))
+    kw = {}
+    if crit_cfg is not None:
+        idx = [crit_cfg['datasets'].index(n) for n in names]
+        kw = dict(topk=[crit_cfg['topk'][k] for k in idx], dataset_weight=[crit_cfg['datasets_weights'][k] for k in idx])
+    loss = oc.criterion(out, insts, **kw)
+    return dict(feats=feats, out=out, loss=loss, coords=x.indices, centers=cent, insts=insts)
+
+
+def product_forward(prod, inputs, samples):
+    """One training pass of the product with the decoder input / output captured (the tensors the loss really used)."""
+    seen = {}
+    orig = prod.extract_feat
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        seen['feats'] = r
+        return r
+    prod.extract_feat = spy
+    h = prod.decoder.register_forward_hook(lambda m, i, o: seen.update(out=o))
+    try:
+        loss = prod.loss(inputs, samples)['det_loss']
+    finally:
+        h.remove()
+        prod.extract_feat = orig
+    return dict(loss=loss, feats=seen['feats'], out=seen['out'], coords=prod._vb.coords)
+
+
+def compare(name, P, O, prod, orac, grad_tol=None):
+    """Asserts the north-star tolerances and returns / logs the measured errors."""
+    n = len(O['feats'])
+    assert torch.equal(P['coords'].cpu(), O['coords']), 'voxel coordinates differ from the oracle'
+    err = dict(n_scenes=n, n_voxels=int(O['coords'].shape[0]),
+               feats=max(rel(P['feats'][i], O['feats'][i]) for i in range(n)))
+    heads_p = [P['out']] + list(P['out']['aux_outputs'])
+    heads_o = [O['out']] + list(O['out']['aux_outputs'])
+    assert len(heads_p) == len(heads_o)
+    err['logits'] = max(rel(hp['cls_preds'][i], ho['cls_preds'][i]) for hp, ho in zip(heads_p, heads_o) for i in range(n))
+    err['boxes'] = max(rel(hp['bboxes'][i], ho['bboxes'][i]) for hp, ho in zip(heads_p, heads_o) for i in range(n))
+    err['loss'] = abs(float(P['loss'].detach()) - float(O['loss'].detach())) / abs(float(O['loss'].detach()))
+    P['loss'].backward()
+    O['loss'].backward()
+    og = dict(orac.named_parameters())
+    grads = {}
+    for k, p in prod.named_parameters():
+        if og[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        grads[k] = rel(p.grad, og[k].grad)
+    err['grad_max'] = max(grads.values())
+    err['grad_median'] = float(np.median(list(grads.values())))
+    err['grad_worst'] = sorted(grads.items(), key=lambda kv: -kv[1])[:5]
+    err['grad_decoder_max'] = max(v for k, v in grads.items() if k.startswith('decoder.'))
+    err['grad_backbone_max'] = max(v for k, v in grads.items() if not k.startswith('decoder.'))
+    log_errors(name, err)
+    print(name, json.dumps({k: v for k, v in err.items() if k != 'grad_worst'}))
+    assert err['feats'] < 1e-3 and err['logits'] < 1e-3 and err['boxes'] < 1e-3 and err['loss'] < 1e-3, err
+    if grad_tol is not None:
+        assert err['grad_decoder_max'] < grad_tol[0] and err['grad_backbone_max'] < grad_tol[1], err
+    return err

@@ -106,3 +106,95 @@ def test_overlap_buckets_with_unused_parameters_single_process():
         assert torch.equal(used.weight.grad, torch.full((3, 4), 2.0)) and torch.equal(used.bias.grad, torch.full((3,), 2.0))
         assert float(unused.weight.grad.abs().sum()) == 0.0 and float(unused.bias.grad.abs().sum()) == 0.0
     assert float(b.clip_grad_norm_(1.0)) > 1.0 and abs(float(b.flat.norm()) - 1.0) < 1e-5
+
+
+# ---- 4 ranks, unequal scenes, one rank without ground truth, one rank that skips a parameter ---------------------------
+class _Head(torch.nn.Module):
+    """A stand-in decoder head: per-query class logits and (exp-sized) boxes, plus a branch only some ranks use."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.Linear(8, 16)
+        self.cls = torch.nn.Linear(16, 6)
+        self.box = torch.nn.Linear(16, 6)
+        self.extra = torch.nn.Linear(16, 16)
+
+    def forward(self, x, use_extra):
+        h = torch.relu(self.trunk(x))
+        if use_extra:
+            h = h + self.extra(h)
+        b = self.box(h)
+        return self.cls(h), torch.cat((b[:, :3], torch.exp(b[:, 3:])), 1)
+
+
+def _scene_of(rank):
+    """(queries [n, 8], gt boxes [g, 6], labels [g], query_masks [g, n]); rank 2 has no ground truth."""
+    g = torch.Generator().manual_seed(50 + rank)
+    n, gts = 20 + 7 * rank, (0 if rank == 2 else 2 + rank)
+    x = torch.randn(n, 8, generator=g)
+    gt = torch.cat((torch.rand(gts, 3, generator=g) * 2, torch.rand(gts, 3, generator=g) + 0.3), 1)
+    return x, gt, torch.randint(0, 5, (gts,), generator=g), torch.rand(gts, n, generator=g) < 0.6
+
+
+def _loss_of(net, rank):
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd.config import scannet_model_cfg
+    from unidet3d_amd.registry import MODELS
+    from unidet3d_amd.structures import DepthInstance3DBoxes, InstanceData_
+    crit = MODELS.build(scannet_model_cfg()['criterion'])
+    x, gt, labels, qm = _scene_of(rank)
+    cls, box = net(x, use_extra=rank != 1)                   # rank 1 never touches ``extra``: no gradient for it there
+    inst = InstanceData_(labels_3d=labels, query_masks=qm, bboxes_3d=DepthInstance3DBoxes(gt, with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5)))
+    return crit(dict(cls_preds=[cls], bboxes=[box], aux_outputs=[]), [inst], ['scannet'])['det_loss']
+
+
+def _worker4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from unidet3d_amd.dist import FlatGradBucket, broadcast_params, init_from_env
+    init_from_env('gloo')
+    torch.manual_seed(0)
+    net = _Head()
+    broadcast_params(net)
+    b = FlatGradBucket(net.parameters(), attach=False).enable_overlap(bucket_bytes=256)
+    assert len(b.buckets) >= 4
+    order = []
+    launch = b._launch
+    b._launch = lambda bk, sync=False: (order.append(bk['index']), launch(bk, sync))[1]
+    for _ in range(2):
+        b.clear_grads()
+        _loss_of(net, rank).backward()
+        b.finish()
+        assert b.check_views()
+    q.put((rank, b.flat.clone().numpy(), order))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_order_is_rank_independent_world4_with_empty_gt_and_unused_parameter():
+    """the buckets' all-reduces must start in the same order on every rank even when a rank has no ground truth
+    (box loss contributes a graph-connected zero) or skips a parameter altogether; the averaged gradient equals the mean of
+    the four single-process gradients."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_b = max(res[0][2]) + 1
+    for r in res:
+        assert r[2] == list(range(n_b - 1, -1, -1)) * 2            # descending bucket index, both steps, on every rank
+        assert np.allclose(r[1], res[0][1])
+    torch.manual_seed(0)
+    net = _Head()
+    want = None
+    for rank in range(world):
+        net.zero_grad()
+        _loss_of(net, rank).backward()
+        g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()])
+        want = g if want is None else want + g
+    assert np.allclose(res[0][1], (want / world).numpy(), atol=1e-6)
+    assert float(np.abs(res[0][1]).max()) > 0

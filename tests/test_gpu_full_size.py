@@ -1,0 +1,172 @@
+"""End-to-end parity at the sizes BASELINE.json names, product (HIP, cuda:0) vs CPU oracle on identical scenes and weights.
+
+* cfg2 -- 8 scenes x 100 k points, 2 cm voxels, the ScanNet model: voxel coordinates and all rulebooks bit-exact, per-superpoint
+  features, class logits AND box parameters of all 7 decoder heads, loss <= 1e-3; every parameter gradient compared.
+* cfg4 -- the reference's 6-dataset joint config (model dict captured from the real config file): a mixed batch of 8 scenes
+  over all six datasets incl. 7-dof ARKitScenes ground truth, ``target_by_distance`` / ``get_targets`` and boxes given by the
+  dataset; plus ``predict`` through the fast_nms=False (S3DIS) and rotated (ARKitScenes) NMS branches.
+Measured errors go to gpurun_out/parity_errors.jsonl (kept copy: profiles/round2_parity_errors.jsonl); the gradient
+tolerances asserted here are ~3x what was measured on the MI355X.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _parity as PA
+from oracle import postproc as pp
+from oracle import sparse_ops as so
+
+pytestmark = pytest.mark.gpu
+DEV = PA.DEV
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _scannet_cfg():
+    from unidet3d_amd.config import scannet_model_cfg
+    return scannet_model_cfg()
+
+
+def test_cfg2_rulebooks_bit_exact_all_levels_full_batch():
+    """8 x 100 k points @ 2 cm (~356 k voxels): coordinates, inverse map and the rulebooks of all five U-Net levels."""
+    from unidet3d_amd import ops, sparse
+    from unidet3d_amd.synthetic import make_scene
+    scenes = [make_scene(i, n_points=100_000) for i in range(8)]
+    pts_cpu = [torch.from_numpy(s.points) for s in scenes]
+    oc, _, oinv, oshape = so.voxelize(pts_cpu, 0.02, 128)
+    vb = ops.voxelize([p.to(DEV) for p in pts_cpu], 0.02, 128)
+    assert torch.equal(vb.coords.cpu(), oc) and torch.equal(vb.inverse.cpu(), oinv)
+    assert 300_000 < len(oc) < 420_000
+    coords, shape, index = vb.coords, vb.spatial_shape, vb.index
+    n_pairs = []
+    for level in range(5):
+        rb = sparse.build_subm_rulebook(coords, index)
+        want = so.build_subm_rulebook(oc, oshape)
+        got = rb.lists()
+        for k, ((gi, go), (oi, oo)) in enumerate(zip(got, want)):
+            assert np.array_equal(gi, oi) and np.array_equal(go, oo), f'level {level} offset {k}'
+        n_pairs.append(sum(len(a) for a, _ in want))
+        if level == 4:
+            break
+        oc2, oshape2, opairs = so.build_down_rulebook(oc, oshape)
+        c2, shape2, ix2, rb2 = sparse.build_down_rulebook(coords, 8, shape)
+        assert torch.equal(c2.cpu(), oc2) and shape2 == [int(s) for s in oshape2]
+        for k, ((gi, go), (oi, oo)) in enumerate(zip(rb2.lists(), opairs)):
+            assert np.array_equal(gi, oi) and np.array_equal(go, oo), f'level {level} down offset {k}'
+        coords, shape, index, oc, oshape = c2, shape2, ix2, oc2, oshape2
+    PA.log_errors('cfg2_rulebooks', dict(n_voxels_l1=int(vb.coords.shape[0]), subm_pairs_per_level=n_pairs, bit_exact=True))
+
+
+def test_cfg2_full_size_end_to_end_vs_oracle():
+    """BASELINE configs[1] at full size: B = 8 x 100 k points, fp32."""
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = _scannet_cfg()
+    prod, orac = PA.build_pair(cfg)
+    scenes = [make_scene(i, n_points=100_000) for i in range(8)]
+    O = PA.oracle_forward(orac, scenes, ['scannet'] * 8)
+    inputs, samples = make_batch_inputs(scenes, DEV)
+    P = PA.product_forward(prod, inputs, samples)
+    assert len(P['out']['aux_outputs']) == 6                                 # 7 heads in total
+    # measured on MI355X (profiles/round2_parity_errors.jsonl): decoder grads ~1e-4, backbone grads <= ~1e-2 (90 BN layers, the
+    # deepest over ~1 k voxels, and a discrete matcher in between)
+    PA.compare('cfg2_full_size_8x100k', P, O, prod, orac, grad_tol=(5e-3, 5e-2))
+
+
+def _joint_cfg():
+    cfg = json.load(open(os.path.join(GOLD, 'ref_joint_model_cfg.json')))
+    return cfg
+
+
+JOINT_SCENES = [('scannet', 40_000), ('arkitscenes', 30_000), ('s3dis', 50_000), ('multiscan', 30_000), ('3rscan', 30_000),
+                ('scannetpp', 40_000), ('scannet', 30_000), ('arkitscenes', 35_000)]
+
+
+def _joint_batch(cfg):
+    """Synthetic mixed batch following each dataset's annotation style (configs/...arkitscenes.py:36-43): ScanNet / S3DIS carry
+    instance masks (bbox_by_mask), the others boxes (ARKitScenes with a heading) and get their masks by distance."""
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.structures import DepthInstance3DBoxes
+    from unidet3d_amd.synthetic import make_scene
+    dec = cfg['decoder']
+    scenes, names, gt_boxes = [], [], []
+    rng = np.random.default_rng(4)
+    for i, (name, n_pts) in enumerate(JOINT_SCENES):
+        d = dec['datasets'].index(name)
+        sc = make_scene(200 + i, n_points=n_pts, n_classes=len(dec['datasets_classes'][d]), dataset=name)
+        scenes.append(sc); names.append(name)
+        if cfg['bbox_by_mask'][d]:
+            gt_boxes.append(None)
+        else:
+            b, keep = PA.scene_boxes(sc)
+            if dec['angles'][d]:
+                b = np.concatenate((b, rng.uniform(-0.6, 0.6, (len(b), 1)).astype(np.float32)), 1)
+            gt_boxes.append((b, sc.labels[keep]))
+    inputs, samples = make_batch_inputs(scenes, DEV)
+    for ds, gb in zip(samples, gt_boxes):
+        if gb is not None:
+            b, lab = gb
+            ds.gt_instances_3d.labels_3d = torch.from_numpy(lab).to(DEV)
+            ds.gt_instances_3d.sp_masks = ds.gt_instances_3d.sp_masks[:len(lab)]        # replaced by get_targets in loss()
+            ds.gt_instances_3d.bboxes_3d = DepthInstance3DBoxes(torch.from_numpy(b), with_yaw=b.shape[1] == 7, box_dim=b.shape[1],
+                                                                origin=(0.5, 0.5, 0.5)).to(DEV)
+    return scenes, names, gt_boxes, inputs, samples
+
+
+def test_cfg4_joint_config_mixed_batch_vs_oracle():
+    """BASELINE configs[3] on one GPU: the reference's joint model config, 8 scenes over the six datasets."""
+    cfg = _joint_cfg()
+    prod, orac = PA.build_pair(cfg, tag0=5000)
+    assert prod.decoder.datasets == ['scannet', 's3dis', 'multiscan', '3rscan', 'scannetpp', 'arkitscenes']
+    scenes, names, gt_boxes, inputs, samples = _joint_batch(cfg)
+    O = PA.oracle_forward(orac, scenes, names, crit_cfg=cfg['criterion'], gt_boxes=gt_boxes, train_topk=cfg['train_cfg']['topk'])
+    P = PA.product_forward(prod, inputs, samples)
+    assert P['out']['bboxes'][1].shape[1] == 7 and P['out']['bboxes'][0].shape[1] == 6            # ARKitScenes head is 7-dof
+    for i, ds in enumerate(samples):                                           # target assignment is integer work: exact
+        assert torch.equal(ds.gt_instances_3d.sp_masks.cpu(), O['insts'][i].sp_masks), names[i]
+        assert PA.rel(ds.gt_instances_3d.sp_centers, O['centers'][i]) < 1e-5
+        assert PA.rel(ds.gt_instances_3d.bboxes_3d.gravity_center, O['insts'][i].bboxes_3d.gravity_center) < 1e-5
+    PA.compare('cfg4_joint_mixed_batch', P, O, prod, orac, grad_tol=(5e-3, 5e-2))
+
+
+@pytest.mark.parametrize('name', ['s3dis', 'arkitscenes', '3rscan'])
+def test_cfg4_predict_branches_match_oracle_postprocessing(name):
+    """``predict`` of the joint model: S3DIS = aligned_3d_nms (fast_nms=False) + superpoint trimming; ARKitScenes = rotated NMS,
+    7-dof boxes, no trimming; 3RScan = BEV NMS, no trimming (7 columns with a zero heading, as the reference returns them)."""
+    from _detw import fill_state_dict
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd.config import build_model
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = _joint_cfg()
+    cfg['decoder']['num_layers'] = 2
+    model = fill_state_dict(build_model(cfg), tag0=3000, scale=0.06).to(DEV).eval()
+    model.voxel_size = 0.05
+    d = model.decoder.datasets.index(name)
+    sc = make_scene(31, n_points=20_000, dataset=name, n_classes=len(cfg['decoder']['datasets_classes'][d]))
+    inputs, samples = make_batch_inputs([sc], DEV)
+    seen, orig = {}, model.predict_by_feat
+    model.predict_by_feat = lambda out, *a, **k: (seen.update(out=out), orig(out, *a, **k))[1]
+    with torch.no_grad():
+        res = model.predict(inputs, samples)[0].pred_instances_3d
+    cls_preds, bboxes = seen['out']['cls_preds'][0], seen['out']['bboxes'][0]
+    scores = torch.softmax(cls_preds, -1)[:, :-1]
+    nc = scores.shape[1]
+    s, idx = scores.flatten().topk(min(1000, scores.numel()), sorted=True)
+    lab, q = (idx % nc).cpu().numpy(), torch.div(idx, nc, rounding_mode='floor')
+    boxes = bboxes[q].cpu().numpy()
+    if name == 'arkitscenes':
+        assert boxes.shape[1] == 7
+    nb, ns, nl = pp.multiclass_nms(boxes, s.cpu().numpy(), lab, cfg['test_cfg']['iou_thr'][d], 0.0, bool(cfg['fast_nms'][d]))
+    assert len(nl) > 0 and res.labels_3d.cpu().numpy().tolist() == nl.tolist()
+    assert np.array_equal(res.scores_3d.cpu().numpy(), ns)
+    if cfg['use_superpoints'][d]:
+        want = pp.trim_boxes(sc.points[:, :3], sc.superpoints, nb, 0.18, 0.81)
+        assert res.bboxes_3d.tensor.shape[1] == 6 and not res.bboxes_3d.with_yaw
+    else:
+        want = nb.copy()
+        assert res.bboxes_3d.tensor.shape[1] == 7 and res.bboxes_3d.with_yaw
+    want[:, 2] += want[:, 5] * np.float32(-0.5)                                # stored bottom-centre (mmdet3d convention)
+    assert np.array_equal(res.bboxes_3d.tensor.cpu().numpy(), want, equal_nan=True)

@@ -19,7 +19,7 @@ def _boxes(rng, n, spread=4.0):
 
 @pytest.mark.parametrize('fast', [True, False])
 @pytest.mark.parametrize('n,n_cls,thr,score_thr', [(0, 3, 0.5, 0.0), (1, 1, 0.5, 0.0), (300, 5, 0.5, 0.0), (1000, 18, 0.5, 0.0),
-                                                   (1000, 18, 0.25, 0.3), (1500, 2, 0.7, 0.0), (64, 1, 0.0, 0.0), (200, 4, 0.5, 2.0)])
+                                                   (1000, 18, 0.25, 0.3), (1500, 2, 0.7, 0.0), (4000, 18, 0.5, 0.0), (64, 1, 0.0, 0.0), (200, 4, 0.5, 2.0)])
 def test_multiclass_nms_matches_oracle(n, n_cls, thr, score_thr, fast):
     from unidet3d_amd import ops
     rng = np.random.default_rng(n * 31 + n_cls)
@@ -36,7 +36,7 @@ def test_multiclass_nms_matches_oracle(n, n_cls, thr, score_thr, fast):
     assert np.array_equal(gs.cpu().numpy(), os_) and np.array_equal(gb.cpu().numpy(), ob)
 
 
-@pytest.mark.parametrize('n,n_cls,thr', [(1, 1, 0.5), (400, 6, 0.5), (1000, 18, 0.3), (1300, 2, 0.6)])
+@pytest.mark.parametrize('n,n_cls,thr', [(1, 1, 0.5), (400, 6, 0.5), (1000, 18, 0.3), (1300, 2, 0.6), (3000, 18, 0.5)])
 def test_rotated_nms_matches_oracle(n, n_cls, thr):
     """mmcv nms3d path (7-dof boxes).  The kernel sums the clipped edges in fp32, the oracle intersects polygons in fp64: a pair
     whose IoU lies within 1e-4 of the threshold may legitimately flip, so such inputs are nudged away from it first."""
@@ -69,7 +69,7 @@ def test_rotated_nms_matches_oracle(n, n_cls, thr):
 
 def test_nms_rejects_too_many_boxes_and_bad_shapes():
     from unidet3d_amd import _lib as L, ops
-    b = torch.zeros(3000, 6, device=DEV); s = torch.linspace(1, 0.1, 3000, device=DEV); l = torch.zeros(3000, dtype=torch.long, device=DEV)
+    b = torch.zeros(5000, 6, device=DEV); s = torch.linspace(1, 0.1, 5000, device=DEV); l = torch.zeros(5000, dtype=torch.long, device=DEV)
     with pytest.raises(L.U3DError):
         ops.nms_bev_multiclass(b, s, l, 0.5, 0.0)
     with pytest.raises(ValueError):

@@ -360,8 +360,18 @@ def gen_transforms(out):
     out['stubs'] = np.array(['torch_scatter.scatter_mean (sn / s3 sp_masks)'])
 
 
+def gen_joint_cfg():
+    """The ``model`` dict of the reference's 6-dataset joint config (values only) so that the GPU box can build it."""
+    ns = {}
+    path = os.path.join(RS.REF_ROOT, 'configs', 'unidet3d_1xb8_scannet_s3dis_multiscan_3rscan_scannetpp_arkitscenes.py')
+    exec(compile(open(path).read(), path, 'exec'), ns)
+    json.dump(ns['model'], open(os.path.join(GOLD, 'ref_joint_model_cfg.json'), 'w'), indent=0, sort_keys=True)
+    print('joint model cfg: datasets', ns['model']['decoder']['datasets'])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    gen_joint_cfg()
     for name, fn in (('ref_criterion', gen_criterion), ('ref_detector', gen_detector), ('ref_eval', gen_eval),
                      ('ref_transforms', gen_transforms)):
         out = {}

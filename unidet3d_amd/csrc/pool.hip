@@ -100,13 +100,13 @@ __global__ __launch_bounds__(256) void seg_mean_xyz_k(const float* __restrict__ 
 // atomics on order-preserving float keys, one global atomic per (block, segment, component).
 __device__ __forceinline__ int f2ord_(float f) { int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
 __global__ __launch_bounds__(256) void seg_minmax_xyz_k(const float* __restrict__ points, int ld, const int64_t* __restrict__ ids, int64_t n,
-                                                        int n_seg, const float* __restrict__ sub, int sub_ld,
-                                                        const int64_t* __restrict__ pt_offsets, int B, int* __restrict__ out /*[n_seg][6] ordered ints*/) {
+                                                        int seg_lo, int n_seg, const float* __restrict__ sub, int sub_ld,
+                                                        const int64_t* __restrict__ pt_offsets, int B, int* __restrict__ out /*[n_seg][6] ordered ints of segments seg_lo..*/) {
     extern __shared__ int sm[];                   // [n_seg][6]
     for (int i = threadIdx.x; i < n_seg * 6; i += blockDim.x) sm[i] = (i % 6 < 3) ? 0x7fffffff : (int)0x80000000;
     __syncthreads();
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t id = ids[p];
+        const int64_t id = ids[p] - seg_lo;
         if (id < 0 || id >= n_seg) continue;
         float sx = 0.f, sy = 0.f, sz = 0.f;
         if (sub) {
@@ -209,7 +209,7 @@ int u3d_segment_mean_xyz(const float* points, int pt_ld, const int32_t* list, co
 
 int u3d_segment_minmax_xyz(const float* points, int pt_ld, const int64_t* ids, int64_t n, int n_seg, const float* sub,
                            int sub_ld, const int64_t* pt_offsets, int B, float* out, void* ws, u3d_stream_t stream) {
-    if (!points || !ids || !out || !ws || n <= 0 || n_seg <= 0 || n_seg > 4096 || pt_ld < 3 ||
+    if (!points || !ids || !out || !ws || n <= 0 || n_seg <= 0 || pt_ld < 3 ||
         (sub && (!pt_offsets || B <= 0 || sub_ld < 3)))
         return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -218,8 +218,12 @@ int u3d_segment_minmax_xyz(const float* points, int pt_ld, const int64_t* ids, i
     hipLaunchKernelGGL(seg_minmax_init_k, dim3((n6 + 255) / 256), dim3(256), 0, s, tmp, n6);
     int64_t g = ceil_div(n, 256 * 8);
     g = g < 1 ? 1 : (g > 512 ? 512 : g);
-    hipLaunchKernelGGL(seg_minmax_xyz_k, dim3((unsigned)g), dim3(256), (size_t)n6 * sizeof(int), s, points, pt_ld, ids, n, n_seg, sub,
-                       sub_ld, pt_offsets, B, tmp);
+    constexpr int SEG_CHUNK = 2048;               // 2048 x 6 ints = 48 KB of LDS per pass (64 KB is the limit without opt-in)
+    for (int lo = 0; lo < n_seg; lo += SEG_CHUNK) {
+        const int m = n_seg - lo < SEG_CHUNK ? n_seg - lo : SEG_CHUNK;
+        hipLaunchKernelGGL(seg_minmax_xyz_k, dim3((unsigned)g), dim3(256), (size_t)m * 6 * sizeof(int), s, points, pt_ld, ids, n, lo, m, sub,
+                           sub_ld, pt_offsets, B, tmp + (int64_t)lo * 6);
+    }
     hipLaunchKernelGGL(seg_minmax_fin_k, dim3((n6 + 255) / 256), dim3(256), 0, s, (const int*)tmp, n6, out);
     return check_launch("segment_minmax_xyz");
 }

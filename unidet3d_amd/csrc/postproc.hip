@@ -14,7 +14,8 @@
 
 namespace u3d {
 
-constexpr int NMS_MAX = 1800;          // 9 LDS words per box: 64.8 KB, just inside the 64 KB a launch may request without opting in
+constexpr int NMS_MAX = 4400;          // 9 LDS words per box: 158 KB of the CU's 160 KB (launches above 64 KB opt in, see lds_opt_in)
+constexpr int NMS_ROT_MAX = 3600;      // 11 LDS words per box
 
 // MODE 0: BEV IoU of (cx, cy, cz, dx, dy, dz) boxes, suppress when iou > thr           (mmcv nms3d_normal / iou_normal)
 // MODE 1: 3-D IoU of (x1, y1, z1, x2, y2, z2) boxes, survive only when iou <= thr       (mmdet3d aligned_3d_nms: a 0/0 IoU
@@ -204,6 +205,17 @@ using namespace u3d;
 
 extern "C" {
 
+// a launch that wants more than 64 KB of dynamic LDS has to raise the kernel's limit first (gfx950: 160 KB per workgroup)
+static int lds_opt_in(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return U3D_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("nms: cannot reserve %zu bytes of LDS", bytes);
+        return U3D_EUNSUPPORTED;
+    }
+    return U3D_OK;
+}
+
 static int launch_nms(int mode, const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
     if (n < 0 || (n > 0 && (!boxes || !labels || !keep))) return U3D_EINVAL;
     if (n == 0) return U3D_OK;
@@ -212,6 +224,7 @@ static int launch_nms(int mode, const float* boxes, const int32_t* labels, int n
         return U3D_EUNSUPPORTED;
     }
     const size_t lds = (size_t)n * 9 * sizeof(float);
+    if (int rc = lds_opt_in(mode == 0 ? (const void*)nms_k<0> : (const void*)nms_k<1>, lds)) return rc;
     if (mode == 0) hipLaunchKernelGGL(nms_k<0>, dim3(1), dim3(1024), lds, (hipStream_t)stream, boxes, labels, n, iou_thr, keep);
     else hipLaunchKernelGGL(nms_k<1>, dim3(1), dim3(1024), lds, (hipStream_t)stream, boxes, labels, n, iou_thr, keep);
     return check_launch("nms");
@@ -224,10 +237,11 @@ int u3d_nms_bev(const float* boxes, const int32_t* labels, int n, float iou_thr,
 int u3d_nms_rotated(const float* boxes, const int32_t* labels, int n, float iou_thr, uint8_t* keep, u3d_stream_t stream) {
     if (n < 0 || (n > 0 && (!boxes || !labels || !keep))) return U3D_EINVAL;
     if (n == 0) return U3D_OK;
-    if (n > 1400) {
-        set_error("nms_rotated: %d boxes exceed the single-workgroup limit of 1400", n);
+    if (n > NMS_ROT_MAX) {
+        set_error("nms_rotated: %d boxes exceed the single-workgroup limit of %d", n, NMS_ROT_MAX);
         return U3D_EUNSUPPORTED;
     }
+    if (int rc = lds_opt_in((const void*)nms_rot_k, (size_t)n * 11 * sizeof(float))) return rc;
     hipLaunchKernelGGL(nms_rot_k, dim3(1), dim3(1024), (size_t)n * 11 * sizeof(float), (hipStream_t)stream, boxes, labels, n, iou_thr, keep);
     return check_launch("nms_rotated");
 }

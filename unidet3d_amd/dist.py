@@ -95,11 +95,18 @@ class FlatGradBucket:
                 self.buckets.append(dict(lo=i0, hi=i + 1, flat=self.flat[o0:o], pending=i + 1 - i0, launched=False, dirty=False, work=None))
                 i0, o0 = i + 1, o
         self._bucket_of = {}
-        for b in self.buckets:
+        for k, b in enumerate(self.buckets):
+            b['index'] = k
             for i in range(b['lo'], b['hi']):
                 self._bucket_of[id(self.params[i])] = b
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
+        # Collectives on one communicator must be issued in the SAME order on every rank.  Backward produces gradients
+        # from the last parameter to the first, so buckets are launched strictly in descending index order: bucket k goes
+        # out only when it is complete AND every bucket above it has been launched (torch DDP's rule).  A parameter that
+        # receives no gradient on one rank only therefore cannot reorder that rank's collectives; finish() flushes the
+        # rest in the same order.
+        self._next = len(self.buckets) - 1
         self._overlap = True
         return self
 
@@ -112,8 +119,9 @@ class FlatGradBucket:
             b['dirty'] = True
             return
         b['pending'] -= 1
-        if b['pending'] == 0:
-            self._launch(b)
+        while self._next >= 0 and self.buckets[self._next]['pending'] == 0:
+            self._launch(self.buckets[self._next])
+            self._next -= 1
 
     def _launch(self, b, sync: bool = False):
         src, dst = [], []
@@ -134,9 +142,9 @@ class FlatGradBucket:
     def finish(self):
         """Call after backward: launches the buckets that never completed (unused parameters), waits for the
         collectives, averages, and re-arms the hooks' counters for the next step."""
-        for b in self.buckets:
-            if not b['launched']:
-                self._launch(b)
+        while self._next >= 0:                  # descending index order, like the hooks
+            self._launch(self.buckets[self._next])
+            self._next -= 1
         for b in self.buckets:
             if b['work'] is not None and b['work'] is not True:
                 b['work'].wait()
@@ -148,6 +156,7 @@ class FlatGradBucket:
             self.flat.div_(w)
         for b in self.buckets:
             b.update(pending=b['hi'] - b['lo'], launched=False, dirty=False, work=None)
+        self._next = len(self.buckets) - 1
 
     def sync(self):
         """After backward: the overlapped form when ``enable_overlap()`` was called, else one copy + one all-reduce."""

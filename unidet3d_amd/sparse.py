@@ -275,15 +275,20 @@ class _BNReLUFn(torch.autograd.Function):
         y = torch.empty_like(x)
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
         sums = None
-        if training and n:
+        sync_on = sync and _dist_on()
+        if training and (n or sync_on):           # a rank without rows still joins the exchange (zero sums, zero count), like nn.SyncBatchNorm
             sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)   # [sum x, sum x^2, rows]
-            if sync and _dist_on():
-                L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(sums), L.ptr(ws), L.stream())
+            if sync_on:
+                if n:
+                    L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(sums), L.ptr(ws), L.stream())
+                else:
+                    sums.zero_()
                 allreduce_bn_sums(sums)          # rows ride along: no host read-back on the critical path
                 L.call('u3d_bn_finalize', L.ptr(sums), -1.0, L.ptr(gamma), L.ptr(beta), eps, momentum,
                        L.ptr(running_mean), L.ptr(running_var), C, L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]),
                        L.ptr(st[3]), L.ptr(nbt), L.stream())
-                L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
+                if n:
+                    L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
             else:                                # one call: stats -> finalize -> apply
                 L.call('u3d_bn_forward', L.ptr(x), n, C, L.ptr(gamma), L.ptr(beta), eps, momentum, L.ptr(running_mean),
                        L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
@@ -308,6 +313,8 @@ class _BNReLUFn(torch.autograd.Function):
         # dgamma, dbeta (local sums: DDP averages later); separate tensors so that autograd can adopt them as .grad without a copy
         dgb = [torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)]
         if not n:
+            if ctx.training and fsums is not None and ctx.sync and _dist_on():     # keep the collective sequence of the other ranks
+                dist.all_reduce(torch.zeros(2 * C, dtype=torch.float64, device=dev), op=dist.ReduceOp.SUM)
             return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
@@ -355,7 +362,7 @@ class SparseBatchNorm(nn.Module):
         # num_batches_tracked is incremented by the statistics kernel (one launch less per layer)
         return _BNReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                self.momentum, relu, self.training, self.sync,
-                               self.num_batches_tracked if self.training and x.shape[0] else None)
+                               self.num_batches_tracked if self.training and (x.shape[0] or (self.sync and _dist_on())) else None)
 
 
 # ----------------------------------------------------------------------------------------

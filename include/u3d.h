@@ -235,6 +235,20 @@ int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, c
  * ===================================================================================== */
 int u3d_gemm_nt(const float* A /*[M,K]*/, const float* W /*[N,K]*/, const float* bias /*[N] or NULL*/, float* C /*[M,N]*/,
                 int64_t M, int N, int K /* % 16 == 0 */, double flops_hint, u3d_stream_t stream);
+/* Linear + activation in the GEMM epilogue (no separate elementwise kernel): Y = act(X W^T + bias), act: 0 none, 1 ReLU,
+ * 2 GELU (erf form, unidet3d/encoder.py:58-59 `nn.GELU()`).  For GELU `pre` [M,N] receives X W^T + bias (kept for backward). */
+int u3d_linear_act(const float* X /*[M,K]*/, const float* W /*[N,K]*/, const float* bias, int act, float* pre, float* Y /*[M,N]*/,
+                   int64_t M, int N, int K, double flops_hint, u3d_stream_t stream);
+/* input gradient THROUGH the activation: dX = (dY Wt^T) * act'(aux), Wt [N,K] = the next layer's weight transposed;
+ * aux [M,N] = the ReLU output (act 1) or the GELU pre-activation (act 2). */
+int u3d_linear_dact(const float* dY /*[M,K]*/, const float* Wt /*[N,K]*/, const float* aux, int act, float* dX /*[M,N]*/,
+                    int64_t M, int N, int K, double flops_hint, u3d_stream_t stream);
+/* SURVEY.md 8(b) `ffn`: Z = act(X W1^T + b1) W2^T + b2 in two launches -- the FFN block (encoder.py:55-61, act 2), input_proj
+ * (:138-140, act 1) and the class head (:153-155, act 1).  A [M,hid] receives the activation, H [M,hid] the GELU
+ * pre-activation (NULL for ReLU); both are what the backward pass needs (u3d_linear_dact, u3d_gemm_tn). */
+int u3d_ffn_fwd(const float* X, const float* W1 /*[hid,d_in]*/, const float* b1, const float* W2 /*[d_out,hid]*/, const float* b2,
+                int act, float* H, float* A, float* Z /*[M,d_out]*/, int64_t M, int d_in, int hid, int d_out, double flops_hint,
+                u3d_stream_t stream);
 /* colsum_A (nullable, [N]): column sums of A -- the bias gradient of the Linear layer -- produced by the same pass */
 int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[N,K] = A^T B*/, float* colsum_A, int64_t M, int N, int K,
                 void* ws, double flops_hint, u3d_stream_t stream);

@@ -290,6 +290,7 @@ class ODetector(nn.Module):
     def extract_feat(self, points: List[torch.Tensor], superpoints: List[torch.Tensor], elastic_coords=None):
         """collate + SparseConvTensor + extract_feat (unidet3d.py:349-357); elastic_coords as in :351."""
         coords, feats, inverse, shape = so.voxelize(points, self.voxel_size, self.min_spatial_shape, elastic_coords)
+        feats = feats.to(self.output_layer[0].weight.dtype)      # fp64 run of the oracle (gradient ground truth): same voxels, wider arithmetic
         x = OSparse(feats, coords, shape, len(points))
         x = self.input_conv(x)
         x, _ = self.unet(x)

@@ -107,8 +107,24 @@ def product_forward(prod, inputs, samples):
     return dict(loss=loss, feats=seen['feats'], out=seen['out'], coords=prod._vb.coords)
 
 
-def compare(name, P, O, prod, orac, grad_tol=None):
-    """Asserts the north-star tolerances and returns / logs the measured errors."""
+def oracle_fp64_grads(orac, run):
+    """Parameter gradients of the SAME oracle in float64 -- the ground truth the fp32 gradients of both the product and the
+    fp32 oracle are measured against.  ``run(model)`` must return the oracle_forward dict."""
+    import copy
+    o64 = copy.deepcopy(orac).double().train()
+    o64.zero_grad()
+    O = run(o64)
+    O['loss'].backward()
+    return {k: p.grad for k, p in o64.named_parameters() if p.grad is not None}
+
+
+def compare(name, P, O, prod, orac, g64=None):
+    """Asserts the north-star tolerances (features, logits, boxes, loss <= 1e-3 relative against the fp32 oracle) and returns /
+    logs the measured errors.  Backbone parameter gradients pass through ~90 batch-norm layers whose backward cancels the
+    mean and scale components of the incoming gradient: they are ill-conditioned in fp32 -- the CPU oracle itself moves by
+    5e-4 (median) to 4e-2 (worst parameter) of the largest entry when only the summation ORDER changes (two scenes swapped).
+    With ``g64`` (fp64 gradients of the oracle) the product's gradient error is therefore judged against the error the fp32
+    oracle has against the same ground truth."""
     n = len(O['feats'])
     assert torch.equal(P['coords'].cpu(), O['coords']), 'voxel coordinates differ from the oracle'
     err = dict(n_scenes=n, n_voxels=int(O['coords'].shape[0]),
@@ -134,9 +150,25 @@ def compare(name, P, O, prod, orac, grad_tol=None):
     err['grad_worst'] = sorted(grads.items(), key=lambda kv: -kv[1])[:5]
     err['grad_decoder_max'] = max(v for k, v in grads.items() if k.startswith('decoder.'))
     err['grad_backbone_max'] = max(v for k, v in grads.items() if not k.startswith('decoder.'))
+    if g64 is not None:
+        pp = dict(prod.named_parameters())
+        e_prod = {k: rel(pp[k].grad, g) for k, g in g64.items()}
+        e_orac = {k: rel(og[k].grad, g) for k, g in g64.items()}
+        bb = [k for k in g64 if not k.startswith('decoder.')]
+        err['vs_fp64'] = dict(
+            product_backbone_median=float(np.median([e_prod[k] for k in bb])), product_backbone_max=max(e_prod[k] for k in bb),
+            oracle32_backbone_median=float(np.median([e_orac[k] for k in bb])), oracle32_backbone_max=max(e_orac[k] for k in bb),
+            product_decoder_max=max(v for k, v in e_prod.items() if k.startswith('decoder.')),
+            oracle32_decoder_max=max(v for k, v in e_orac.items() if k.startswith('decoder.')),
+            product_worst=sorted(e_prod.items(), key=lambda kv: -kv[1])[:3], oracle32_worst=sorted(e_orac.items(), key=lambda kv: -kv[1])[:3])
     log_errors(name, err)
     print(name, json.dumps({k: v for k, v in err.items() if k != 'grad_worst'}))
     assert err['feats'] < 1e-3 and err['logits'] < 1e-3 and err['boxes'] < 1e-3 and err['loss'] < 1e-3, err
-    if grad_tol is not None:
-        assert err['grad_decoder_max'] < grad_tol[0] and err['grad_backbone_max'] < grad_tol[1], err
+    assert err['grad_decoder_max'] < 1e-3, err              # well-conditioned part: the north-star tolerance applies as is
+    if g64 is not None:
+        v = err['vs_fp64']
+        assert v['product_decoder_max'] < 1e-3, v
+        # ill-conditioned part: no worse than a small multiple of what fp32 arithmetic on the CPU delivers for the same quantity
+        assert v['product_backbone_median'] < 10 * v['oracle32_backbone_median'] + 1e-3, v
+        assert v['product_backbone_max'] < 4 * v['oracle32_backbone_max'] + 2e-2, v
     return err

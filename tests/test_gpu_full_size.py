@@ -5,8 +5,9 @@
 * cfg4 -- the reference's 6-dataset joint config (model dict captured from the real config file): a mixed batch of 8 scenes
   over all six datasets incl. 7-dof ARKitScenes ground truth, ``target_by_distance`` / ``get_targets`` and boxes given by the
   dataset; plus ``predict`` through the fast_nms=False (S3DIS) and rotated (ARKitScenes) NMS branches.
-Measured errors go to gpurun_out/parity_errors.jsonl (kept copy: profiles/round2_parity_errors.jsonl); the gradient
-tolerances asserted here are ~3x what was measured on the MI355X.
+Measured errors go to gpurun_out/parity_errors.jsonl (kept copy: profiles/round2_parity_errors.jsonl).  Gradients of the
+backbone are ill-conditioned in fp32 (see _parity.compare): they are judged against an fp64 run of the oracle, next to the
+error the fp32 CPU oracle has against that same ground truth.
 """
 import json
 import os
@@ -67,12 +68,11 @@ def test_cfg2_full_size_end_to_end_vs_oracle():
     prod, orac = PA.build_pair(cfg)
     scenes = [make_scene(i, n_points=100_000) for i in range(8)]
     O = PA.oracle_forward(orac, scenes, ['scannet'] * 8)
+    g64 = PA.oracle_fp64_grads(orac, lambda m: PA.oracle_forward(m, scenes, ['scannet'] * 8))
     inputs, samples = make_batch_inputs(scenes, DEV)
     P = PA.product_forward(prod, inputs, samples)
     assert len(P['out']['aux_outputs']) == 6                                 # 7 heads in total
-    # measured on MI355X (profiles/round2_parity_errors.jsonl): decoder grads ~1e-4, backbone grads <= ~1e-2 (90 BN layers, the
-    # deepest over ~1 k voxels, and a discrete matcher in between)
-    PA.compare('cfg2_full_size_8x100k', P, O, prod, orac, grad_tol=(5e-3, 5e-2))
+    PA.compare('cfg2_full_size_8x100k', P, O, prod, orac, g64)
 
 
 def _joint_cfg():
@@ -121,14 +121,16 @@ def test_cfg4_joint_config_mixed_batch_vs_oracle():
     prod, orac = PA.build_pair(cfg, tag0=5000)
     assert prod.decoder.datasets == ['scannet', 's3dis', 'multiscan', '3rscan', 'scannetpp', 'arkitscenes']
     scenes, names, gt_boxes, inputs, samples = _joint_batch(cfg)
-    O = PA.oracle_forward(orac, scenes, names, crit_cfg=cfg['criterion'], gt_boxes=gt_boxes, train_topk=cfg['train_cfg']['topk'])
+    kw = dict(crit_cfg=cfg['criterion'], gt_boxes=gt_boxes, train_topk=cfg['train_cfg']['topk'])
+    O = PA.oracle_forward(orac, scenes, names, **kw)
+    g64 = PA.oracle_fp64_grads(orac, lambda m: PA.oracle_forward(m, scenes, names, **kw))
     P = PA.product_forward(prod, inputs, samples)
     assert P['out']['bboxes'][1].shape[1] == 7 and P['out']['bboxes'][0].shape[1] == 6            # ARKitScenes head is 7-dof
     for i, ds in enumerate(samples):                                           # target assignment is integer work: exact
         assert torch.equal(ds.gt_instances_3d.sp_masks.cpu(), O['insts'][i].sp_masks), names[i]
         assert PA.rel(ds.gt_instances_3d.sp_centers, O['centers'][i]) < 1e-5
         assert PA.rel(ds.gt_instances_3d.bboxes_3d.gravity_center, O['insts'][i].bboxes_3d.gravity_center) < 1e-5
-    PA.compare('cfg4_joint_mixed_batch', P, O, prod, orac, grad_tol=(5e-3, 5e-2))
+    PA.compare('cfg4_joint_mixed_batch', P, O, prod, orac, g64)
 
 
 @pytest.mark.parametrize('name', ['s3dis', 'arkitscenes', '3rscan'])

@@ -113,54 +113,22 @@ def _build_pair(num_layers=6):
 
 @pytest.mark.parametrize('n_scenes,n_points,vs', [(1, 10_000, 0.05), (2, 20_000, 0.02)])
 def test_end_to_end_features_logits_boxes_loss_grads(n_scenes, n_points, vs):
+    """BASELINE configs[0] (one 10 k-point scene, 5 cm voxels) and a 2-scene 2 cm batch through the shared harness
+    (tests/_parity.py): coordinates bit-exact; per-superpoint features, class logits AND boxes of all 7 heads, loss <= 1e-3;
+    every parameter gradient against the fp64 oracle (the full-size cfg2 / cfg4 runs are in test_gpu_full_size.py)."""
+    import _parity as PA
+    from unidet3d_amd.config import scannet_model_cfg
     from unidet3d_amd.data import make_batch_inputs
     from unidet3d_amd.synthetic import make_scene
-    prod, orac, cfg = _build_pair()
-    prod.voxel_size = orac.voxel_size = vs
+    cfg = scannet_model_cfg(voxel_size=vs)
+    prod, orac = PA.build_pair(cfg)
     scenes = [make_scene(40 + i, n_points=n_points) for i in range(n_scenes)]
-    # ---- oracle (CPU) ----
-    pts = [torch.from_numpy(s.points) for s in scenes]
-    sps = [torch.from_numpy(s.superpoints) for s in scenes]
-    orac.train()
-    ofeats, ox = orac.extract_feat(pts, sps)
-    ocent = orac.sp_centers(pts, sps)
-    oout = orac.decoder(ofeats, ocent, ['scannet'] * n_scenes)
-    insts = [oc.gt_from_scene(p[:, :3] - p[:, :3].min(0)[0], torch.from_numpy(s.instance_mask),
-                              torch.from_numpy(s.labels), sp) for p, s, sp in zip(pts, scenes, sps)]
-    oloss = oc.criterion(oout, insts)
-    oloss.backward()
-    # ---- product (GPU) ----
-    prod.train()
+    names = ['scannet'] * n_scenes
+    O = PA.oracle_forward(orac, scenes, names)
+    g64 = PA.oracle_fp64_grads(orac, lambda m: PA.oracle_forward(m, scenes, names))
     inputs, samples = make_batch_inputs(scenes, DEV)
-    loss = prod.loss(inputs, samples)['det_loss']
-    loss.backward()
-    # features / logits / boxes through a second, hook-free forward of the same modules
-    prod.zero_grad(set_to_none=False)
-    with torch.no_grad():
-        raw = prod.predict_raw(inputs, samples)          # train-mode BN (module still in train()) but no grad
-    assert abs(loss.item() - oloss.item()) < 1e-3 * abs(oloss.item()), (loss.item(), oloss.item())
-    # bit-exact integer side
-    assert torch.equal(prod._vb.coords.cpu(), ox.indices)
-    for i in range(n_scenes):
-        # predict_raw uses raw (unshifted) superpoint centres: compare class logits (centre independent)
-        assert _rel(raw['cls_preds'][i], oout['cls_preds'][i]) < 1e-3
-    # gradients of the first and last layers of the path
-    og = dict(orac.named_parameters())
-    # re-run loss for grads (zero_grad above cleared them)
-    loss = prod.loss(inputs, samples)['det_loss']
-    loss.backward()
-    rels = {}
-    for k in ('input_conv.0.weight', 'unet.blocks.block0.conv_branch.2.weight', 'unet.u.u.u.u.blocks.block1.conv_branch.5.weight',
-              'unet.deconv.2.weight', 'unet.blocks_tail.block0.i_branch.0.weight', 'output_layer.0.weight',
-              'decoder.input_proj.0.weight', 'decoder.self_attn_layers.5.attn.in_proj_weight', 'decoder.out_bboxes.linear.weight'):
-        g = dict(prod.named_parameters())[k].grad
-        assert g is not None and torch.isfinite(g).all(), k
-        rels[k] = _rel(g, og[k].grad)
-    print('grad rel err vs oracle:', {k: f'{v:.2e}' for k, v in rels.items()})
-    # gradients pass through ~90 BN layers (the deepest over a few dozen voxels) and a discrete matcher:
-    # 5e-2 of the largest entry bounds fp32 reassociation noise there; the decoder-side grads sit near 1e-4
-    assert max(rels.values()) < 5e-2, rels
-    assert rels['decoder.out_bboxes.linear.weight'] < 5e-3 and rels['decoder.input_proj.0.weight'] < 2e-2, rels
+    P = PA.product_forward(prod, inputs, samples)
+    PA.compare(f'e2e_{n_scenes}x{n_points}_{vs}', P, O, prod, orac, g64)
 
 
 def test_backbone_features_match_oracle_per_superpoint():
@@ -196,6 +164,26 @@ def test_dense_linear_fwd_bwd(M, K, N):
     yg = linear(xg, wg, bg); yg.backward(go.to(DEV))
     assert _rel(yg, yo) < 1e-5 and _rel(xg.grad, xo.grad) < 1e-5
     assert _rel(wg.grad, wo.grad) < 2e-5 and _rel(bg.grad, bo.grad) < 1e-5
+
+
+# ---------------------------------------------------------------------------- fused MLP (u3d_ffn_fwd / u3d_linear_dact)
+@pytest.mark.parametrize('M,d_in,hid,d_out,act', [(16001, 256, 1024, 256, 'gelu'), (4097, 32, 256, 256, 'relu'), (2500, 256, 256, 19, 'relu'),
+                                                    (333, 256, 1024, 256, 'relu'), (1, 256, 256, 8, 'gelu'), (0, 32, 256, 256, 'relu')])
+def test_mlp_fused_epilogues_fwd_bwd(M, d_in, hid, d_out, act):
+    """Linear -> activation -> Linear with bias/activation in the GEMM epilogues vs torch in float64 (erf GELU as nn.GELU())."""
+    from unidet3d_amd.dense import mlp
+    g = torch.Generator().manual_seed(M + hid + d_out)
+    x = torch.randn(M, d_in, generator=g); w1 = torch.randn(hid, d_in, generator=g) * 0.1; b1 = torch.randn(hid, generator=g)
+    w2 = torch.randn(d_out, hid, generator=g) * 0.05; b2 = torch.randn(d_out, generator=g); go = torch.randn(M, d_out, generator=g)
+    ref = [t.clone().double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    h = torch.nn.functional.linear(ref[0], ref[1], ref[2])
+    a = torch.relu(h) if act == 'relu' else torch.nn.functional.gelu(h)
+    zo = torch.nn.functional.linear(a, ref[3], ref[4]); zo.backward(go.double())
+    dev = [t.clone().to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+    z = mlp(*dev, act); z.backward(go.to(DEV))
+    assert _rel(z, zo) < 1e-5
+    for name, d, r in zip(('x', 'w1', 'b1', 'w2', 'b2'), dev, ref):
+        assert d.grad is not None and _rel(d.grad, r.grad) < 3e-5, name
 
 
 # ---------------------------------------------------------------------------- elastic training frame (unidet3d.py:295-299)

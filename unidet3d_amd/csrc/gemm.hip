@@ -29,9 +29,22 @@ constexpr int GLD = GK + 4;    // padded LDS row of the NT tiles
 // invariant (no VALU in the K loop for addressing -- VALU time adds to MFMA time on this hardware), and rows past M / N
 // read as zeros through the descriptor's bounds check instead of a compare + select.  The epilogue stores through a
 // bounds-checked descriptor the same way (row offset scalar, column offset per lane, out-of-range lanes dropped).
-template <int TN>
+// Epilogues (EPI) -- the decoder's MLPs (unidet3d/encoder.py:55-61 FFN, :138-140 input_proj, :153-155 outs_cls) without
+// separate elementwise kernels:
+//   0  C = acc + bias                                   plain nn.Linear
+//   1  C = relu(acc + bias)                             Linear + ReLU
+//   2  pre = acc + bias, C = gelu(pre)                  Linear + GELU (erf form, torch's default); pre is kept for backward
+//   3  C = aux > 0 ? acc : 0                            input gradient through ReLU   (aux = the ReLU output)
+//   4  C = acc * gelu'(aux)                             input gradient through GELU   (aux = the pre-activation)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+template <int TN, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
-                                                 float* __restrict__ C, int64_t M, int N, int K) {
+                                                 float* __restrict__ C, int64_t M, int N, int K, const float* __restrict__ aux,
+                                                 float* __restrict__ pre) {
     constexpr int NB = TN / 64;                 // 32-column MFMA tiles per wave
     __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][TN * GLD];
@@ -99,6 +112,7 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
     }
     // D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(C + m0 * N, (int64_t)rows_a * N * 4);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((EPI == 2 ? (const float*)pre : aux) + (EPI >= 2 ? m0 * N : 0), (int64_t)rows_a * N * 4);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int n = n0 + wc * (TN / 2) + b * 32 + i32;
@@ -110,6 +124,17 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
                 float v = acc[a][b][r] + bv;
+                if constexpr (EPI == 1) v = fmaxf(v, 0.f);
+                if constexpr (EPI == 2) {
+                    float h = v;
+                    asm volatile("" : "+v"(h));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rs_x, vc, row * N * 4, 0);
+                    v = gelu_f(v);
+                }
+                if constexpr (EPI == 3 || EPI == 4) {       // rows / columns outside the tile read as 0 through the descriptor
+                    const float x = __builtin_bit_cast(float, bload32(rs_x, vc, row * N * 4));
+                    v = EPI == 3 ? (x > 0.f ? v : 0.f) : v * gelu_grad_f(x);
+                }
                 asm volatile("" : "+v"(v));          // see gemm_tn_k: keeps the store builtin from mis-selecting the vector element
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, vc, row * N * 4, 0);
             }
@@ -255,25 +280,64 @@ static int tn_splits(int64_t M, int N, int K) {
     return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
 }
 
+template <int EPI>
+static void launch_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, const float* aux, float* pre,
+                      hipStream_t s) {
+    // 128x64 tiles when 128x128 would leave the 256 CUs with fewer than two workgroups each
+    if (ceil_div(M, GT) * ceil_div(N, GT) < 512)
+        hipLaunchKernelGGL((gemm_nt_k<64, EPI>), dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    else
+        hipLaunchKernelGGL((gemm_nt_k<128, EPI>), dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, GT)), dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+}
+
+static int gemm_nt_epi(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int epi, const float* aux,
+                       float* pre, double flops_hint, hipStream_t s) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 4 || (epi == 2 && !pre) || (epi >= 3 && !aux)) return U3D_EINVAL;
+    if (K % GK) { set_error("gemm_nt: K=%d must be a multiple of %d", K, GK); return U3D_EUNSUPPORTED; }
+    ProfScope prof(U3D_K_GEMM, s, flops_hint);
+    if ((int64_t)GT * K * 4 >= 0x7fffffffLL || (int64_t)GT * N * 4 >= 0x7fffffffLL) { set_error("gemm_nt: N=%d / K=%d too large for 32-bit tile offsets", N, K); return U3D_EUNSUPPORTED; }
+    switch (epi) {
+        case 0: launch_nt<0>(A, W, bias, C, M, N, K, aux, pre, s); break;
+        case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, s); break;
+        case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, s); break;
+        case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, s); break;
+        default: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, s); break;
+    }
+    return check_launch("gemm_nt");
+}
+
 }  // namespace u3d
 
 using namespace u3d;
 
 extern "C" {
 
+
 int u3d_gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, double flops_hint,
                 u3d_stream_t stream) {
-    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return U3D_EINVAL;
-    if (K % GK) { set_error("gemm_nt: K=%d must be a multiple of %d", K, GK); return U3D_EUNSUPPORTED; }
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(U3D_K_GEMM, s, flops_hint);
-    if ((int64_t)GT * K * 4 >= 0x7fffffffLL || (int64_t)GT * N * 4 >= 0x7fffffffLL) { set_error("gemm_nt: N=%d / K=%d too large for 32-bit tile offsets", N, K); return U3D_EUNSUPPORTED; }
-    // 128x64 tiles when 128x128 would leave the 256 CUs with fewer than two workgroups each
-    if (ceil_div(M, GT) * ceil_div(N, GT) < 512)
-        hipLaunchKernelGGL(gemm_nt_k<64>, dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, W, bias, C, M, N, K);
-    else
-        hipLaunchKernelGGL(gemm_nt_k<128>, dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, GT)), dim3(256), 0, s, A, W, bias, C, M, N, K);
-    return check_launch("gemm_nt");
+    return gemm_nt_epi(A, W, bias, C, M, N, K, 0, nullptr, nullptr, flops_hint, (hipStream_t)stream);
+}
+
+int u3d_linear_act(const float* X, const float* W, const float* bias, int act, float* pre, float* Y, int64_t M, int N, int K,
+                   double flops_hint, u3d_stream_t stream) {
+    if (act < 0 || act > 2) return U3D_EINVAL;
+    return gemm_nt_epi(X, W, bias, Y, M, N, K, act, nullptr, pre, flops_hint, (hipStream_t)stream);
+}
+
+int u3d_linear_dact(const float* dY, const float* Wt, const float* aux, int act, float* dX, int64_t M, int N, int K, double flops_hint,
+                    u3d_stream_t stream) {
+    if (act < 0 || act > 2) return U3D_EINVAL;
+    return gemm_nt_epi(dY, Wt, nullptr, dX, M, N, K, act == 0 ? 0 : act + 2, aux, nullptr, flops_hint, (hipStream_t)stream);
+}
+
+int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, int act, float* H, float* A, float* Z,
+                int64_t M, int d_in, int hid, int d_out, double flops_hint, u3d_stream_t stream) {
+    if (act != 1 && act != 2) return U3D_EINVAL;
+    if (!A || !Z) return U3D_EINVAL;
+    const double f1 = flops_hint > 0 ? 2.0 * M * d_in * hid : 0.0, f2 = flops_hint > 0 ? 2.0 * M * hid * d_out : 0.0;
+    int rc = gemm_nt_epi(X, W1, b1, A, M, hid, d_in, act, nullptr, H, f1, (hipStream_t)stream);
+    if (rc) return rc;
+    return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, 0, nullptr, nullptr, f2, (hipStream_t)stream);
 }
 
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K) * ((int64_t)N * K + N) * 4 + 256; }

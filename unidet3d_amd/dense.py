@@ -24,6 +24,67 @@ def _gemm_nt(a, w, bias):
     return c
 
 
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def _flops(M, N, K):
+    return 2.0 * M * N * K if _PROFILE_FLOPS else 0.0
+
+
+def _input_grad(dy, weight, act=ACT_NONE, aux=None):
+    """dX[M,K] = dY[M,N] . W[N,K], optionally times act'(aux) in the GEMM epilogue (u3d_linear_dact): the input gradient
+    THROUGH the activation that produced this layer's input (aux = its ReLU output / GELU pre-activation)."""
+    M, N = dy.shape
+    K = weight.shape[1]
+    dev = dy.device
+    if N % 16 == 0:
+        wt = torch.empty(K, N, dtype=torch.float32, device=dev)
+        L.call('u3d_transpose', L.ptr(weight.contiguous()), L.ptr(wt), N, K, L.stream())
+    else:                                               # tiny heads (N = 19, 8): pad the reduction dim to 16 with zero columns
+        Np = (N + 15) // 16 * 16
+        wt = torch.zeros(K, Np, dtype=torch.float32, device=dev)
+        wt[:, :N] = weight.t()
+        dyp = torch.zeros(M, Np, dtype=torch.float32, device=dev)
+        dyp[:, :N] = dy
+        dy, N = dyp, Np
+    if act == ACT_NONE:
+        return _gemm_nt(dy, wt, None)
+    dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+    if M:
+        L.call('u3d_linear_dact', L.ptr(dy), L.ptr(wt), L.ptr(aux), act, L.ptr(dx), M, K, N, _flops(M, K, N), L.stream())
+    return dx
+
+
+def _weight_grad(dy, x, want_bias):
+    """(dW[N,K] = dY^T X, db[N] = column sums of dY or None): one pass of u3d_gemm_tn (+ fixed-order reduce)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dev = dy.device
+    db = None
+    dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+    if M and N % 4 == 0:
+        ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, N, K), dev)
+        if want_bias:                                   # the bias gradient (column sums of dy) rides along
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+        L.call('u3d_gemm_tn', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), M, N, K, L.ptr(ws), _flops(M, N, K), L.stream())
+    elif M:
+        Np = (N + 3) // 4 * 4
+        dyp = torch.zeros(M, Np, dtype=torch.float32, device=dev)
+        dyp[:, :N] = dy
+        dwp = torch.empty(Np, K, dtype=torch.float32, device=dev)
+        ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, Np, K), dev)
+        dbp = torch.empty(Np, dtype=torch.float32, device=dev) if want_bias else None
+        L.call('u3d_gemm_tn', L.ptr(dyp), L.ptr(x), L.ptr(dwp), L.ptr(dbp), M, Np, K, L.ptr(ws), 0.0, L.stream())
+        dw = dwp[:N].contiguous()
+        if dbp is not None:
+            db = dbp[:N].contiguous()
+    else:
+        dw.zero_()
+        if want_bias:
+            db = torch.zeros(N, dtype=torch.float32, device=dev)
+    return dw, db
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -36,42 +97,11 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        M, K = x.shape
-        N = weight.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if N % 16 == 0:
-                wt = torch.empty(K, N, dtype=torch.float32, device=weight.device)
-                L.call('u3d_transpose', L.ptr(weight.contiguous()), L.ptr(wt), N, K, L.stream())
-                dx = _gemm_nt(dy, wt, None)                     # dX[M,K] = dY[M,N] . (W^T)[K,N]^T
-            else:                                               # tiny heads (N = 19, 8): pad N to 16 with zero columns
-                Np = (N + 15) // 16 * 16
-                wt = torch.zeros(K, Np, dtype=torch.float32, device=weight.device)
-                wt[:, :N] = weight.t()
-                dyp = torch.zeros(M, Np, dtype=torch.float32, device=dy.device)
-                dyp[:, :N] = dy
-                dx = _gemm_nt(dyp, wt, None)
+            dx = _input_grad(dy, weight)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(N, K, dtype=torch.float32, device=weight.device)
-            if M and N % 4 == 0:
-                ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, N, K), weight.device)
-                if ctx.has_bias and ctx.needs_input_grad[2]:      # the bias gradient (column sums of dy) rides along
-                    db = torch.empty(N, dtype=torch.float32, device=weight.device)
-                L.call('u3d_gemm_tn', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), M, N, K, L.ptr(ws),
-                       2.0 * M * N * K if _PROFILE_FLOPS else 0.0, L.stream())
-            elif M:
-                Np = (N + 3) // 4 * 4
-                dyp = torch.zeros(M, Np, dtype=torch.float32, device=dy.device)
-                dyp[:, :N] = dy
-                dwp = torch.empty(Np, K, dtype=torch.float32, device=weight.device)
-                ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, Np, K), weight.device)
-                dbp = torch.empty(Np, dtype=torch.float32, device=weight.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
-                L.call('u3d_gemm_tn', L.ptr(dyp), L.ptr(x), L.ptr(dwp), L.ptr(dbp), M, Np, K, L.ptr(ws), 0.0, L.stream())
-                dw = dwp[:N].contiguous()
-                if dbp is not None:
-                    db = dbp[:N].contiguous()
-            else:
-                dw.zero_()
+            dw, db = _weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db
@@ -80,6 +110,44 @@ class _LinearFn(torch.autograd.Function):
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     """y = x W^T + b for 2-D x [M, K] (K % 16 == 0)."""
     return _LinearFn.apply(x, weight, bias)
+
+
+class _MLPFn(torch.autograd.Function):
+    """z = act(x W1^T + b1) W2^T + b2 (include/u3d.h u3d_ffn_fwd): bias and activation live in the first GEMM's epilogue, the
+    activation's derivative in the epilogue of the GEMM that produces the hidden gradient -- no elementwise kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act):
+        x = x.contiguous()
+        M, d_in = x.shape
+        hid, d_out = w1.shape[0], w2.shape[0]
+        dev = x.device
+        a = torch.empty(M, hid, dtype=torch.float32, device=dev)
+        h = torch.empty(M, hid, dtype=torch.float32, device=dev) if act == ACT_GELU else None
+        z = torch.empty(M, d_out, dtype=torch.float32, device=dev)
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        if M:
+            L.call('u3d_ffn_fwd', L.ptr(x), L.ptr(w1c), L.ptr(b1), L.ptr(w2c), L.ptr(b2), act, L.ptr(h), L.ptr(a), L.ptr(z),
+                   M, d_in, hid, d_out, 1.0 if _PROFILE_FLOPS else 0.0, L.stream())
+        ctx.save_for_backward(x, w1c, w2c, a, h)
+        ctx.act, ctx.bias = act, (b1 is not None, b2 is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w1, w2, a, h = ctx.saved_tensors
+        dz = dz.contiguous()
+        need = ctx.needs_input_grad
+        dw2, db2 = _weight_grad(dz, a, ctx.bias[1] and need[4]) if need[3] else (None, None)
+        dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a)
+        dw1, db1 = _weight_grad(dh, x, ctx.bias[0] and need[2]) if need[1] else (None, None)
+        dx = _input_grad(dh, w1) if need[0] else None
+        return dx, dw1, db1, dw2, db2, None
+
+
+def mlp(x, w1, b1, w2, b2, act: str) -> torch.Tensor:
+    """Linear -> ReLU / GELU -> Linear on 2-D x (d_in, hidden % 16 == 0)."""
+    return _MLPFn.apply(x, w1, b1, w2, b2, {'relu': ACT_RELU, 'gelu': ACT_GELU}[act])
 
 
 class _LayerNormFn(torch.autograd.Function):

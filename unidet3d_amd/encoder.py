@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .dense import LayerNorm, linear
+from .dense import LayerNorm, linear, mlp
 from .registry import MODELS
 
 
@@ -100,11 +100,11 @@ class FFN(nn.Module):                         # encoder.py:43-80
         self.net = nn.Sequential(nn.Linear(d_model, hidden_dim), nn.ReLU() if activation_fn == 'relu' else nn.GELU(),
                                  nn.Dropout(dropout), nn.Linear(hidden_dim, d_model), nn.Dropout(dropout))
         self.norm = LayerNorm(d_model)
+        self.act = 'relu' if activation_fn == 'relu' else 'gelu'
 
     def forward(self, x):
-        h = linear(x, self.net[0].weight, self.net[0].bias)
-        h = self.net[1](h)
-        return self.norm(linear(h, self.net[3].weight, self.net[3].bias), x)
+        # bias + activation in the first GEMM's epilogue, residual add inside the LayerNorm kernel
+        return self.norm(mlp(x, self.net[0].weight, self.net[0].bias, self.net[3].weight, self.net[3].bias, self.act), x)
 
 
 class PredBBox(nn.Module):                    # encoder.py:82-111
@@ -164,14 +164,17 @@ class UniDet3DEncoder(nn.Module):
         With a single dataset in the batch the class-column select and the box decode also run once
         on the packed matrix and the per-scene outputs are views of it."""
         nq = self.out_norm(feats)
-        cls_all = linear(torch.relu(linear(nq, self.outs_cls[0].weight, self.outs_cls[0].bias)),
-                         self.outs_cls[2].weight, self.outs_cls[2].bias)
         box_all = self.out_bboxes(nq)
+        w1, b1, w2, b2 = self.outs_cls[0].weight, self.outs_cls[0].bias, self.outs_cls[2].weight, self.outs_cls[2].bias
         if len(set(datasets_names)) == 1:
+            # the dataset's class columns (encoder.py:192-194) are selected as ROWS of the [n_cls, d] output weight: the packed
+            # [sum n_i, n_cls] logit matrix is never gathered (nor scattered back in backward)
             idx = self.datasets.index(datasets_names[0])
-            cls_p = cls_all[:, self._cidx(idx, feats.device)]
+            cidx = self._cidx(idx, feats.device)
+            cls_p = mlp(nq, w1, b1, w2[cidx], b2[cidx], 'relu')
             box_p = _bbox_pred_to_bbox(centers_packed, box_all if self.angles[idx] else box_all[:, :6])
             return list(cls_p.split(sizes)), list(box_p.split(sizes)), (cls_p, box_p)
+        cls_all = mlp(nq, w1, b1, w2, b2, 'relu')
         cls_preds, boxes = [], []
         for i, (c, pb, name) in enumerate(zip(cls_all.split(sizes), box_all.split(sizes), datasets_names)):
             idx = self.datasets.index(name)
@@ -188,8 +191,7 @@ class UniDet3DEncoder(nn.Module):
         max_len = max(sizes) if sizes else 0
         centers_packed = torch.cat(sp_centers) if len(sp_centers) > 1 else sp_centers[0]
         x0 = torch.cat(x) if len(x) > 1 else x[0]
-        feats = linear(torch.relu(linear(x0, self.input_proj[0].weight, self.input_proj[0].bias)),
-                       self.input_proj[2].weight, self.input_proj[2].bias)
+        feats = mlp(x0, self.input_proj[0].weight, self.input_proj[0].bias, self.input_proj[2].weight, self.input_proj[2].bias, 'relu')
         outs = [self._forward_head(feats, sizes, sp_centers, centers_packed, datasets_names)]
         for i in range(self.num_layers):
             feats = self.self_attn_layers[i](feats, cu, max_len)

@@ -123,6 +123,13 @@ int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_packed, const
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst,
                    int tile_rows, int k_groups, const float* addend, float* dst, void* ws, double flops_hint,
                    u3d_stream_t stream);
+/* bf16-operand form (BASELINE configs[2], "MFMA bf16 on rule GEMM"): same arguments; src / dst / addend stay fp32, gathered
+ * rows are rounded to bf16 as the MFMA operand is formed, weights come pre-rounded from u3d_weight_pack_bf16 (Cd*K*Cs*2 bytes,
+ * fragment order of v_mfma_f32_16x16x32_bf16); fp32 accumulation.  Cs % 32 == 0. */
+int u3d_spconv_gmm_bf16(const float* src, int64_t n_src, const void* w_rows_bf16, const int32_t* gather, const int32_t* scatter,
+                        const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                        int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream);
+int u3d_weight_pack_bf16(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream);
 /* Launch plan for a shape: tile_rows (rows per wave-tile = the tile height to pass to u3d_tile_starts) and
  * k_groups (kernel offsets are split into that many groups when the level has too few rows to fill the chip;
  * the groups' partial sums go through ws = k_groups*n_dst*Cd*4 bytes and a fixed-order reduce).
@@ -227,6 +234,13 @@ int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, c
                         const int32_t* cu_seqlens, int B, int max_len, int64_t n_total, int H, int hd,
                         float scale, float* dqkv, float* delta_ws /*[H,n_total]*/, double flops_hint,
                         u3d_stream_t stream);
+/* bf16-operand form of the two calls above (BASELINE configs[2]): identical arguments and results layout; Q/K/V/dO tiles and
+ * the probabilities are rounded to bf16 for v_mfma_f32_16x16x32_bf16, softmax statistics and all accumulators stay fp32. */
+int u3d_attn_varlen_fwd_bf16(const float* qkv, const int32_t* cu_seqlens, int B, int max_len, int64_t n_total, int H, int hd,
+                             float scale, float* out, float* lse, double flops_hint, u3d_stream_t stream);
+int u3d_attn_varlen_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, const int32_t* cu_seqlens,
+                             int B, int max_len, int64_t n_total, int H, int hd, float scale, float* dqkv, float* delta_ws,
+                             double flops_hint, u3d_stream_t stream);
 
 /* =====================================================================================
  * K14  dense fp32 GEMMs of the decoder's nn.Linear layers (unidet3d/encoder.py:19-21,55-61,138-140,
@@ -235,6 +249,10 @@ int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, c
  * ===================================================================================== */
 int u3d_gemm_nt(const float* A /*[M,K]*/, const float* W /*[N,K]*/, const float* bias /*[N] or NULL*/, float* C /*[M,N]*/,
                 int64_t M, int N, int K /* % 16 == 0 */, double flops_hint, u3d_stream_t stream);
+/* OR-ed into `act` of u3d_linear_act / u3d_linear_dact / u3d_ffn_fwd: the MFMA operands are rounded to bf16 (round to nearest
+ * even) on their way into LDS -- data stays fp32 in HBM, accumulation and epilogues stay fp32 (BASELINE configs[2]; the
+ * reference trains with `--amp`, tools/train.py:86-99).  K must then be a multiple of 32. */
+#define U3D_BF16_OPERANDS 16
 /* Linear + activation in the GEMM epilogue (no separate elementwise kernel): Y = act(X W^T + bias), act: 0 none, 1 ReLU,
  * 2 GELU (erf form, unidet3d/encoder.py:58-59 `nn.GELU()`).  For GELU `pre` [M,N] receives X W^T + bias (kept for backward). */
 int u3d_linear_act(const float* X /*[M,K]*/, const float* W /*[N,K]*/, const float* bias, int act, float* pre, float* Y /*[M,N]*/,

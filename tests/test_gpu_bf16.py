@@ -1,0 +1,160 @@
+"""bf16-operand kernels (BASELINE configs[2]) on the MI355X.
+
+Two kinds of checks, as VERDICT r1 item 3 asks:
+  * against fp64 references at a bf16 tolerance (operands carry 8 mantissa bits: ~4e-3 relative per element);
+  * fp32-accumulate self-consistency: a bf16-operand GEMM / sparse conv must reproduce the FP32 kernel run on inputs that were
+    rounded to bf16 beforehand to ~1e-5 -- products of bf16 numbers are exact in fp32, so only the summation order differs.
+    This separates "rounding as designed" from indexing / layout mistakes, which the loose tolerance alone would hide.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12)) if a.numel() else 0.0
+
+
+def _rb(t):
+    """round to bf16 and back (round to nearest even, what v_cvt_pk_bf16_f32 does)"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# ---------------------------------------------------------------------------- dense Linear / MLP
+@pytest.mark.parametrize('M,K,N', [(1000, 256, 768), (16001, 256, 1024), (4097, 1024, 256), (333, 32, 256), (2500, 256, 19), (1, 256, 256)])
+def test_linear_bf16_self_consistent_and_close(M, K, N):
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.dense import linear
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * 0.1; b = torch.randn(N, generator=g)
+    go = torch.randn(M, N, generator=g)
+    xb, wb, bb = [t.clone().to(DEV).requires_grad_() for t in (x, w, b)]
+    with P.operands('bf16'):
+        yb = linear(xb, wb, bb)
+        yb.backward(go.to(DEV))
+    # (1) fp32 kernel on pre-rounded operands: forward and input gradient use rounded (x, w) / (dy, w)
+    xr, wr, br = [t.clone().to(DEV).requires_grad_() for t in (_rb(x), _rb(w), b)]
+    yr = linear(xr, wr, br)
+    assert _rel(yb, yr) < 2e-5
+    if N % 16 == 0:
+        dx_ref = linear(_rb(go).to(DEV), _rb(w).t().contiguous().to(DEV))      # dX = round(dY) . round(W)
+        assert _rel(xb.grad, dx_ref) < 2e-5
+    # (2) against fp64 at the bf16 tolerance; the weight gradient stays on the fp32 kernel
+    xo, wo, bo = [t.clone().double().requires_grad_() for t in (x, w, b)]
+    yo = torch.nn.functional.linear(xo, wo, bo); yo.backward(go.double())
+    assert _rel(yb, yo) < 1e-2 and _rel(xb.grad, xo.grad) < 1e-2
+    assert _rel(wb.grad, wo.grad) < 2e-5 and _rel(bb.grad, bo.grad) < 1e-5
+
+
+@pytest.mark.parametrize('M,d_in,hid,d_out,act', [(16001, 256, 1024, 256, 'gelu'), (4097, 32, 256, 256, 'relu'), (2500, 256, 256, 19, 'relu')])
+def test_mlp_bf16_close(M, d_in, hid, d_out, act):
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.dense import mlp
+    g = torch.Generator().manual_seed(M + hid)
+    x = torch.randn(M, d_in, generator=g); w1 = torch.randn(hid, d_in, generator=g) * 0.1; b1 = torch.randn(hid, generator=g)
+    w2 = torch.randn(d_out, hid, generator=g) * 0.05; b2 = torch.randn(d_out, generator=g); go = torch.randn(M, d_out, generator=g)
+    ref = [t.clone().double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    h = torch.nn.functional.linear(ref[0], ref[1], ref[2])
+    a = torch.relu(h) if act == 'relu' else torch.nn.functional.gelu(h)
+    zo = torch.nn.functional.linear(a, ref[3], ref[4]); zo.backward(go.double())
+    dev = [t.clone().to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+    with P.operands('bf16'):
+        z = mlp(*dev, act)
+        z.backward(go.to(DEV))
+    assert _rel(z, zo) < 1e-2
+    for name, d, r in zip(('x', 'w1', 'b1', 'w2', 'b2'), dev, ref):
+        assert _rel(d.grad, r.grad) < 2e-2, name
+
+
+# ---------------------------------------------------------------------------- attention
+@pytest.mark.parametrize('lens', [[48, 17], [1, 64, 65, 130], [333], [0, 5, 0, 700], [2100, 1900]])
+def test_attention_bf16_fwd_bwd(lens):
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.encoder import attention_varlen
+    H, hd = 8, 32
+    n = sum(lens)
+    g = torch.Generator().manual_seed(n)
+    qkv = torch.randn(n, 3 * H * hd, generator=g)
+    go = torch.randn(n, H * hd, generator=g)
+    ref_in = qkv.clone().double().requires_grad_()
+    outs, o = [], 0
+    for ln in lens:
+        x = ref_in[o:o + ln]; o += ln
+        q, k, v = x.chunk(3, -1)
+        q = q.view(ln, H, hd).transpose(0, 1); k = k.view(ln, H, hd).transpose(0, 1); v = v.view(ln, H, hd).transpose(0, 1)
+        a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), -1)
+        outs.append((a @ v).transpose(0, 1).reshape(ln, H * hd))
+    ref = torch.cat(outs); ref.backward(go.double())
+    x = qkv.clone().to(DEV).requires_grad_()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    with P.operands('bf16'):
+        out = attention_varlen(x, cu, max(lens), H)
+        out.backward(go.to(DEV))
+    xf = qkv.clone().to(DEV).requires_grad_()
+    outf = attention_varlen(xf, cu, max(lens), H)                        # fp32 kernels, same inputs
+    outf.backward(go.to(DEV))
+    e_out, e_grad = _rel(out, ref), _rel(x.grad, ref_in.grad)
+    print(f'attention bf16 lens={lens}: out {e_out:.2e} grad {e_grad:.2e} (fp32 kernel: {_rel(outf, ref):.1e} / {_rel(xf.grad, ref_in.grad):.1e})')
+    assert e_out < 2e-2 and e_grad < 3e-2
+    # the error must be rounding noise, not structure: mean absolute error well below the max-norm bound
+    assert float((out.double().cpu() - ref).abs().mean() / ref.abs().mean()) < 1e-2
+
+
+# ---------------------------------------------------------------------------- sparse convolution ("MFMA bf16 on rule GEMM")
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (64, 64), (128, 64), (96, 96), (192, 96), (128, 128), (256, 128), (160, 160), (16, 32)])
+def test_subm_conv_bf16_self_consistent_and_close(cin, cout):
+    """SubM 3x3x3 conv forward + input gradient with bf16 operands == the fp32 kernel on pre-rounded operands (1e-5), and
+    within bf16 tolerance of the fp32 result on the original operands.  (16 -> 32, the padded input conv, stays fp32.)"""
+    from oracle import sparse_ops as so
+    from unidet3d_amd import ops, sparse, precision as P
+    from unidet3d_amd.synthetic import make_scene
+    scenes = [make_scene(21 + i, n_points=12_000) for i in range(2)]
+    vb = ops.voxelize([torch.from_numpy(s.points).to(DEV) for s in scenes], 0.05, 128)
+    n = vb.coords.shape[0]
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(n, cin, generator=g); w = torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1
+    add = torch.randn(n, cout, generator=g); go = torch.randn(n, cout, generator=g)
+
+    def run(xx, ww, gg, mode):
+        xd, wd, ad = xx.clone().to(DEV).requires_grad_(), ww.clone().to(DEV).requires_grad_(), add.clone().to(DEV).requires_grad_()
+        with P.operands(mode):
+            y = sparse.sparse_conv(xd, wd, rb, 'fwd', ad)
+            y.backward(gg.to(DEV))
+        return y, xd.grad, wd.grad
+    yb, dxb, dwb = run(x, w, go, 'bf16')
+    yr, _, _ = run(_rb(x), _rb(w), go, 'fp32')
+    _, dxr, _ = run(x, _rb(w), _rb(go), 'fp32')
+    yf, dxf, dwf = run(x, w, go, 'fp32')
+    tol_same = 2e-5 if cin % 32 == 0 else 1e-2          # 16-channel sources run the fp32 kernel: then yb == yf instead
+    assert _rel(yb, yr) < tol_same, 'forward is not the fp32 kernel on rounded operands'
+    if cout % 32 == 0:
+        assert _rel(dxb, dxr) < 2e-5, 'input gradient is not the fp32 kernel on rounded operands'
+    assert _rel(yb, yf) < 1e-2 and _rel(dxb, dxf) < 1e-2
+    assert _rel(dwb, dwf) < 1e-5                          # the weight gradient stays on fp32 operands
+
+
+def test_strided_and_inverse_conv_bf16():
+    from unidet3d_amd import ops, sparse, precision as P
+    from unidet3d_amd.synthetic import make_scene
+    sc = make_scene(5, n_points=15_000)
+    vb = ops.voxelize([torch.from_numpy(sc.points).to(DEV)], 0.05, 128)
+    oc, oshape, ix2, rb = sparse.build_down_rulebook(vb.coords, 1, vb.spatial_shape)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(vb.coords.shape[0], 32, generator=g); w = torch.randn(64, 2, 2, 2, 32, generator=g) * 0.1
+    wi = torch.randn(32, 2, 2, 2, 64, generator=g) * 0.1
+    outs = {}
+    for mode, xx, ww, wwi in (('bf16', x, w, wi), ('fp32', _rb(x), _rb(w), _rb(wi))):
+        with P.operands(mode):
+            y = sparse.sparse_conv(xx.to(DEV), ww.to(DEV), rb, 'fwd')
+            z = sparse.sparse_conv((y if mode == 'bf16' else _rb(y.cpu()).to(DEV)), wwi.to(DEV), rb, 'inv')
+        outs[mode] = (y, z)
+    assert _rel(outs['bf16'][0], outs['fp32'][0]) < 2e-5
+    assert _rel(outs['bf16'][1], outs['fp32'][1]) < 3e-3      # y itself differs in the last bits before it is rounded again

@@ -16,6 +16,7 @@
 namespace u3d {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define U3D_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 constexpr int GT = 128;        // macro tile (both dims)
@@ -39,6 +40,43 @@ constexpr int GLD = GK + 4;    // padded LDS row of the NT tiles
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// Shared epilogue of the NT kernels.  D layout of 32x32 MFMAs (dtype independent): col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <int TN, int EPI>
+__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[2][TN / 64], float* __restrict__ C, const float* __restrict__ bias,
+                                            const float* __restrict__ aux, float* __restrict__ pre, int64_t m0, int n0, int rows_a, int N,
+                                            int wr, int wc, int i32, int kh) {
+    constexpr int NB = TN / 64;
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(C + m0 * N, (int64_t)rows_a * N * 4);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((EPI == 2 ? (const float*)pre : aux) + (EPI >= 2 ? m0 * N : 0), (int64_t)rows_a * N * 4);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int n = n0 + wc * (TN / 2) + b * 32 + i32;
+        const float bv = (bias && n < N) ? bias[n] : 0.f;
+        const int vc = n < N ? (4 * kh * N + n) * 4 : 0x7fffffff;        // columns past N: dropped by the bounds check
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[a][b][r] + bv;
+                if constexpr (EPI == 1) v = fmaxf(v, 0.f);
+                if constexpr (EPI == 2) {
+                    float h = v;
+                    asm volatile("" : "+v"(h));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rs_x, vc, row * N * 4, 0);
+                    v = gelu_f(v);
+                }
+                if constexpr (EPI == 3 || EPI == 4) {       // rows / columns outside the tile read as 0 through the descriptor
+                    const float x = __builtin_bit_cast(float, bload32(rs_x, vc, row * N * 4));
+                    v = EPI == 3 ? (x > 0.f ? v : 0.f) : v * gelu_grad_f(x);
+                }
+                asm volatile("" : "+v"(v));          // see gemm_tn_k: keeps the store builtin from mis-selecting the vector element
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, vc, row * N * 4, 0);
+            }
+    }
 }
 
 template <int TN, int EPI>
@@ -110,35 +148,86 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
-    // D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(C + m0 * N, (int64_t)rows_a * N * 4);
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((EPI == 2 ? (const float*)pre : aux) + (EPI >= 2 ? m0 * N : 0), (int64_t)rows_a * N * 4);
+    nt_epilogue<TN, EPI>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
+}
+
+// bf16-operand form of gemm_nt_k (BASELINE configs[2]; the reference's `--amp` Linear layers): A and W are fp32 in HBM, rounded
+// to bf16 (RNE) while they are staged into LDS, multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; same tiling,
+// descriptors and epilogues.  A K-step is 32 deep (two MFMAs per tile pair); lane (i, h) holds k = 8h .. 8h+7 of each 16-deep
+// half, one 16-byte LDS read.  80-byte LDS rows keep the 16-byte reads of 32 consecutive rows conflict-free.
+constexpr int GKH = 32;        // K-step of the bf16 kernel
+constexpr int GLH = GKH + 8;   // padded LDS row (halves)
+
+template <int TN, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                      float* __restrict__ C, int64_t M, int N, int K, const float* __restrict__ aux,
+                                                      float* __restrict__ pre) {
+    constexpr int NB = TN / 64;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][GT * GLH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TN * GLH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * GT;
+    const int n0 = blockIdx.y * TN;
+    const int rows_a = (int)min((int64_t)GT, M - m0), rows_b = min(TN, N - n0);
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + m0 * K, (int64_t)rows_a * K * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(W + (int64_t)n0 * K, (int64_t)rows_b * K * 4);
+    // staging map: thread -> (row = tid>>2 (+64), 8 floats at column 8 * (tid&3))
+    const int srow = tid >> 2, sc8 = tid & 3;
+    const int vo = (srow * K + sc8 * 8) * 4, vstep = 64 * K * 4;
+    f32x4 ra[2][2], rb[NB][2];
+    auto gload = [&](int kt) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int n = n0 + wc * (TN / 2) + b * 32 + i32;
-        const float bv = (bias && n < N) ? bias[n] : 0.f;
-        const int vc = n < N ? (4 * kh * N + n) * 4 : 0x7fffffff;        // columns past N: dropped by the bounds check
+        for (int j = 0; j < 2; ++j) {
+            ra[j][0] = bload128(rs_a, vo + j * vstep, kt * (GKH * 4));
+            ra[j][1] = bload128(rs_a, vo + j * vstep + 16, kt * (GKH * 4));
+        }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int j = 0; j < NB; ++j) {
+            rb[j][0] = bload128(rs_b, vo + j * vstep, kt * (GKH * 4));
+            rb[j][1] = bload128(rs_b, vo + j * vstep + 16, kt * (GKH * 4));
+        }
+    };
+    auto cvt8 = [](const f32x4& lo, const f32x4& hi) {
+        return bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
-                float v = acc[a][b][r] + bv;
-                if constexpr (EPI == 1) v = fmaxf(v, 0.f);
-                if constexpr (EPI == 2) {
-                    float h = v;
-                    asm volatile("" : "+v"(h));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rs_x, vc, row * N * 4, 0);
-                    v = gelu_f(v);
-                }
-                if constexpr (EPI == 3 || EPI == 4) {       // rows / columns outside the tile read as 0 through the descriptor
-                    const float x = __builtin_bit_cast(float, bload32(rs_x, vc, row * N * 4));
-                    v = EPI == 3 ? (x > 0.f ? v : 0.f) : v * gelu_grad_f(x);
-                }
-                asm volatile("" : "+v"(v));          // see gemm_tn_k: keeps the store builtin from mis-selecting the vector element
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, vc, row * N * 4, 0);
-            }
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x8*>(&As[buf][(srow + 64 * j) * GLH + sc8 * 8]) = cvt8(ra[j][0], ra[j][1]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<bf16x8*>(&Bs[buf][(srow + 64 * j) * GLH + sc8 * 8]) = cvt8(rb[j][0], rb[j][1]);
+    };
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nk = K / GKH;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 af[2], bf[NB];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const bf16x8*>(&As[buf][(wr * 64 + t * 32 + i32) * GLH + h * 16 + kh * 8]);
+#pragma unroll
+            for (int t = 0; t < NB; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wc * (TN / 2) + t * 32 + i32) * GLH + h * 16 + kh * 8]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
     }
+    nt_epilogue<TN, EPI>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
 }
 
 constexpr int TLD = GT + 4;    // padded LDS row of the TN tiles ([16 rows][128 cols])
@@ -282,26 +371,34 @@ static int tn_splits(int64_t M, int N, int K) {
 
 template <int EPI>
 static void launch_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, const float* aux, float* pre,
-                      hipStream_t s) {
+                      bool bf16_operands, hipStream_t s) {
     // 128x64 tiles when 128x128 would leave the 256 CUs with fewer than two workgroups each
-    if (ceil_div(M, GT) * ceil_div(N, GT) < 512)
-        hipLaunchKernelGGL((gemm_nt_k<64, EPI>), dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, 64)), dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
-    else
-        hipLaunchKernelGGL((gemm_nt_k<128, EPI>), dim3((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, GT)), dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    const bool narrow = ceil_div(M, GT) * ceil_div(N, GT) < 512;
+    const dim3 grid((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, narrow ? 64 : GT));
+    if (bf16_operands) {
+        if (narrow) hipLaunchKernelGGL((gemm_nt_bf16_k<64, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+        else hipLaunchKernelGGL((gemm_nt_bf16_k<128, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    } else {
+        if (narrow) hipLaunchKernelGGL((gemm_nt_k<64, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+        else hipLaunchKernelGGL((gemm_nt_k<128, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    }
 }
 
+// epi: 0..4 (see nt_epilogue); + 8: bf16 MFMA operands (fp32 data in HBM, fp32 accumulation)
 static int gemm_nt_epi(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int epi, const float* aux,
                        float* pre, double flops_hint, hipStream_t s) {
+    const bool bf = (epi & 8) != 0;
+    epi &= 7;
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 4 || (epi == 2 && !pre) || (epi >= 3 && !aux)) return U3D_EINVAL;
-    if (K % GK) { set_error("gemm_nt: K=%d must be a multiple of %d", K, GK); return U3D_EUNSUPPORTED; }
+    if (K % (bf ? GKH : GK)) { set_error("gemm_nt: K=%d must be a multiple of %d", K, bf ? GKH : GK); return U3D_EUNSUPPORTED; }
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
     if ((int64_t)GT * K * 4 >= 0x7fffffffLL || (int64_t)GT * N * 4 >= 0x7fffffffLL) { set_error("gemm_nt: N=%d / K=%d too large for 32-bit tile offsets", N, K); return U3D_EUNSUPPORTED; }
     switch (epi) {
-        case 0: launch_nt<0>(A, W, bias, C, M, N, K, aux, pre, s); break;
-        case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, s); break;
-        case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, s); break;
-        case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, s); break;
-        default: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, s); break;
+        case 0: launch_nt<0>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
+        case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
+        case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
+        case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
+        default: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
     }
     return check_launch("gemm_nt");
 }
@@ -318,26 +415,33 @@ int u3d_gemm_nt(const float* A, const float* W, const float* bias, float* C, int
     return gemm_nt_epi(A, W, bias, C, M, N, K, 0, nullptr, nullptr, flops_hint, (hipStream_t)stream);
 }
 
+// `act` of the three entry points below: 0 none, 1 ReLU, 2 GELU; + U3D_BF16_OPERANDS (16) selects the bf16-operand kernels
 int u3d_linear_act(const float* X, const float* W, const float* bias, int act, float* pre, float* Y, int64_t M, int N, int K,
                    double flops_hint, u3d_stream_t stream) {
+    const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
+    act &= ~U3D_BF16_OPERANDS;
     if (act < 0 || act > 2) return U3D_EINVAL;
-    return gemm_nt_epi(X, W, bias, Y, M, N, K, act, nullptr, pre, flops_hint, (hipStream_t)stream);
+    return gemm_nt_epi(X, W, bias, Y, M, N, K, act | bf, nullptr, pre, flops_hint, (hipStream_t)stream);
 }
 
 int u3d_linear_dact(const float* dY, const float* Wt, const float* aux, int act, float* dX, int64_t M, int N, int K, double flops_hint,
                     u3d_stream_t stream) {
+    const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
+    act &= ~U3D_BF16_OPERANDS;
     if (act < 0 || act > 2) return U3D_EINVAL;
-    return gemm_nt_epi(dY, Wt, nullptr, dX, M, N, K, act == 0 ? 0 : act + 2, aux, nullptr, flops_hint, (hipStream_t)stream);
+    return gemm_nt_epi(dY, Wt, nullptr, dX, M, N, K, (act == 0 ? 0 : act + 2) | bf, aux, nullptr, flops_hint, (hipStream_t)stream);
 }
 
 int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, int act, float* H, float* A, float* Z,
                 int64_t M, int d_in, int hid, int d_out, double flops_hint, u3d_stream_t stream) {
+    const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
+    act &= ~U3D_BF16_OPERANDS;
     if (act != 1 && act != 2) return U3D_EINVAL;
     if (!A || !Z) return U3D_EINVAL;
     const double f1 = flops_hint > 0 ? 2.0 * M * d_in * hid : 0.0, f2 = flops_hint > 0 ? 2.0 * M * hid * d_out : 0.0;
-    int rc = gemm_nt_epi(X, W1, b1, A, M, hid, d_in, act, nullptr, H, f1, (hipStream_t)stream);
+    int rc = gemm_nt_epi(X, W1, b1, A, M, hid, d_in, act | bf, nullptr, H, f1, (hipStream_t)stream);
     if (rc) return rc;
-    return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, 0, nullptr, nullptr, f2, (hipStream_t)stream);
+    return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, bf, nullptr, nullptr, f2, (hipStream_t)stream);
 }
 
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K) * ((int64_t)N * K + N) * 4 + 256; }

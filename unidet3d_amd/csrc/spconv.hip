@@ -80,7 +80,14 @@ struct GmmItem {
     bool valid;
 };
 
-template <int CS16, int R, int JB_>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// BF: bf16 MFMA operands (BASELINE configs[2], "MFMA bf16 on rule GEMM").  Rows are gathered as fp32 exactly as below and
+// rounded to bf16 (RNE) only when the MFMA operand is formed: two 16-channel pieces of a unit make one
+// v_mfma_f32_16x16x32_bf16 (k = 8q + e <-> channel 16 (2 jl + (e >> 2)) + 4q + (e & 3) for lane group q), the weight
+// fragments come pre-rounded in that order from u3d_weight_pack_bf16 (half the weight bytes); accumulation, the LDS
+// accumulator tile and the output stay fp32.  8 fp32 MFMAs (256 SIMD cycles) become one bf16 MFMA (16) + 4 v_cvt_pk.
+template <int CS16, int R, int JB_, bool BF = false>
 struct GmmWave {
     static constexpr int NCH = R / 32;            // 16-pair chunks per item
     static constexpr int JB = JB_;                // 16-channel groups per unit (1, 2 or 4)
@@ -160,12 +167,24 @@ struct GmmWave {
             const int g = __shfl(raw_g, i * RPI + lr, 64);
             buf.a[i] = bload128(rs_src, (int)__umul24(g, cs4) + lp16, u * (JB * 64));
         }
-        const int wso = ((slice * K + k) * CS16 + u * JB) * 2048;       // bytes: (j, nb) blocks of 1 KB
+        if constexpr (BF) {      // 32-channel groups: (jl, nb) blocks of 1 KB (8 bf16 per lane)
+            const int wso = ((slice * K + k) * (CS16 / 2) + u * (JB / 2)) * 2048;
 #pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            buf.b[j][0] = bload128(rs_w, lane16, wso + j * 2048);
-            buf.b[j][1] = bload128(rs_w, lane16 + 1024, wso + j * 2048);
+            for (int j = 0; j < JB / 2; ++j) {
+                buf.b[j][0] = bload128(rs_w, lane16, wso + j * 2048);
+                buf.b[j][1] = bload128(rs_w, lane16 + 1024, wso + j * 2048);
+            }
+        } else {
+            const int wso = ((slice * K + k) * CS16 + u * JB) * 2048;       // bytes: (j, nb) blocks of 1 KB
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                buf.b[j][0] = bload128(rs_w, lane16, wso + j * 2048);
+                buf.b[j][1] = bload128(rs_w, lane16 + 1024, wso + j * 2048);
+            }
         }
+    }
+    static __device__ __forceinline__ bf16x8 cvt8(const f32x4& lo, const f32x4& hi) {
+        return bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
     }
     struct Frag { f32x4 v[JB]; };
     // rows of one 16-pair chunk: registers -> swizzled LDS image -> fragments
@@ -223,6 +242,22 @@ struct GmmWave {
         } else {
             issue(nxt, g_cur, it0.k, U + 1);
         }
+        if constexpr (BF) {
+#pragma unroll
+            for (int j = 0; j < JB / 2; ++j) {
+                const bf16x8 x0 = cvt8(f0.v[2 * j], f0.v[2 * j + 1]);
+                d00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j][0]), x0, d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j][1]), x0, d01, 0, 0, 0);
+            }
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < JB / 2; ++j) {
+                    const bf16x8 x1 = cvt8(f1.v[2 * j], f1.v[2 * j + 1]);
+                    d10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j][0]), x1, d10, 0, 0, 0);
+                    d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j][1]), x1, d11, 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < JB; ++j)
 #pragma unroll
@@ -238,6 +273,7 @@ struct GmmWave {
                     d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][0][t], f1.v[j][t], d10, 0, 0, 0);
                     d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.b[j][1][t], f1.v[j][t], d11, 0, 0, 0);
                 }
+        }
         }
         if constexpr (U == NJB - 1) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
@@ -284,7 +320,7 @@ struct GmmWave {
 constexpr int gmm_jb(int cs16, int r) { return (cs16 % 4 == 0 && r == 32) ? 4 : (cs16 % 2 == 0 ? 2 : 1); }
 constexpr int gmm_wave_lds(int cs16, int r) { return (r + 1) * GMM_ALD + 16 * gmm_jb(cs16, r) * 16; }      // floats: accumulator + staging image
 
-template <int CS16, int R>
+template <int CS16, int R, bool BF = false>
 __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -310,7 +346,8 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         *reinterpret_cast<float4*>(acc + r * GMM_ALD + c4 * 4) = v;
     }
 
-    GmmWave<CS16, R, gmm_jb(CS16, R)> w;
+    static_assert(!BF || CS16 % 2 == 0, "bf16 operands pair 16-channel groups");
+    GmmWave<CS16, R, gmm_jb(CS16, R), BF> w;
     w.init(p, acc, acc + (R + 1) * GMM_ALD, lane, slice, row0);
     const int k_lo = g * p.kper;
     w.k_hi = min(p.K, k_lo + p.kper);
@@ -355,11 +392,11 @@ static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
     *G = g;
 }
 
-template <int CS16, int R>
+template <int CS16, int R, bool BF = false>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
     const size_t lds = (size_t)4 * gmm_wave_lds(CS16, R) * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
-    hipLaunchKernelGGL((spconv_gmm_k<CS16, R>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((spconv_gmm_k<CS16, R, BF>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");
 }
 
@@ -566,6 +603,29 @@ __global__ __launch_bounds__(256) void weight_pack_k(const float* __restrict__ w
     reinterpret_cast<float4*>(wp)[idx] = v;
 }
 
+// bf16 form: one 16-byte vector (8 bf16) per (lane, 32-channel group jj, column block nb):
+// wp[(((slice*K + k)*CS32 + jj)*2 + nb)*64 + lane][e] = bf16(W(n = slice*32 + nb*16 + (lane&15), k, c = (2 jj + (e>>2))*16 + (lane>>4)*4 + (e&3)))
+__global__ __launch_bounds__(256) void weight_pack_bf16_k(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cd, int K, int Cs, int transposed) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one bf16x8 per thread
+    const int cs32 = Cs / 32;
+    const int64_t total = (int64_t)(Cd / 32) * K * cs32 * 2 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    int64_t t = idx >> 6;
+    const int nb = (int)(t & 1); t >>= 1;
+    const int jj = (int)(t % cs32); t /= cs32;
+    const int k = (int)(t % K);
+    const int slice = (int)(t / K);
+    const int n = slice * 32 + nb * 16 + (lane & 15), q = lane >> 4;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = (2 * jj + (e >> 2)) * 16 + q * 4 + (e & 3);
+        v[e] = (__bf16)(transposed ? w[((int64_t)c * K + k) * Cd + n] : w[((int64_t)n * K + k) * Cs + c]);
+    }
+    wp[idx] = v;
+}
+
 __global__ void weight_transpose_k(const float* __restrict__ w, float* __restrict__ wt, int Cd, int K, int Cs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)Cd * K * Cs;
@@ -592,9 +652,10 @@ int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k
     return U3D_OK;
 }
 
-int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
-                   const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
-                   int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
+static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
+                           const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                           int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream, bool bf) {
+    if (bf && Cs % 32) { set_error("spconv_gmm_bf16: Cs=%d must be a multiple of 32", Cs); return U3D_EUNSUPPORTED; }
     if (!src || !w_rows || !gather || !scatter || !tile_starts || !dst || K <= 0 || K > 32 || n_dst <= 0 || n_src <= 0 || cap <= 0) return U3D_EINVAL;
     // the kernel addresses through 32-bit buffer offsets and multiplies row indices with v_mul_u32_u24
     if (n_src >= (1 << 24) || n_dst >= (1 << 24) || n_src * Cs * 4 >= 0x7fffffffLL || (int64_t)K * cap * 4 >= 0x7fffffffLL) {
@@ -617,8 +678,14 @@ int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_rows, const i
     const int cs16 = Cs / 16;
     int rc = U3D_EUNSUPPORTED;
 #define U3D_GMM_CASE(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64>(p, s) : launch_gmm<cs, 32>(p, s);
-    U3D_GMM_CASE(1) U3D_GMM_CASE(2) U3D_GMM_CASE(4) U3D_GMM_CASE(6) U3D_GMM_CASE(8) U3D_GMM_CASE(10) U3D_GMM_CASE(12) U3D_GMM_CASE(16)
+#define U3D_GMM_CASE_BF(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64, true>(p, s) : launch_gmm<cs, 32, true>(p, s);
+    if (bf) {
+        U3D_GMM_CASE_BF(2) U3D_GMM_CASE_BF(4) U3D_GMM_CASE_BF(6) U3D_GMM_CASE_BF(8) U3D_GMM_CASE_BF(10) U3D_GMM_CASE_BF(12) U3D_GMM_CASE_BF(16)
+    } else {
+        U3D_GMM_CASE(1) U3D_GMM_CASE(2) U3D_GMM_CASE(4) U3D_GMM_CASE(6) U3D_GMM_CASE(8) U3D_GMM_CASE(10) U3D_GMM_CASE(12) U3D_GMM_CASE(16)
+    }
 #undef U3D_GMM_CASE
+#undef U3D_GMM_CASE_BF
     if (rc != U3D_OK) return rc;
     if (G > 1) {
         const int64_t n4 = n_dst * Cd / 4;
@@ -628,6 +695,27 @@ int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_rows, const i
         rc = check_launch("gmm_reduce");
     }
     return rc;
+}
+
+int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
+                   const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                   int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
+    return spconv_gmm_impl(src, n_src, w_rows, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups, addend, dst, ws,
+                           flops_hint, stream, false);
+}
+
+int u3d_spconv_gmm_bf16(const float* src, int64_t n_src, const void* w_rows_bf16, const int32_t* gather, const int32_t* scatter,
+                        const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                        int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
+    return spconv_gmm_impl(src, n_src, (const float*)w_rows_bf16, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups,
+                           addend, dst, ws, flops_hint, stream, true);
+}
+
+int u3d_weight_pack_bf16(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {
+    if (!w || !wp || Cd <= 0 || K <= 0 || Cs <= 0 || Cd % 32 || Cs % 32) return U3D_EINVAL;
+    const int64_t total8 = (int64_t)Cd * K * Cs / 8;
+    hipLaunchKernelGGL(weight_pack_bf16_k, dim3((unsigned)ceil_div(total8, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16x8*)wp, Cd, K, Cs, transposed);
+    return check_launch("weight_pack_bf16");
 }
 
 int u3d_spconv_wgrad_tile_rows(int K, int64_t n_rows_dy, int Cs, int Cd) {

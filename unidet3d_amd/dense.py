@@ -5,6 +5,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from . import precision as P
 
 _PROFILE_FLOPS = False
 
@@ -14,13 +15,26 @@ def set_profile_flops(on: bool):
     _PROFILE_FLOPS = bool(on)
 
 
-def _gemm_nt(a, w, bias):
-    M, K = a.shape
+def _pad_k(t, mult):
+    """zero-pad the last (reduction) dim of a 2-D tensor to a multiple of ``mult``"""
+    k = t.shape[1]
+    return t if k % mult == 0 else torch.nn.functional.pad(t, (0, mult - k % mult))
+
+
+def _gemm_nt(a, w, bias, bf=False):
+    """a [M,K] . w[N,K]^T (+ bias); ``bf``: bf16 MFMA operands (K is zero-padded to a multiple of 32 when needed)."""
+    M = a.shape[0]
     N = w.shape[0]
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     if M:
-        L.call('u3d_gemm_nt', L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(c), M, N, K, 2.0 * M * N * K if _PROFILE_FLOPS else 0.0,
-               L.stream())
+        if bf:
+            a, w = _pad_k(a, 32), _pad_k(w, 32)
+            L.call('u3d_linear_act', L.ptr(a), L.ptr(w), L.ptr(bias), P.BF16_FLAG, None, L.ptr(c), M, N, a.shape[1],
+                   _flops(M, N, a.shape[1]), L.stream())
+        else:
+            K = a.shape[1]
+            L.call('u3d_gemm_nt', L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(c), M, N, K, 2.0 * M * N * K if _PROFILE_FLOPS else 0.0,
+                   L.stream())
     return c
 
 
@@ -31,27 +45,29 @@ def _flops(M, N, K):
     return 2.0 * M * N * K if _PROFILE_FLOPS else 0.0
 
 
-def _input_grad(dy, weight, act=ACT_NONE, aux=None):
+def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False):
     """dX[M,K] = dY[M,N] . W[N,K], optionally times act'(aux) in the GEMM epilogue (u3d_linear_dact): the input gradient
     THROUGH the activation that produced this layer's input (aux = its ReLU output / GELU pre-activation)."""
     M, N = dy.shape
     K = weight.shape[1]
     dev = dy.device
-    if N % 16 == 0:
+    q = 32 if bf else 16                                # reduction-depth granule of the kernel
+    if N % q == 0:
         wt = torch.empty(K, N, dtype=torch.float32, device=dev)
         L.call('u3d_transpose', L.ptr(weight.contiguous()), L.ptr(wt), N, K, L.stream())
-    else:                                               # tiny heads (N = 19, 8): pad the reduction dim to 16 with zero columns
-        Np = (N + 15) // 16 * 16
+    else:                                               # tiny heads (N = 19, 8): pad the reduction dim with zero columns
+        Np = (N + q - 1) // q * q
         wt = torch.zeros(K, Np, dtype=torch.float32, device=dev)
         wt[:, :N] = weight.t()
         dyp = torch.zeros(M, Np, dtype=torch.float32, device=dev)
         dyp[:, :N] = dy
         dy, N = dyp, Np
     if act == ACT_NONE:
-        return _gemm_nt(dy, wt, None)
+        return _gemm_nt(dy, wt, None, bf)
     dx = torch.empty(M, K, dtype=torch.float32, device=dev)
     if M:
-        L.call('u3d_linear_dact', L.ptr(dy), L.ptr(wt), L.ptr(aux), act, L.ptr(dx), M, K, N, _flops(M, K, N), L.stream())
+        L.call('u3d_linear_dact', L.ptr(dy), L.ptr(wt), L.ptr(aux), act | (P.BF16_FLAG if bf else 0), L.ptr(dx), M, K, N,
+               _flops(M, K, N), L.stream())
     return dx
 
 
@@ -91,7 +107,8 @@ class _LinearFn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _gemm_nt(x, weight.contiguous(), bias)
+        ctx.bf = P.bf16()
+        return _gemm_nt(x, weight.contiguous(), bias, ctx.bf)
 
     @staticmethod
     def backward(ctx, dy):
@@ -99,7 +116,7 @@ class _LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, weight)
+            dx = _input_grad(dy, weight, bf=ctx.bf)
         if ctx.needs_input_grad[1]:
             dw, db = _weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
@@ -126,9 +143,10 @@ class _MLPFn(torch.autograd.Function):
         h = torch.empty(M, hid, dtype=torch.float32, device=dev) if act == ACT_GELU else None
         z = torch.empty(M, d_out, dtype=torch.float32, device=dev)
         w1c, w2c = w1.contiguous(), w2.contiguous()
+        ctx.bf = P.bf16()
         if M:
-            L.call('u3d_ffn_fwd', L.ptr(x), L.ptr(w1c), L.ptr(b1), L.ptr(w2c), L.ptr(b2), act, L.ptr(h), L.ptr(a), L.ptr(z),
-                   M, d_in, hid, d_out, 1.0 if _PROFILE_FLOPS else 0.0, L.stream())
+            L.call('u3d_ffn_fwd', L.ptr(x), L.ptr(w1c), L.ptr(b1), L.ptr(w2c), L.ptr(b2), act | (P.BF16_FLAG if ctx.bf else 0),
+                   L.ptr(h), L.ptr(a), L.ptr(z), M, d_in, hid, d_out, 1.0 if _PROFILE_FLOPS else 0.0, L.stream())
         ctx.save_for_backward(x, w1c, w2c, a, h)
         ctx.act, ctx.bias = act, (b1 is not None, b2 is not None)
         return z
@@ -139,9 +157,9 @@ class _MLPFn(torch.autograd.Function):
         dz = dz.contiguous()
         need = ctx.needs_input_grad
         dw2, db2 = _weight_grad(dz, a, ctx.bias[1] and need[4]) if need[3] else (None, None)
-        dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a)
+        dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf)
         dw1, db1 = _weight_grad(dh, x, ctx.bias[0] and need[2]) if need[1] else (None, None)
-        dx = _input_grad(dh, w1) if need[0] else None
+        dx = _input_grad(dh, w1, bf=ctx.bf) if need[0] else None
         return dx, dw1, db1, dw2, db2, None
 
 

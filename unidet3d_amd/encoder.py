@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
+from . import precision as P
 from .dense import LayerNorm, linear, mlp
 from .registry import MODELS
 
@@ -37,8 +38,9 @@ class _AttnFn(torch.autograd.Function):
         lse = torch.empty(H, n, dtype=torch.float32, device=qkv.device)
         B = cu_seqlens.numel() - 1
         flops = 0.0
+        ctx.sfx = '_bf16' if P.bf16() else ''
         if n:
-            L.call('u3d_attn_varlen_fwd', L.ptr(qkv), L.ptr(cu_seqlens), B, max_len, n, H, hd, 1.0 / math.sqrt(hd),
+            L.call('u3d_attn_varlen_fwd' + ctx.sfx, L.ptr(qkv), L.ptr(cu_seqlens), B, max_len, n, H, hd, 1.0 / math.sqrt(hd),
                    L.ptr(out), L.ptr(lse), flops, L.stream())
         ctx.save_for_backward(qkv, out, lse, cu_seqlens)
         ctx.max_len, ctx.H = max_len, H
@@ -54,7 +56,7 @@ class _AttnFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(H, n, dtype=torch.float32, device=qkv.device)
         if n:
-            L.call('u3d_attn_varlen_bwd', L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(cu), cu.numel() - 1,
+            L.call('u3d_attn_varlen_bwd' + ctx.sfx, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(cu), cu.numel() - 1,
                    ctx.max_len, n, H, hd, 1.0 / math.sqrt(hd), L.ptr(dqkv), L.ptr(delta), 0.0, L.stream())
         return dqkv, None, None, None
 

@@ -26,6 +26,7 @@ from torch import nn
 
 from . import _lib as L
 from . import dense
+from . import precision as P
 
 
 # ----------------------------------------------------------------------------------------
@@ -149,8 +150,10 @@ def _plan(Cs, Cd, K, n_dst):
     return R.value, G.value
 
 
-def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops):
-    """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in)."""
+def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=False):
+    """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in).
+    ``bf``: bf16 MFMA operands (precision.py); source channel counts that are not a multiple of 32 (the 6 -> 32 input
+    convolution, padded to 16) stay on the fp32 kernel."""
     Cs, Cd = src.shape[1], (weight.shape[2] if transposed else weight.shape[0])
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     if n_dst:
@@ -160,9 +163,10 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
             ACCOUNT['gmm_flops'] += flops
             ACCOUNT['gmm_bytes'] += 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
-        wp = torch.empty(weight.numel(), dtype=torch.float32, device=src.device)       # MFMA-fragment order
-        L.call('u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
-        L.call('u3d_spconv_gmm', L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
+        bf = bf and Cs % 32 == 0
+        wp = torch.empty(weight.numel() // (2 if bf else 1), dtype=torch.float32, device=src.device)       # MFMA-fragment order
+        L.call('u3d_weight_pack_bf16' if bf else 'u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
+        L.call('u3d_spconv_gmm_bf16' if bf else 'u3d_spconv_gmm', L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
                rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
     return dst
 
@@ -202,7 +206,8 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
-        dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops)
+        ctx.bf = P.bf16()
+        dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops, ctx.bf)
         ctx.save_for_backward(src, weight)
         ctx.rb, ctx.mode, ctx.has_addend = rb, mode, addend is not None
         return dst
@@ -241,7 +246,7 @@ class _SparseConvFn(torch.autograd.Function):
                 g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
             else:
                 g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
-            dsrc = _gmm(dout, weight.reshape(cout, rb.K, cin).contiguous(), True, rb, g, s, role, n_dst, None, flops)
+            dsrc = _gmm(dout, weight.reshape(cout, rb.K, cin).contiguous(), True, rb, g, s, role, n_dst, None, flops, ctx.bf)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return dsrc, dw, None, None, (dout if ctx.has_addend else None)

@@ -25,7 +25,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector rate)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -34,7 +35,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='scenes per GPU (cfg2: 8)')
+    ap.add_argument('--batch', type=int, default=None, help='scenes per GPU (cfg2: 8; cfg3 = --dtype bf16: 16)')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help="MFMA operand precision: fp32 = BASELINE configs[1] (the headline line), bf16 = configs[2] "
+                         "(bf16 operands, fp32 accumulate / statistics / optimizer; unidet3d_amd/precision.py)")
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--voxel-size', type=float, default=0.02)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -118,7 +122,10 @@ def log(msg: str):
 
 def main():
     args = parse()
+    if args.batch is None:
+        args.batch = 16 if args.dtype == 'bf16' else 8
     from unidet3d_amd import _lib as L
+    from unidet3d_amd import account, precision
     from unidet3d_amd import sparse
     from unidet3d_amd.config import build_model, scannet_model_cfg
     from unidet3d_amd.data import make_batch_inputs
@@ -137,6 +144,7 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     dev = torch.device('cuda', local_dev)
 
+    precision.set_operand_dtype(args.dtype)
     torch.manual_seed(0)
     model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)
     model.train()
@@ -174,10 +182,11 @@ def main():
         torch.cuda.synchronize()
         log(f'warm-up step {i} done, loss {float(loss.detach()):.4f}')
     assert bucket.check_views(), 'p.grad does not alias the flat gradient buffer'
-    for c in (L.K_CONV_FWD, L.K_CONV_WGRAD, L.K_ATTN_FWD, L.K_ATTN_BWD):
-        L.prof_enable(c, True)
-    for k in sparse.ACCOUNT:
-        sparse.ACCOUNT[k] = 0
+    FAMILIES = (('conv_gmm', L.K_CONV_FWD), ('conv_wgrad', L.K_CONV_WGRAD), ('attn_fwd', L.K_ATTN_FWD), ('attn_bwd', L.K_ATTN_BWD),
+                ('gemm', L.K_GEMM))
+    for _, c in FAMILIES:
+        L.prof_enable(c, True)       # HIP events around every launch of the family, on the stream it runs on
+    account.reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -186,11 +195,12 @@ def main():
     dt = time.perf_counter() - t0
     log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step')
     prof = {}
-    for name, c in (('conv_gmm', L.K_CONV_FWD), ('conv_wgrad', L.K_CONV_WGRAD), ('attn_fwd', L.K_ATTN_FWD),
-                    ('attn_bwd', L.K_ATTN_BWD)):
+    acc = account.snapshot()
+    for name, c in FAMILIES:
         ms, n, work = L.prof_collect(c)
         L.prof_enable(c, False)
-        prof[name] = dict(ms=ms, launches=n, flops=work)
+        prof[name] = dict(ms=ms, launches=n, flops=work, bytes=acc.get(name, {}).get('bytes', 0.0),
+                          flops_booked=acc.get(name, {}).get('flops', 0.0))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,16 +208,35 @@ def main():
     loss_val = float(loss.item())
 
     if rank == 0:
+        bf = args.dtype == 'bf16'
+        # which MFMA peak prices a family: the bf16-operand kernels exist for the sparse conv forward / input gradient, the
+        # decoder's NT GEMMs and attention; weight gradients (sparse and dense) keep fp32 operands
+        peak = {k: (PEAK_BF16_MFMA_TFLOPS if bf and k in ('conv_gmm', 'attn_fwd', 'attn_bwd') else PEAK_F32_MFMA_TFLOPS) for k in prof}
+        kernels = {}
+        for k, v in prof.items():
+            t = v['ms'] * 1e-3
+            tf = v['flops'] / t / 1e12 if t > 0 and v['flops'] > 0 else None
+            gbs = v['bytes'] / t / 1e9 if t > 0 and v['bytes'] > 0 else None
+            kernels[k] = {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
+                          'algorithmic_gflop_per_step': v['flops'] / args.steps / 1e9, 'algorithmic_MB_per_step': v['bytes'] / args.steps / 1e6,
+                          'tflops': tf, 'mfma_peak': peak[k] if k != 'gemm' else ('mixed' if bf else PEAK_F32_MFMA_TFLOPS),
+                          'frac_mfma': (tf / peak[k] if tf and (k != 'gemm' or not bf) else None),
+                          'hbm_gbs': gbs, 'frac_hbm': gbs / PEAK_HBM_GBS if gbs else None}
         g = prof['conv_gmm']
         ach = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
-        w = prof['conv_wgrad']
         n_vox = int(model._vb.coords.shape[0])
-        acc = sparse.ACCOUNT
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'round1_final_pmc_traffic.json')
-        if os.path.exists(tpath):       # PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KB) of this same command, tools/pmc_bench.sh
-            traffic = json.load(open(tpath))['_spconv_gmm_k_all']['hbm_MB_per_launch'] * 1e6
-            traffic_src = 'profiles/round1_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+        tpath = os.path.join(ROOT, 'profiles', 'round2_pmc_traffic.json')
+        if os.path.exists(tpath) and not bf:   # PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KB) of this same command, tools/pmc_bench.sh
+            import hashlib
+            rec = json.load(open(tpath))
+            sha = hashlib.sha256(open(os.path.join(ROOT, 'unidet3d_amd', 'csrc', 'spconv.hip'), 'rb').read()).hexdigest()[:16]
+            if rec.get('_meta', {}).get('spconv_hip_sha16') == sha:        # stale counters are not reported
+                traffic = rec['_spconv_gmm_k_all']['hbm_MB_per_launch'] * 1e6
+                traffic_src = (f"profiles/round2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
+                               f"command at commit {rec['_meta'].get('git_head', '?')}; spconv.hip sha256/16 {sha} matches the kernel timed here)")
+            else:
+                traffic_src = 'profiles/round2_pmc_traffic.json was measured on a different spconv.hip: not reported'
         out = {
             'metric': 'scenes/sec fwd+bwd, 100k-pt ScanNet voxel grid',
             'value': args.batch * world * args.steps / dt,
@@ -215,24 +244,30 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'cfg2: {args.batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
-                                   f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, fp32; '
-                                   'step = voxelise+rulebook+fwd+loss+bwd' +
-                                   ('' if args.no_optimizer else '+clip+AdamW'),
+            'dtype': 'bf16' if bf else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{"cfg3" if bf else "cfg2"}: {args.batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
+                                   f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, '
+                                   + ('bf16 MFMA operands (sparse conv fwd/dgrad, Linear fwd/dX, attention), fp32 accumulate/BN/softmax/optimizer; '
+                                      if bf else 'fp32; ') +
+                                   'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else '+clip+AdamW'),
                        'global_batch': args.batch * world, 'points_per_scene': args.points,
                        'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val},
             'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
-                         'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
+                         'bound': 'mfma', 'achieved': ach, 'peak': peak['conv_gmm'], 'unit': 'TFLOP/s',
+                         'frac': ach / peak['conv_gmm'], 'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
                          'traffic_source': traffic_src,
-                         'algorithmic_bytes_per_launch': acc['gmm_bytes'] / max(acc['gmm_launches'], 1),
+                         'algorithmic_bytes_per_launch': g['bytes'] / max(g['launches'], 1),
+                         'hbm_achieved_gbs': kernels['conv_gmm']['hbm_gbs'], 'hbm_frac': kernels['conv_gmm']['frac_hbm'],
                          'launches': g['launches'], 'avg_launch_us': g['ms'] * 1e3 / max(g['launches'], 1),
                          'algorithmic_gflop_per_launch': g['flops'] / max(g['launches'], 1) / 1e9,
                          'share_of_step': g['ms'] / (dt * 1e3)},
-            'kernels': {k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
-                            'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] > 0 and v['flops'] > 0 else None)}
-                        for k, v in prof.items()},
+            'kernels': kernels,
+            'step_roofline': {
+                'note': 'all five timed families: sum of algorithmic flops / (sum of their time); HBM side: sum of algorithmic bytes / time',
+                'families_ms_per_step': sum(v['ms'] for v in prof.values()) / args.steps,
+                'tflops': sum(v['flops'] for v in prof.values()) / max(sum(v['ms'] for v in prof.values()) * 1e-3, 1e-12) / 1e12,
+                'hbm_gbs': sum(v['bytes'] for v in prof.values()) / max(sum(v['ms'] for v in prof.values()) * 1e-3, 1e-12) / 1e9,
+                'share_of_step': sum(v['ms'] for v in prof.values()) / (dt * 1e3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.points, args.voxel_size)

@@ -267,6 +267,9 @@ int u3d_linear_dact(const float* dY /*[M,K]*/, const float* Wt /*[N,K]*/, const 
 int u3d_ffn_fwd(const float* X, const float* W1 /*[hid,d_in]*/, const float* b1, const float* W2 /*[d_out,hid]*/, const float* b2,
                 int act, float* H, float* A, float* Z /*[M,d_out]*/, int64_t M, int d_in, int hid, int d_out, double flops_hint,
                 u3d_stream_t stream);
+/* stand-alone erf-GELU passes (the unfused alternative to act = 2 above; n % 4 == 0): a = gelu(h); dh = da * gelu'(h) */
+int u3d_gelu_fwd(const float* h, float* a, int64_t n, u3d_stream_t stream);
+int u3d_gelu_bwd(const float* da, const float* h, float* dh, int64_t n, u3d_stream_t stream);
 /* colsum_A (nullable, [N]): column sums of A -- the bias gradient of the Linear layer -- produced by the same pass */
 int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[N,K] = A^T B*/, float* colsum_A, int64_t M, int N, int K,
                 void* ws, double flops_hint, u3d_stream_t stream);

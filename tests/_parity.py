@@ -118,13 +118,32 @@ def oracle_fp64_grads(orac, run):
     return {k: p.grad for k, p in o64.named_parameters() if p.grad is not None}
 
 
-def compare(name, P, O, prod, orac, g64=None):
+def oracle_perturbed_grads(orac, run, rel_sigma=2e-7, seed=1):
+    """fp32 gradients of the oracle with every weight multiplied by (1 + rel_sigma * N(0, 1)) -- a perturbation the size of
+    ONE fp32 rounding.  Together with ``oracle_fp64_grads`` this measures how far fp32 arithmetic can legitimately move a
+    gradient of this (non-smooth: ReLU after batch norm over as few as ~20 voxels, top-k matcher) function; the plain fp32
+    oracle shares its operation order with the fp64 run and underestimates that."""
+    import copy
+    op = copy.deepcopy(orac).float().train()
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in op.parameters():
+            p.mul_(1 + rel_sigma * torch.randn(p.shape, generator=gen))
+    op.zero_grad()
+    O = run(op)
+    O['loss'].backward()
+    return {k: p.grad for k, p in op.named_parameters() if p.grad is not None}
+
+
+def compare(name, P, O, prod, orac, g64=None, gpert=None):
     """Asserts the north-star tolerances (features, logits, boxes, loss <= 1e-3 relative against the fp32 oracle) and returns /
     logs the measured errors.  Backbone parameter gradients pass through ~90 batch-norm layers whose backward cancels the
     mean and scale components of the incoming gradient: they are ill-conditioned in fp32 -- the CPU oracle itself moves by
-    5e-4 (median) to 4e-2 (worst parameter) of the largest entry when only the summation ORDER changes (two scenes swapped).
-    With ``g64`` (fp64 gradients of the oracle) the product's gradient error is therefore judged against the error the fp32
-    oracle has against the same ground truth."""
+    5e-4 (median) to 4e-2 (worst parameter) of the largest entry when only the summation ORDER changes (two scenes swapped),
+    and a single ReLU unit that switches in a 20-voxel level moves a deep weight gradient by 10 %.
+    With ``g64`` (fp64 gradients of the oracle) and ``gpert`` (fp32 gradients of the oracle under a one-rounding weight
+    perturbation) the product's error against fp64 is judged against the error of that perturbed fp32 CPU run: median and
+    90th percentile over the parameters (single-unit flips make the maximum a lottery; it is logged, not asserted)."""
     n = len(O['feats'])
     assert torch.equal(P['coords'].cpu(), O['coords']), 'voxel coordinates differ from the oracle'
     err = dict(n_scenes=n, n_voxels=int(O['coords'].shape[0]),
@@ -152,15 +171,16 @@ def compare(name, P, O, prod, orac, g64=None):
     err['grad_backbone_max'] = max(v for k, v in grads.items() if not k.startswith('decoder.'))
     if g64 is not None:
         pp = dict(prod.named_parameters())
-        e_prod = {k: rel(pp[k].grad, g) for k, g in g64.items()}
-        e_orac = {k: rel(og[k].grad, g) for k, g in g64.items()}
-        bb = [k for k in g64 if not k.startswith('decoder.')]
-        err['vs_fp64'] = dict(
-            product_backbone_median=float(np.median([e_prod[k] for k in bb])), product_backbone_max=max(e_prod[k] for k in bb),
-            oracle32_backbone_median=float(np.median([e_orac[k] for k in bb])), oracle32_backbone_max=max(e_orac[k] for k in bb),
-            product_decoder_max=max(v for k, v in e_prod.items() if k.startswith('decoder.')),
-            oracle32_decoder_max=max(v for k, v in e_orac.items() if k.startswith('decoder.')),
-            product_worst=sorted(e_prod.items(), key=lambda kv: -kv[1])[:3], oracle32_worst=sorted(e_orac.items(), key=lambda kv: -kv[1])[:3])
+        runs = {'product': {k: rel(pp[k].grad, g) for k, g in g64.items()}, 'oracle32': {k: rel(og[k].grad, g) for k, g in g64.items()}}
+        if gpert is not None:
+            runs['oracle32_perturbed'] = {k: rel(gpert[k], g) for k, g in g64.items()}
+        v = {}
+        for tag, e in runs.items():
+            for part, keys in (('backbone', [k for k in g64 if not k.startswith('decoder.')]), ('decoder', [k for k in g64 if k.startswith('decoder.')])):
+                vals = np.array([e[k] for k in keys])
+                v[f'{tag}_{part}_median'], v[f'{tag}_{part}_p90'], v[f'{tag}_{part}_max'] = float(np.median(vals)), float(np.percentile(vals, 90)), float(vals.max())
+            v[f'{tag}_worst'] = sorted(e.items(), key=lambda kv: -kv[1])[:3]
+        err['vs_fp64'] = v
     log_errors(name, err)
     print(name, json.dumps({k: v for k, v in err.items() if k != 'grad_worst'}))
     assert err['feats'] < 1e-3 and err['logits'] < 1e-3 and err['boxes'] < 1e-3 and err['loss'] < 1e-3, err
@@ -169,6 +189,10 @@ def compare(name, P, O, prod, orac, g64=None):
         v = err['vs_fp64']
         assert v['product_decoder_max'] < 1e-3, v
         # ill-conditioned part: no worse than a small multiple of what fp32 arithmetic on the CPU delivers for the same quantity
-        assert v['product_backbone_median'] < 10 * v['oracle32_backbone_median'] + 1e-3, v
-        assert v['product_backbone_max'] < 4 * v['oracle32_backbone_max'] + 2e-2, v
+        # (the larger of the two CPU fp32 runs: which side of a ReLU threshold a run falls on is a coin toss per run)
+        def base(stat):
+            return max(v[f'oracle32_{stat}'], v.get(f'oracle32_perturbed_{stat}', 0.0))
+        assert v['product_backbone_median'] < 5 * base('backbone_median') + 2e-3, v
+        assert v['product_backbone_p90'] < 5 * base('backbone_p90') + 1e-2, v
+        assert v['product_decoder_median'] < 5 * base('decoder_median') + 1e-5, v
     return err

@@ -68,11 +68,12 @@ def test_cfg2_full_size_end_to_end_vs_oracle():
     prod, orac = PA.build_pair(cfg)
     scenes = [make_scene(i, n_points=100_000) for i in range(8)]
     O = PA.oracle_forward(orac, scenes, ['scannet'] * 8)
-    g64 = PA.oracle_fp64_grads(orac, lambda m: PA.oracle_forward(m, scenes, ['scannet'] * 8))
+    run = lambda m: PA.oracle_forward(m, scenes, ['scannet'] * 8)  # noqa: E731
+    g64, gpert = PA.oracle_fp64_grads(orac, run), PA.oracle_perturbed_grads(orac, run)
     inputs, samples = make_batch_inputs(scenes, DEV)
     P = PA.product_forward(prod, inputs, samples)
     assert len(P['out']['aux_outputs']) == 6                                 # 7 heads in total
-    PA.compare('cfg2_full_size_8x100k', P, O, prod, orac, g64)
+    PA.compare('cfg2_full_size_8x100k', P, O, prod, orac, g64, gpert)
 
 
 def _joint_cfg():
@@ -123,14 +124,15 @@ def test_cfg4_joint_config_mixed_batch_vs_oracle():
     scenes, names, gt_boxes, inputs, samples = _joint_batch(cfg)
     kw = dict(crit_cfg=cfg['criterion'], gt_boxes=gt_boxes, train_topk=cfg['train_cfg']['topk'])
     O = PA.oracle_forward(orac, scenes, names, **kw)
-    g64 = PA.oracle_fp64_grads(orac, lambda m: PA.oracle_forward(m, scenes, names, **kw))
+    run = lambda m: PA.oracle_forward(m, scenes, names, **kw)  # noqa: E731
+    g64, gpert = PA.oracle_fp64_grads(orac, run), PA.oracle_perturbed_grads(orac, run)
     P = PA.product_forward(prod, inputs, samples)
     assert P['out']['bboxes'][1].shape[1] == 7 and P['out']['bboxes'][0].shape[1] == 6            # ARKitScenes head is 7-dof
     for i, ds in enumerate(samples):                                           # target assignment is integer work: exact
         assert torch.equal(ds.gt_instances_3d.sp_masks.cpu(), O['insts'][i].sp_masks), names[i]
         assert PA.rel(ds.gt_instances_3d.sp_centers, O['centers'][i]) < 1e-5
         assert PA.rel(ds.gt_instances_3d.bboxes_3d.gravity_center, O['insts'][i].bboxes_3d.gravity_center) < 1e-5
-    PA.compare('cfg4_joint_mixed_batch', P, O, prod, orac, g64)
+    PA.compare('cfg4_joint_mixed_batch', P, O, prod, orac, g64, gpert)
 
 
 @pytest.mark.parametrize('name', ['s3dis', 'arkitscenes', '3rscan'])

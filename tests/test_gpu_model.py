@@ -125,10 +125,11 @@ def test_end_to_end_features_logits_boxes_loss_grads(n_scenes, n_points, vs):
     scenes = [make_scene(40 + i, n_points=n_points) for i in range(n_scenes)]
     names = ['scannet'] * n_scenes
     O = PA.oracle_forward(orac, scenes, names)
-    g64 = PA.oracle_fp64_grads(orac, lambda m: PA.oracle_forward(m, scenes, names))
+    run = lambda m: PA.oracle_forward(m, scenes, names)  # noqa: E731
+    g64, gpert = PA.oracle_fp64_grads(orac, run), PA.oracle_perturbed_grads(orac, run)
     inputs, samples = make_batch_inputs(scenes, DEV)
     P = PA.product_forward(prod, inputs, samples)
-    PA.compare(f'e2e_{n_scenes}x{n_points}_{vs}', P, O, prod, orac, g64)
+    PA.compare(f'e2e_{n_scenes}x{n_points}_{vs}', P, O, prod, orac, g64, gpert)
 
 
 def test_backbone_features_match_oracle_per_superpoint():
@@ -170,7 +171,9 @@ def test_dense_linear_fwd_bwd(M, K, N):
 @pytest.mark.parametrize('M,d_in,hid,d_out,act', [(16001, 256, 1024, 256, 'gelu'), (4097, 32, 256, 256, 'relu'), (2500, 256, 256, 19, 'relu'),
                                                     (333, 256, 1024, 256, 'relu'), (1, 256, 256, 8, 'gelu'), (0, 32, 256, 256, 'relu')])
 def test_mlp_fused_epilogues_fwd_bwd(M, d_in, hid, d_out, act):
-    """Linear -> activation -> Linear with bias/activation in the GEMM epilogues vs torch in float64 (erf GELU as nn.GELU())."""
+    """Linear -> activation -> Linear with bias/activation in the GEMM epilogues vs torch in float64 (erf GELU as nn.GELU());
+    GELU both as GEMM epilogue and as the stand-alone pass (dense.FUSE_GELU)."""
+    from unidet3d_amd import dense
     from unidet3d_amd.dense import mlp
     g = torch.Generator().manual_seed(M + hid + d_out)
     x = torch.randn(M, d_in, generator=g); w1 = torch.randn(hid, d_in, generator=g) * 0.1; b1 = torch.randn(hid, generator=g)
@@ -179,11 +182,16 @@ def test_mlp_fused_epilogues_fwd_bwd(M, d_in, hid, d_out, act):
     h = torch.nn.functional.linear(ref[0], ref[1], ref[2])
     a = torch.relu(h) if act == 'relu' else torch.nn.functional.gelu(h)
     zo = torch.nn.functional.linear(a, ref[3], ref[4]); zo.backward(go.double())
-    dev = [t.clone().to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
-    z = mlp(*dev, act); z.backward(go.to(DEV))
-    assert _rel(z, zo) < 1e-5
-    for name, d, r in zip(('x', 'w1', 'b1', 'w2', 'b2'), dev, ref):
-        assert d.grad is not None and _rel(d.grad, r.grad) < 3e-5, name
+    for fuse in ((True, False) if act == 'gelu' else (dense.FUSE_GELU,)):
+        dev = [t.clone().to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+        prev, dense.FUSE_GELU = dense.FUSE_GELU, fuse
+        try:
+            z = mlp(*dev, act); z.backward(go.to(DEV))
+        finally:
+            dense.FUSE_GELU = prev
+        assert _rel(z, zo) < 1e-5
+        for name, d, r in zip(('x', 'w1', 'b1', 'w2', 'b2'), dev, ref):
+            assert d.grad is not None and _rel(d.grad, r.grad) < 3e-5, (name, fuse)
 
 
 # ---------------------------------------------------------------------------- elastic training frame (unidet3d.py:295-299)

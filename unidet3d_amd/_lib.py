@@ -71,6 +71,8 @@ PROTOTYPES = {
     'u3d_linear_act': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
     'u3d_linear_dact': (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _vp]),
     'u3d_ffn_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp]),
+    'u3d_gelu_fwd': (_i32, [_vp, _vp, _i64, _vp]),
+    'u3d_gelu_bwd': (_i32, [_vp, _vp, _vp, _i64, _vp]),
     'u3d_gemm_tn': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp]),
     'u3d_gemm_tn_ws_bytes': (_i64, [_i64, _i32, _i32]),
     'u3d_transpose': (_i32, [_vp, _vp, _i32, _i32, _vp]),

@@ -37,10 +37,20 @@ constexpr int GLD = GK + 4;    // padded LDS row of the NT tiles
 //   2  pre = acc + bias, C = gelu(pre)                  Linear + GELU (erf form, torch's default); pre is kept for backward
 //   3  C = aux > 0 ? acc : 0                            input gradient through ReLU   (aux = the ReLU output)
 //   4  C = acc * gelu'(aux)                             input gradient through GELU   (aux = the pre-activation)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+// erf GELU with ONE exponential per element: erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2
+// (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 -- below fp32 resolution of the products it enters), and exp(-z^2) =
+// exp(-x^2 / 2) is also the Gaussian of the derivative.  libm's erff costs ~3x the VALU instructions, and VALU time in a
+// GEMM epilogue is not hidden (one wave per SIMD): measured +95 us on the [16k x 1024] hidden-gradient GEMM with erff.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x), e = __expf(-0.5f * x * x);
+    const float t = __frcp_rn(1.f + 0.3275911f * 0.70710678118654752440f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float tail = 0.5f * poly * e;                     // 0.5 * erfc(|x| / sqrt 2): Phi(-|x|) without cancellation
+    cdf = x >= 0.f ? 1.f - tail : tail;
+    pdf = 0.39894228040143267794f * e;
 }
+__device__ __forceinline__ float gelu_f(float x) { float c, p; gelu_parts(x, c, p); return x * c; }
+__device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
 
 // Shared epilogue of the NT kernels.  D layout of 32x32 MFMAs (dtype independent): col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -349,6 +359,20 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict_
     }
 }
 
+// stand-alone GELU (erf) passes over [n] floats -- the unfused alternative to epilogues 2 / 4 (HBM-bound, full occupancy)
+__global__ __launch_bounds__(256) void gelu_fwd_k(const float4* __restrict__ h, float4* __restrict__ a, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = h[i];
+        a[i] = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_k(const float4* __restrict__ da, const float4* __restrict__ h, float4* __restrict__ dh, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 g = da[i], v = h[i];
+        dh[i] = make_float4(g.x * gelu_grad_f(v.x), g.y * gelu_grad_f(v.y), g.z * gelu_grad_f(v.z), g.w * gelu_grad_f(v.w));
+    }
+}
+
 // out[c][r] = in[r][c]
 __global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in, float* __restrict__ out, int R, int Ccols) {
     __shared__ float tile[32][33];
@@ -464,6 +488,20 @@ int u3d_gemm_tn(const float* A, const float* B, float* C, float* colsum_A, int64
     grid = grid > 1024 ? 1024 : grid;
     hipLaunchKernelGGL(gemm_tn_reduce_k, dim3((unsigned)grid), dim3(256), 0, s, (const float*)ws, S, n4, n4_main, C, colsum_A);
     return check_launch("gemm_tn");
+}
+
+int u3d_gelu_fwd(const float* h, float* a, int64_t n, u3d_stream_t stream) {
+    if (!h || !a || n <= 0 || n % 4) return U3D_EINVAL;
+    int64_t g = ceil_div(n / 4, 256);
+    hipLaunchKernelGGL(gelu_fwd_k, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, (hipStream_t)stream, (const float4*)h, (float4*)a, n / 4);
+    return check_launch("gelu_fwd");
+}
+
+int u3d_gelu_bwd(const float* da, const float* h, float* dh, int64_t n, u3d_stream_t stream) {
+    if (!da || !h || !dh || n <= 0 || n % 4) return U3D_EINVAL;
+    int64_t g = ceil_div(n / 4, 256);
+    hipLaunchKernelGGL(gelu_bwd_k, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, (hipStream_t)stream, (const float4*)da, (const float4*)h, (float4*)dh, n / 4);
+    return check_launch("gelu_bwd");
 }
 
 int u3d_transpose(const float* in, float* out, int R, int C, u3d_stream_t stream) {

@@ -2,10 +2,13 @@
 weight gradient of the decoder's Linear layers (unidet3d/encoder.py:19-21,55-61,138-140,153-155,163)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
 from . import precision as P
+from . import account
 
 _PROFILE_FLOPS = False
 
@@ -33,16 +36,19 @@ def _gemm_nt(a, w, bias, bf=False):
                    _flops(M, N, a.shape[1]), L.stream())
         else:
             K = a.shape[1]
-            L.call('u3d_gemm_nt', L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(c), M, N, K, 2.0 * M * N * K if _PROFILE_FLOPS else 0.0,
-                   L.stream())
+            L.call('u3d_gemm_nt', L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(c), M, N, K, _flops(M, N, K), L.stream())
     return c
 
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
-def _flops(M, N, K):
-    return 2.0 * M * N * K if _PROFILE_FLOPS else 0.0
+def _flops(M, N, K, extra_mn=0):
+    """algorithmic flops of an [M,K] x [K,N] product, booked with its bytes (operands + result (+ extra [M,N] streams))"""
+    if not _PROFILE_FLOPS:
+        return 0.0
+    account.add('gemm', 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N * (1 + extra_mn)))
+    return 2.0 * M * N * K
 
 
 def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False):
@@ -67,7 +73,7 @@ def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False):
     dx = torch.empty(M, K, dtype=torch.float32, device=dev)
     if M:
         L.call('u3d_linear_dact', L.ptr(dy), L.ptr(wt), L.ptr(aux), act | (P.BF16_FLAG if bf else 0), L.ptr(dx), M, K, N,
-               _flops(M, K, N), L.stream())
+               _flops(M, K, N, extra_mn=1), L.stream())
     return dx
 
 
@@ -129,6 +135,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     return _LinearFn.apply(x, weight, bias)
 
 
+# GELU in the GEMM epilogues (True) or as stand-alone passes u3d_gelu_fwd / u3d_gelu_bwd between plain GEMMs (False).  ReLU is
+# always fused (one v_max / one compare per element).  Measured on MI355X (tools/prof_mlp.py, FFN 256 -> 1024 -> 256 over 16.8 k
+# rows, forward + backward): fused 0.761 ms, stand-alone passes 0.682 ms (bf16 operands: 0.487 / 0.438) -- the ~15 VALU
+# instructions per element of the erf GELU are not hidden in a GEMM epilogue (one wave per SIMD), while the stand-alone pass
+# runs at HBM speed; so the default is the stand-alone pass.
+FUSE_GELU = os.environ.get('U3D_FUSE_GELU', '0') == '1'
+
+
 class _MLPFn(torch.autograd.Function):
     """z = act(x W1^T + b1) W2^T + b2 (include/u3d.h u3d_ffn_fwd): bias and activation live in the first GEMM's epilogue, the
     activation's derivative in the epilogue of the GEMM that produces the hidden gradient -- no elementwise kernels."""
@@ -144,7 +158,14 @@ class _MLPFn(torch.autograd.Function):
         z = torch.empty(M, d_out, dtype=torch.float32, device=dev)
         w1c, w2c = w1.contiguous(), w2.contiguous()
         ctx.bf = P.bf16()
-        if M:
+        ctx.fused = act != ACT_GELU or FUSE_GELU
+        if M and not ctx.fused:                      # plain GEMM (+bias) -> GELU pass -> plain GEMM
+            h = _gemm_nt(x, w1c, b1, ctx.bf)
+            L.call('u3d_gelu_fwd', L.ptr(h), L.ptr(a), M * hid, L.stream())
+            z = _gemm_nt(a, w2c, b2, ctx.bf)
+        elif M:
+            _flops(M, hid, d_in, extra_mn=1 if act == ACT_GELU else 0)
+            _flops(M, d_out, hid)
             L.call('u3d_ffn_fwd', L.ptr(x), L.ptr(w1c), L.ptr(b1), L.ptr(w2c), L.ptr(b2), act | (P.BF16_FLAG if ctx.bf else 0),
                    L.ptr(h), L.ptr(a), L.ptr(z), M, d_in, hid, d_out, 1.0 if _PROFILE_FLOPS else 0.0, L.stream())
         ctx.save_for_backward(x, w1c, w2c, a, h)
@@ -157,7 +178,13 @@ class _MLPFn(torch.autograd.Function):
         dz = dz.contiguous()
         need = ctx.needs_input_grad
         dw2, db2 = _weight_grad(dz, a, ctx.bias[1] and need[4]) if need[3] else (None, None)
-        dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf)
+        if ctx.fused:
+            dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf)
+        else:
+            da = _input_grad(dz, w2, bf=ctx.bf)
+            dh = torch.empty_like(da)
+            if da.numel():
+                L.call('u3d_gelu_bwd', L.ptr(da), L.ptr(h), L.ptr(dh), da.numel(), L.stream())
         dw1, db1 = _weight_grad(dh, x, ctx.bias[0] and need[2]) if need[1] else (None, None)
         dx = _input_grad(dh, w1, bf=ctx.bf) if need[0] else None
         return dx, dw1, db1, dw2, db2, None

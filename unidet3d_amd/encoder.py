@@ -23,13 +23,14 @@ from torch import nn
 
 from . import _lib as L
 from . import precision as P
+from . import account
 from .dense import LayerNorm, linear, mlp
 from .registry import MODELS
 
 
 class _AttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cu_seqlens, max_len, H):
+    def forward(ctx, qkv, cu_seqlens, max_len, H, sum_sq):
         qkv = qkv.contiguous()
         n, d3 = qkv.shape
         d = d3 // 3
@@ -37,7 +38,11 @@ class _AttnFn(torch.autograd.Function):
         out = torch.empty(n, d, dtype=torch.float32, device=qkv.device)
         lse = torch.empty(H, n, dtype=torch.float32, device=qkv.device)
         B = cu_seqlens.numel() - 1
-        flops = 0.0
+        # algorithmic work (bench accounting): S = Q K^T and O = P V -> 4 n_i^2 d flops per scene; qkv read once, out written once
+        flops = 4.0 * sum_sq * d if account.ON and sum_sq else 0.0
+        if flops:
+            account.add('attn_fwd', flops, 4.0 * n * (4 * d + H))
+        ctx.sum_sq = sum_sq
         ctx.sfx = '_bf16' if P.bf16() else ''
         if n:
             L.call('u3d_attn_varlen_fwd' + ctx.sfx, L.ptr(qkv), L.ptr(cu_seqlens), B, max_len, n, H, hd, 1.0 / math.sqrt(hd),
@@ -55,15 +60,20 @@ class _AttnFn(torch.autograd.Function):
         hd = d3 // 3 // H
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(H, n, dtype=torch.float32, device=qkv.device)
+        # five matrix products are needed (S, dP, dV, dK, dQ): 10 n_i^2 d flops; qkv, out, dout read, dqkv written
+        flops = 10.0 * ctx.sum_sq * (d3 // 3) if account.ON and ctx.sum_sq else 0.0
+        if flops:
+            account.add('attn_bwd', flops, 4.0 * n * (8 * (d3 // 3) + 2 * H))
         if n:
             L.call('u3d_attn_varlen_bwd' + ctx.sfx, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(cu), cu.numel() - 1,
-                   ctx.max_len, n, H, hd, 1.0 / math.sqrt(hd), L.ptr(dqkv), L.ptr(delta), 0.0, L.stream())
-        return dqkv, None, None, None
+                   ctx.max_len, n, H, hd, 1.0 / math.sqrt(hd), L.ptr(dqkv), L.ptr(delta), flops, L.stream())
+        return dqkv, None, None, None, None
 
 
-def attention_varlen(qkv, cu_seqlens, max_len, num_heads):
-    """softmax(Q K^T / sqrt(hd)) V per scene and head; qkv [n, 3*d] packed, cu_seqlens int32 [B+1]."""
-    return _AttnFn.apply(qkv, cu_seqlens, max_len, num_heads)
+def attention_varlen(qkv, cu_seqlens, max_len, num_heads, sum_sq=0):
+    """softmax(Q K^T / sqrt(hd)) V per scene and head; qkv [n, 3*d] packed, cu_seqlens int32 [B+1];
+    ``sum_sq`` = sum of n_i^2 (host value, only used for the bench's flops accounting)."""
+    return _AttnFn.apply(qkv, cu_seqlens, max_len, num_heads, sum_sq)
 
 
 class _MHA(nn.Module):
@@ -78,9 +88,9 @@ class _MHA(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 
-    def forward(self, x, cu_seqlens, max_len):
+    def forward(self, x, cu_seqlens, max_len, sum_sq=0):
         qkv = linear(x, self.in_proj_weight, self.in_proj_bias)
-        o = attention_varlen(qkv, cu_seqlens, max_len, self.num_heads)
+        o = attention_varlen(qkv, cu_seqlens, max_len, self.num_heads, sum_sq)
         return linear(o, self.out_proj.weight, self.out_proj.bias)
 
 
@@ -92,8 +102,8 @@ class SelfAttentionLayer(nn.Module):          # encoder.py:8-41
         self.attn = _MHA(d_model, num_heads)
         self.norm = LayerNorm(d_model)
 
-    def forward(self, x, cu_seqlens, max_len):
-        return self.norm(self.attn(x, cu_seqlens, max_len), x)           # LayerNorm(attn + x), add fused
+    def forward(self, x, cu_seqlens, max_len, sum_sq=0):
+        return self.norm(self.attn(x, cu_seqlens, max_len, sum_sq), x)   # LayerNorm(attn + x), add fused
 
 
 class FFN(nn.Module):                         # encoder.py:43-80
@@ -191,12 +201,13 @@ class UniDet3DEncoder(nn.Module):
         dev = x[0].device
         cu = L.h2d([0] + list(itertools.accumulate(sizes)), torch.int32, dev)
         max_len = max(sizes) if sizes else 0
+        sum_sq = sum(s * s for s in sizes)
         centers_packed = torch.cat(sp_centers) if len(sp_centers) > 1 else sp_centers[0]
         x0 = torch.cat(x) if len(x) > 1 else x[0]
         feats = mlp(x0, self.input_proj[0].weight, self.input_proj[0].bias, self.input_proj[2].weight, self.input_proj[2].bias, 'relu')
         outs = [self._forward_head(feats, sizes, sp_centers, centers_packed, datasets_names)]
         for i in range(self.num_layers):
-            feats = self.self_attn_layers[i](feats, cu, max_len)
+            feats = self.self_attn_layers[i](feats, cu, max_len, sum_sq)
             feats = self.ffn_layers[i](feats)
             outs.append(self._forward_head(feats, sizes, sp_centers, centers_packed, datasets_names))
         aux = [dict(cls_preds=c, bboxes=b) for c, b, _ in outs[:-1]]

@@ -27,6 +27,7 @@ from torch import nn
 from . import _lib as L
 from . import dense
 from . import precision as P
+from . import account
 
 
 # ----------------------------------------------------------------------------------------
@@ -159,9 +160,7 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
     if n_dst:
         R, G = _plan(Cs, Cd, rb.K, n_dst)
         if _PROFILE_FLOPS:      # N(Cs+Cd)s + 2P*idx + K*Cs*Cd*s  (s = 4 B, idx = 4 B)
-            ACCOUNT['gmm_launches'] += 1
-            ACCOUNT['gmm_flops'] += flops
-            ACCOUNT['gmm_bytes'] += 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd
+            account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
         bf = bf and Cs % 32 == 0
         wp = torch.empty(weight.numel() // (2 if bf else 1), dtype=torch.float32, device=src.device)       # MFMA-fragment order
@@ -184,12 +183,15 @@ def _side_stream(device):
 
 
 _PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops
-ACCOUNT = dict(gmm_launches=0, gmm_flops=0.0, gmm_bytes=0.0)      # algorithmic work of spconv_gmm launches (bench)
 
 
 def set_profile_flops(on: bool):
+    """Launches carry their algorithmic flops to the C side (HIP-event timing per kernel family) and are booked in
+    ``account`` (sparse conv here, dense GEMMs and attention in dense.py / encoder.py)."""
     global _PROFILE_FLOPS
     _PROFILE_FLOPS = bool(on)
+    dense.set_profile_flops(on)
+    account.enable(on)
 
 
 class _SparseConvFn(torch.autograd.Function):
@@ -227,6 +229,8 @@ class _SparseConvFn(torch.autograd.Function):
                 rx, rg, role, n_dy = rb.pair_in, rb.pair_out, 'out', rb.n_out
             else:
                 rx, rg, role, n_dy = rb.pair_out, rb.pair_in, 'in', rb.n_in
+            if _PROFILE_FLOPS:
+                account.add('conv_wgrad', flops, 4.0 * (src.shape[0] * cin + n_dy * cout) + 8.0 * rb.total_pairs + 4.0 * rb.K * cin * cout)
             Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
             ws = L.scratch(L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout), weight.device)
             ts = rb.tile_starts(role, Tw)

@@ -144,6 +144,11 @@ int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k
 int u3d_spconv_wgrad(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
                      const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
                      float* dW, void* ws, double flops_hint, u3d_stream_t stream);
+/* bf16-operand form (BASELINE configs[2]): x and dy rows are rounded to bf16 as the v_mfma_f32_16x16x32_bf16 operands are
+ * formed (32 pairs per instruction); fp32 accumulation, partials and reduce.  Same arguments / workspace. */
+int u3d_spconv_wgrad_bf16(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
+                          const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
+                          float* dW, void* ws, double flops_hint, u3d_stream_t stream);
 int u3d_spconv_wgrad_tile_rows(int K, int64_t n_rows_dy, int Cs, int Cd);
 int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd);
 /* wp = fragment-ordered copy of the weights for u3d_spconv_gmm ([Cd*K*Cs] floats):
@@ -273,6 +278,10 @@ int u3d_gelu_bwd(const float* da, const float* h, float* dh, int64_t n, u3d_stre
 /* colsum_A (nullable, [N]): column sums of A -- the bias gradient of the Linear layer -- produced by the same pass */
 int u3d_gemm_tn(const float* A /*[M,N]*/, const float* B /*[M,K]*/, float* C /*[N,K] = A^T B*/, float* colsum_A, int64_t M, int N, int K,
                 void* ws, double flops_hint, u3d_stream_t stream);
+/* bf16-operand form (BASELINE configs[2]): A and B are rounded to bf16 as they are staged, fp32 accumulation; colsum_A is
+ * summed from the unrounded fp32 values.  Same workspace. */
+int u3d_gemm_tn_bf16(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
+                     u3d_stream_t stream);
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K);
 int u3d_transpose(const float* in /*[R,C]*/, float* out /*[C,R]*/, int R, int C, u3d_stream_t stream);
 

@@ -46,11 +46,15 @@ def test_linear_bf16_self_consistent_and_close(M, K, N):
     if N % 16 == 0:
         dx_ref = linear(_rb(go).to(DEV), _rb(w).t().contiguous().to(DEV))      # dX = round(dY) . round(W)
         assert _rel(xb.grad, dx_ref) < 2e-5
-    # (2) against fp64 at the bf16 tolerance; the weight gradient stays on the fp32 kernel
+    # weight gradient: the fp32 kernel on round(dY), round(X); the bias gradient is summed from the unrounded dY
+    xg, wg, bg = [t.clone().to(DEV).requires_grad_() for t in (_rb(x), w, b)]
+    linear(xg, wg, bg).backward(_rb(go).to(DEV))
+    assert _rel(wb.grad, wg.grad) < 2e-5
+    # (2) against fp64 at the bf16 tolerance
     xo, wo, bo = [t.clone().double().requires_grad_() for t in (x, w, b)]
     yo = torch.nn.functional.linear(xo, wo, bo); yo.backward(go.double())
     assert _rel(yb, yo) < 1e-2 and _rel(xb.grad, xo.grad) < 1e-2
-    assert _rel(wb.grad, wo.grad) < 2e-5 and _rel(bb.grad, bo.grad) < 1e-5
+    assert _rel(wb.grad, wo.grad) < 1e-2 and _rel(bb.grad, bo.grad) < 1e-5
 
 
 @pytest.mark.parametrize('M,d_in,hid,d_out,act', [(16001, 256, 1024, 256, 'gelu'), (4097, 32, 256, 256, 'relu'), (2500, 256, 256, 19, 'relu')])
@@ -73,7 +77,7 @@ def test_mlp_bf16_close(M, d_in, hid, d_out, act):
         # ReLU is not smooth: hidden units whose pre-activation lies within the bf16 rounding error of zero switch on / off,
         # which moves single gradient entries by their full contribution -- judged in the Frobenius norm there
         e = _rel(d.grad, r.grad) if act == 'gelu' else float((d.grad.double().cpu() - r.grad).norm() / r.grad.norm())
-        assert e < 2e-2, (name, e)
+        assert e < (2e-2 if act == 'gelu' else 6e-2), (name, e)
 
 
 # ---------------------------------------------------------------------------- attention
@@ -135,12 +139,14 @@ def test_subm_conv_bf16_self_consistent_and_close(cin, cout):
     yb, dxb, dwb = run(x, w, go, 'bf16')
     yr, _, _ = run(_rb(x), _rb(w), go, 'fp32')
     _, dxr, _ = run(x, _rb(w), _rb(go), 'fp32')
+    _, _, dwr = run(_rb(x), w, _rb(go), 'fp32')
     yf, dxf, dwf = run(x, w, go, 'fp32')
     assert _rel(yb, yr) < 2e-5, 'forward is not the fp32 kernel on rounded operands'
     if cout % 32 == 0:
         assert _rel(dxb, dxr) < 2e-5, 'input gradient is not the fp32 kernel on rounded operands'
     assert _rel(yb, yf) < 1e-2 and _rel(dxb, dxf) < 1e-2
-    assert _rel(dwb, dwf) < 1e-5                          # the weight gradient stays on fp32 operands
+    assert _rel(dwb, dwr) < 2e-5, 'weight gradient is not the fp32 kernel on rounded operands'
+    assert _rel(dwb, dwf) < 1e-2
 
 
 def test_strided_and_inverse_conv_bf16():

@@ -5,7 +5,7 @@ TAG=${1:-run}; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 rm -f gpurun_out/parity_errors.jsonl
-timeout 1500 python -m pytest tests -m gpu -q -x "$@" > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q "$@" > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt
 tail -5 $OUT/pytest_gpu.txt
 cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.log; tail -c 1500 $OUT/bench.json

@@ -42,6 +42,7 @@ PROTOTYPES = {
     'u3d_weight_pack_bf16': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_spconv_plan': (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
     'u3d_spconv_wgrad': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
+    'u3d_spconv_wgrad_bf16': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
     'u3d_spconv_wgrad_tile_rows': (_i32, [_i32, _i64, _i32, _i32]),
     'u3d_spconv_wgrad_ws_bytes': (_i64, [_i32, _i64, _i32, _i32]),
     'u3d_layer_norm_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
@@ -74,6 +75,7 @@ PROTOTYPES = {
     'u3d_gelu_fwd': (_i32, [_vp, _vp, _i64, _vp]),
     'u3d_gelu_bwd': (_i32, [_vp, _vp, _vp, _i64, _vp]),
     'u3d_gemm_tn': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp]),
+    'u3d_gemm_tn_bf16': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp]),
     'u3d_gemm_tn_ws_bytes': (_i64, [_i64, _i32, _i32]),
     'u3d_transpose': (_i32, [_vp, _vp, _i32, _i32, _vp]),
     'u3d_attn_varlen_fwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),

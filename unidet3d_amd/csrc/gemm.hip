@@ -333,6 +333,118 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
     if (sums && n0 + tid < N) partial[(int64_t)blockIdx.z * pstride + (int64_t)N * K + n0 + tid] = csum;
 }
 
+// bf16-operand form of gemm_tn_k (weight gradients of the Linear layers under BASELINE configs[2]): A (= dY) and B (= X) are
+// rounded to bf16 while they are staged, the reduction over the M rows runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// The reduction index is the ROW index of both operands, so a lane's 8 consecutive k values are a COLUMN of the staged
+// [32 rows][128 cols] tile: eight 2-byte LDS reads per fragment (a half-wave reads 64 contiguous bytes of one row, the two
+// halves rows 8 apart -- conflict free).  The column sums of A (bias gradient) are accumulated from the fp32 values before
+// they are rounded.
+constexpr int TKH = 32;              // rows per stage
+constexpr int TLH = GT + 8;          // padded LDS row (halves)
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
+                                                      int colsum, int64_t M, int N, int K, int64_t rows_per_split) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][TKH * TLH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TKH * TLH];
+    __shared__ float csum_s[8][GT];
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.x * GT, k0 = blockIdx.y * GT;
+    const int64_t mlo = (int64_t)blockIdx.z * rows_per_split;
+    const int64_t mhi = min(M, mlo + rows_per_split);
+    const int rows = (int)max((int64_t)0, mhi - mlo);
+    // staging map: thread -> (row = tid>>5 (+8 j, j < 4), float4 column = tid&31)
+    const int srow = tid >> 5, sc4 = tid & 31;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + mlo * N, (int64_t)rows * N * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + mlo * K, (int64_t)rows * K * 4);
+    const int va = n0 + sc4 * 4 < N ? (srow * N + n0 + sc4 * 4) * 4 : 0x7fffffff;
+    const int vb = k0 + sc4 * 4 < K ? (srow * K + k0 + sc4 * 4) * 4 : 0x7fffffff;
+    const bool ca = va != 0x7fffffff, cb = vb != 0x7fffffff;
+    f32x4 ra[4], rb[4];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = bload128(rs_a, ca ? va + j * 8 * N * 4 : va, t * (TKH * N * 4));
+            rb[j] = bload128(rs_b, cb ? vb + j * 8 * K * 4 : vb, t * (TKH * K * 4));
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cs += ra[j];
+            *reinterpret_cast<bf16x4*>(&As[buf][(srow + 8 * j) * TLH + sc4 * 4]) = bf16x4{(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
+            *reinterpret_cast<bf16x4*>(&Bs[buf][(srow + 8 * j) * TLH + sc4 * 4]) = bf16x4{(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
+        }
+    };
+    auto colfrag = [&](const __bf16* t, int row0, int col) {
+        const __bf16* p = t + row0 * TLH + col;
+        return bf16x8{p[0], p[TLH], p[2 * TLH], p[3 * TLH], p[4 * TLH], p[5 * TLH], p[6 * TLH], p[7 * TLH]};
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nt = (rows + TKH - 1) / TKH;
+    if (nt > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r0 = h * 16 + kh * 8;                 // this lane's 8 reduction rows of the 16-deep block
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                af[u] = colfrag(As[buf], r0, wr * 64 + u * 32 + i32);
+                bf[u] = colfrag(Bs[buf], r0, wc * 64 + u * 32 + i32);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)blockIdx.z * pstride, (int64_t)N * K * 4);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int k = k0 + wc * 64 + b * 32 + i32;
+        const int vo = k < K ? ((n0 + 4 * kh) * K + k) * 4 : 0x7fffffff;        // rows past N fall off the end of the descriptor
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[a][b][r];
+                asm volatile("" : "+v"(v));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, row * K * 4, 0);
+            }
+    }
+    if (colsum && blockIdx.y == 0) {       // column sums of A: 8 row-slots per column -> one value per column
+#pragma unroll
+        for (int c = 0; c < 4; ++c) csum_s[srow][sc4 * 4 + c] = cs[c];
+        __syncthreads();
+        if (tid < GT && n0 + tid < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v += csum_s[r][tid];
+            partial[(int64_t)blockIdx.z * pstride + (int64_t)N * K + n0 + tid] = v;
+        }
+    }
+}
+
 // sums the splits in a fixed order; float4 i < n4_main goes to C, the rest (the column sums) to C2
 __global__ __launch_bounds__(256) void gemm_tn_reduce_k(const float* __restrict__ partial, int S, int64_t n4, int64_t n4_main, float* __restrict__ C,
                                                         float* __restrict__ C2) {
@@ -470,8 +582,8 @@ int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W
 
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K) * ((int64_t)N * K + N) * 4 + 256; }
 
-int u3d_gemm_tn(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
-                u3d_stream_t stream) {
+static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
+                        u3d_stream_t stream, bool bf) {
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return U3D_EINVAL;
     if (N % 4 || K % 4) { set_error("gemm_tn: N=%d, K=%d must be multiples of 4", N, K); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
@@ -482,7 +594,8 @@ int u3d_gemm_tn(const float* A, const float* B, float* C, float* colsum_A, int64
         set_error("gemm_tn: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
         return U3D_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
+    if (bf) hipLaunchKernelGGL(gemm_tn_bf16_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
+    else hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
     const int64_t n4_main = (int64_t)N * K / 4, n4 = n4_main + (colsum_A ? N / 4 : 0);
     int64_t grid = ceil_div(n4, 256);
     grid = grid > 1024 ? 1024 : grid;
@@ -502,6 +615,16 @@ int u3d_gelu_bwd(const float* da, const float* h, float* dh, int64_t n, u3d_stre
     int64_t g = ceil_div(n / 4, 256);
     hipLaunchKernelGGL(gelu_bwd_k, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, (hipStream_t)stream, (const float4*)da, (const float4*)h, (float4*)dh, n / 4);
     return check_launch("gelu_bwd");
+}
+
+int u3d_gemm_tn(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
+                u3d_stream_t stream) {
+    return gemm_tn_impl(A, B, C, colsum_A, M, N, K, ws, flops_hint, stream, false);
+}
+
+int u3d_gemm_tn_bf16(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
+                     u3d_stream_t stream) {
+    return gemm_tn_impl(A, B, C, colsum_A, M, N, K, ws, flops_hint, stream, true);
 }
 
 int u3d_transpose(const float* in, float* out, int R, int C, u3d_stream_t stream) {

@@ -439,8 +439,10 @@ __device__ __forceinline__ void load_row_part(float (&v)[N], __amdgpu_buffer_rsr
     }
 }
 
-// NG = Cd/16, NX = Cs/16 floats per lane per row; SG x SX waves share one pair range
-template <int NG, int NX, int SG, int SX>
+// NG = Cd/16, NX = Cs/16 floats per lane per row; SG x SX waves share one pair range.
+// BF (BASELINE configs[2]): the same walk with v_mfma_f32_16x16x32_bf16 -- 32 pairs per instruction, lane group q takes pairs
+// 8q .. 8q+7 of a trip and rounds its row parts to bf16 (RNE) as it forms the operands; fp32 accumulation and partials.
+template <int NG, int NX, int SG, int SX, bool BF = false>
 __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
     constexpr int NGW = NG / SG, NXW = NX / SX, SPLIT = SG * SX, RPW = 4 / SPLIT;   // RPW ranges per workgroup
     constexpr int CD = NG * 16, CS = NX * 16;
@@ -473,6 +475,41 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
         for (int b = 0; b < NXW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int base = lo;
+    if constexpr (BF) {
+        const int q32 = q * 32;
+        for (; base < hi; base += 32) {            // 32 pairs per trip; the last trip clamps its indices into the range and masks dy
+            const bool full = base + 32 <= hi;       // wave-uniform
+            float gv[8][NGW], xv[8][NXW];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int io, ix;
+                if (full) {
+                    io = bload32(rs_rg, q32 + u * 4, ksoff + base * 4);
+                    ix = bload32(rs_rx, q32 + u * 4, ksoff + base * 4);
+                } else {
+                    const int pi = min(base + 8 * q + u, hi - 1);
+                    io = bload32(rs_rg, pi * 4, ksoff);
+                    ix = bload32(rs_rx, pi * 4, ksoff);
+                }
+                load_row_part<NGW>(gv[u], rs_g, (int)__umul24(io, CD * 4) + gvo);
+                load_row_part<NXW>(xv[u], rs_x, (int)__umul24(ix, CS * 4) + xvo);
+                if (!full && base + 8 * q + u >= hi) {          // pairs past the end contribute exact zeros
+#pragma unroll
+                    for (int a = 0; a < NGW; ++a) gv[u][a] = 0.f;
+                }
+            }
+            bf16x8 xb[NXW];
+#pragma unroll
+            for (int b = 0; b < NXW; ++b)
+                xb[b] = bf16x8{(__bf16)xv[0][b], (__bf16)xv[1][b], (__bf16)xv[2][b], (__bf16)xv[3][b], (__bf16)xv[4][b], (__bf16)xv[5][b], (__bf16)xv[6][b], (__bf16)xv[7][b]};
+#pragma unroll
+            for (int a = 0; a < NGW; ++a) {
+                const bf16x8 ga = bf16x8{(__bf16)gv[0][a], (__bf16)gv[1][a], (__bf16)gv[2][a], (__bf16)gv[3][a], (__bf16)gv[4][a], (__bf16)gv[5][a], (__bf16)gv[6][a], (__bf16)gv[7][a]};
+#pragma unroll
+                for (int b = 0; b < NXW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, xb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
     for (; base + 16 <= hi; base += 16) {        // full trips: 4 MFMA K-steps (16 pairs), all loads up front
         int io[4], ix[4];        // dword loads: `base` is only 4-byte aligned and 16-byte buffer loads are size-aligned by the hardware
 #pragma unroll
@@ -561,7 +598,7 @@ static int plan_wgrad_rows(int K, int64_t n_rows, int Cs, int Cd) {
     return (int)ceil_div(n_rows, nt);
 }
 
-template <int NX, int NG>     // (Cs/16, Cd/16) as the dispatch macro passes them
+template <int NX, int NG, bool BF = false>     // (Cs/16, Cd/16) as the dispatch macro passes them
 static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     // split over the 4 waves until a wave's sub-block is <= 32 accumulators (128 VGPRs)
     constexpr int SG = (NG * NX > 32 && NG % 2 == 0 && NG >= NX) ? 2 : ((NG * NX > 64 && NG % 2 == 0) ? 2 : 1);
@@ -570,7 +607,7 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "wave split");
     const WgParams& p = p0;
     const int64_t groups = ceil_div(ceil_div(p.n_tiles, RPW), 8) * 8;
-    hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, BF>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, p.n_tiles, p.K, NG, NX, SG, SX, dW);
     return check_launch("spconv_wgrad");
 }
@@ -729,9 +766,9 @@ int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd) {
     return (int64_t)K * ceil_div(n_rows_dy, T) * Cs * Cd * 4 + 256;
 }
 
-int u3d_spconv_wgrad(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
-                     const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
-                     float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
+static int spconv_wgrad_impl(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
+                             const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
+                             float* dW, void* ws, double flops_hint, u3d_stream_t stream, bool bf) {
     if (!x || !dy || !rows_x || !rows_dy || !tile_starts || !dW || !ws || K <= 0 || cap <= 0 || n_rows_dy <= 0 || n_rows_x <= 0) return U3D_EINVAL;
     if (n_rows_x >= (1 << 24) || n_rows_dy >= (1 << 24) || n_rows_x * Cs * 4 >= 0x7fffffffLL || n_rows_dy * Cd * 4 >= 0x7fffffffLL ||
         (int64_t)K * cap * 4 >= 0x7fffffffLL) {
@@ -749,7 +786,7 @@ int u3d_spconv_wgrad(const float* x, int64_t n_rows_x, const float* dy, const in
     p.n_tiles = (int)ceil_div(n_rows_dy, tile_rows);
     const int cs16 = Cs / 16, cd16 = Cd / 16;
     if (Cs % 16 || Cd % 32) return U3D_EUNSUPPORTED;
-#define U3D_WG_CASE(cs, cd) if (cs16 == cs && cd16 == cd) return launch_wgrad<cs, cd>(p, dW, s);
+#define U3D_WG_CASE(cs, cd) if (cs16 == cs && cd16 == cd) return bf ? launch_wgrad<cs, cd, true>(p, dW, s) : launch_wgrad<cs, cd, false>(p, dW, s);
     U3D_WG_CASE(1, 2) U3D_WG_CASE(2, 2) U3D_WG_CASE(4, 2) U3D_WG_CASE(4, 4) U3D_WG_CASE(8, 4)
     U3D_WG_CASE(6, 6) U3D_WG_CASE(12, 6) U3D_WG_CASE(8, 8) U3D_WG_CASE(16, 8) U3D_WG_CASE(10, 10)
     U3D_WG_CASE(2, 4) U3D_WG_CASE(4, 6) U3D_WG_CASE(6, 8) U3D_WG_CASE(8, 10)
@@ -757,6 +794,18 @@ int u3d_spconv_wgrad(const float* x, int64_t n_rows_x, const float* dy, const in
 #undef U3D_WG_CASE
     set_error("spconv_wgrad: no instantiation for Cs=%d Cd=%d", Cs, Cd);
     return U3D_EUNSUPPORTED;
+}
+
+int u3d_spconv_wgrad(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
+                     const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
+                     float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
+    return spconv_wgrad_impl(x, n_rows_x, dy, rows_x, rows_dy, tile_starts, K, cap, n_rows_dy, tile_rows, Cs, Cd, dW, ws, flops_hint, stream, false);
+}
+
+int u3d_spconv_wgrad_bf16(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
+                          const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
+                          float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
+    return spconv_wgrad_impl(x, n_rows_x, dy, rows_x, rows_dy, tile_starts, K, cap, n_rows_dy, tile_rows, Cs, Cd, dW, ws, flops_hint, stream, true);
 }
 
 int u3d_weight_pack(const float* w, float* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {

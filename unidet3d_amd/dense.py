@@ -77,8 +77,9 @@ def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False):
     return dx
 
 
-def _weight_grad(dy, x, want_bias):
+def _weight_grad(dy, x, want_bias, bf=False):
     """(dW[N,K] = dY^T X, db[N] = column sums of dY or None): one pass of u3d_gemm_tn (+ fixed-order reduce)."""
+    tn = 'u3d_gemm_tn_bf16' if bf else 'u3d_gemm_tn'
     M, N = dy.shape
     K = x.shape[1]
     dev = dy.device
@@ -88,7 +89,7 @@ def _weight_grad(dy, x, want_bias):
         ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, N, K), dev)
         if want_bias:                                   # the bias gradient (column sums of dy) rides along
             db = torch.empty(N, dtype=torch.float32, device=dev)
-        L.call('u3d_gemm_tn', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), M, N, K, L.ptr(ws), _flops(M, N, K), L.stream())
+        L.call(tn, L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), M, N, K, L.ptr(ws), _flops(M, N, K), L.stream())
     elif M:
         Np = (N + 3) // 4 * 4
         dyp = torch.zeros(M, Np, dtype=torch.float32, device=dev)
@@ -96,7 +97,7 @@ def _weight_grad(dy, x, want_bias):
         dwp = torch.empty(Np, K, dtype=torch.float32, device=dev)
         ws = L.scratch(L.lib().u3d_gemm_tn_ws_bytes(M, Np, K), dev)
         dbp = torch.empty(Np, dtype=torch.float32, device=dev) if want_bias else None
-        L.call('u3d_gemm_tn', L.ptr(dyp), L.ptr(x), L.ptr(dwp), L.ptr(dbp), M, Np, K, L.ptr(ws), 0.0, L.stream())
+        L.call(tn, L.ptr(dyp), L.ptr(x), L.ptr(dwp), L.ptr(dbp), M, Np, K, L.ptr(ws), 0.0, L.stream())
         dw = dwp[:N].contiguous()
         if dbp is not None:
             db = dbp[:N].contiguous()
@@ -124,7 +125,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dy, weight, bf=ctx.bf)
         if ctx.needs_input_grad[1]:
-            dw, db = _weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
+            dw, db = _weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2], ctx.bf)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db
@@ -177,7 +178,7 @@ class _MLPFn(torch.autograd.Function):
         x, w1, w2, a, h = ctx.saved_tensors
         dz = dz.contiguous()
         need = ctx.needs_input_grad
-        dw2, db2 = _weight_grad(dz, a, ctx.bias[1] and need[4]) if need[3] else (None, None)
+        dw2, db2 = _weight_grad(dz, a, ctx.bias[1] and need[4], ctx.bf) if need[3] else (None, None)
         if ctx.fused:
             dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf)
         else:
@@ -185,7 +186,7 @@ class _MLPFn(torch.autograd.Function):
             dh = torch.empty_like(da)
             if da.numel():
                 L.call('u3d_gelu_bwd', L.ptr(da), L.ptr(h), L.ptr(dh), da.numel(), L.stream())
-        dw1, db1 = _weight_grad(dh, x, ctx.bias[0] and need[2]) if need[1] else (None, None)
+        dw1, db1 = _weight_grad(dh, x, ctx.bias[0] and need[2], ctx.bf) if need[1] else (None, None)
         dx = _input_grad(dh, w1, bf=ctx.bf) if need[0] else None
         return dx, dw1, db1, dw2, db2, None
 

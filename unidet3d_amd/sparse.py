@@ -234,16 +234,17 @@ class _SparseConvFn(torch.autograd.Function):
             Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
             ws = L.scratch(L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout), weight.device)
             ts = rb.tile_starts(role, Tw)
+            wg = 'u3d_spconv_wgrad_bf16' if ctx.bf else 'u3d_spconv_wgrad'
             # the weight gradient and the input gradient of a layer are independent: the former runs on a side stream so
             # the two kernels (neither fills the machine alone) share the GPU; joined before the layer's backward returns
             if _WGRAD_SIDE_STREAM and ctx.needs_input_grad[0]:
                 side = _side_stream(weight.device)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    L.call('u3d_spconv_wgrad', L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
+                    L.call(wg, L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                            rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
             else:
-                L.call('u3d_spconv_wgrad', L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
+                L.call(wg, L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                        rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
         if ctx.needs_input_grad[0]:
             if mode == 'fwd':

@@ -60,7 +60,12 @@ int64_t u3d_vox_scene_stats_ws_bytes(int B);
 
 /* Occupancy index of one level: bitmap uint64 [B*X*Y*Zw] (Zw = ceil(Z/64); bit z&63 of word
  * ((b*X+x)*Y+y)*Zw + (z>>6)) and word_rank int32 [n_words+1] = exclusive popcount prefix, so
- * row(b,x,y,z) = word_rank[w] + popc(bitmap[w] & ((1<<bit)-1)) IS the canonical row. */
+ * row(b,x,y,z) = word_rank[w] + popc(bitmap[w] & ((1<<bit)-1)) IS the canonical row.
+ * This is a direct-address (perfect-hash) table over the grid EXTENT -- north_star's "hash-built rulebook" with the hash replaced
+ * by the cell address, which is what makes the rows come out in canonical order without a sort.  Its size does not depend on
+ * occupancy: 12 bytes per 64 z-cells.  u3d_index_words returns the word count, or a negative code when the grid is invalid or
+ * would need more than U3D_INDEX_MAX_WORDS words (refused, never allocated). */
+#define U3D_INDEX_MAX_WORDS (1LL << 31)
 int64_t u3d_index_words(int B, int X, int Y, int Z);
 /* sets the bit of every point's cell; writes pt_cell int64 [n_pts] = word*64 + bit. bitmap must be zeroed. */
 int u3d_vox_mark(const float* points, const float* coord_src, const int64_t* pt_offsets, int B,

@@ -58,3 +58,13 @@ def test_no_cpu_fallback():
         ops.voxelize([torch.rand(10, 6)], 0.02, 128)
     with pytest.raises(_lib.U3DError):
         _lib.ptr(torch.zeros(4))
+
+
+def test_index_words_bounds():
+    """The direct-address occupancy index refuses extents it cannot hold instead of allocating (no GPU needed)."""
+    from unidet3d_amd import _lib as L
+    lib = L.lib()
+    assert lib.u3d_index_words(8, 512, 512, 256) == 8 * 512 * 512 * 4
+    assert lib.u3d_index_words(1, 128, 128, 65) == 128 * 128 * 2
+    assert lib.u3d_index_words(0, 128, 128, 128) < 0
+    assert lib.u3d_index_words(8, 100_000, 100_000, 4096) < 0 and b'extent too large' in lib.u3d_last_error()

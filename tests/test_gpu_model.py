@@ -264,3 +264,39 @@ def test_large_dense_room_forward_backward():
     c0 = model._vb.coords.clone()
     model.collate(inputs['points'])
     assert torch.equal(c0, model._vb.coords)
+
+
+# ---------------------------------------------------------------------------- runner-facing surface (mmengine BaseModel)
+def test_train_step_and_val_step_drive_the_model_like_a_runner():
+    """``train_step(data, optim_wrapper)`` / ``val_step(data)`` on raw host batches (numpy / CPU tensors, one dict per sample), as
+    mmengine's train / val loops call them; the data preprocessor moves the batch to the device."""
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd.config import build_model, scannet_model_cfg
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = scannet_model_cfg(voxel_size=0.05)
+    cfg['decoder']['num_layers'] = 2
+    model = fill_state_dict(build_model(cfg), tag0=3000, scale=0.06).to(DEV)
+    assert type(model.data_preprocessor).__name__ == 'Det3DDataPreprocessor_'
+    scenes = [make_scene(80 + i, n_points=8000) for i in range(2)]
+    inputs, samples = make_batch_inputs(scenes, 'cpu')
+    batch = [dict(inputs=dict(points=inputs['points'][i].numpy()), data_samples=samples[i]) for i in range(2)]   # per-sample dicts
+
+    class OptimWrapper:                                   # the two calls of mmengine.optim.OptimWrapper this path uses
+        def __init__(self, params):
+            self.opt = torch.optim.AdamW(params, lr=1e-3)
+
+        def update_params(self, loss):
+            loss.backward(); self.opt.step(); self.opt.zero_grad()
+    ow = OptimWrapper(model.parameters())
+    model.train()
+    w0 = model.input_conv[0].weight.detach().clone()
+    logs = [model.train_step(batch, ow) for _ in range(3)]
+    assert set(logs[0]) == {'loss', 'det_loss'} and all(torch.isfinite(l['loss']) for l in logs)
+    assert float(logs[-1]['loss']) < float(logs[0]['loss'])            # three AdamW steps on the same batch reduce the loss
+    assert not torch.equal(w0, model.input_conv[0].weight.detach())
+    model.eval()
+    with torch.no_grad():
+        res = model.val_step([batch[0]])
+    pred = res[0].pred_instances_3d
+    assert pred.bboxes_3d.tensor.shape[1] == 6 and len(pred.scores_3d) == len(pred.labels_3d) == len(pred.bboxes_3d)

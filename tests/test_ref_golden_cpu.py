@@ -29,7 +29,7 @@ def T(a):
 
 
 def rel(a, b):
-    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a - b).abs().max() / (b.abs().max() + 1e-12)) if a.numel() else 0.0
 

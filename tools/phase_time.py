@@ -41,3 +41,29 @@ for _ in range(N): step()
 tot = sum(T.values())
 for k, v in T.items(): print(f'{k:32s} {v / N * 1e3:7.2f} ms')
 print(f'{"sum (synchronised phases)":32s} {tot / N * 1e3:7.2f} ms')
+# criterion alone (forward + backward to the decoder outputs), kernel count from the torch profiler
+vb, plan, offs, cent, names = model._front(inputs, samples, True)
+x = model._sparse_input(8); x = model.input_conv(x); x, _ = model.unet(x); x = model.output_layer(x)
+pooled = ops.superpoint_pool(x.features, plan); feats = [pooled[offs[i]:offs[i + 1]] for i in range(8)]
+for i, ds in enumerate(samples):
+    ds.gt_instances_3d.sp_centers = cent[i]
+q, c, g = model._select_queries(feats, [s.gt_instances_3d for s in samples])
+with torch.no_grad():
+    out = model.decoder(q, c, names)
+pk = out['_packed']
+leaves = [t.detach().clone().requires_grad_() for t in pk['cls'] + pk['box']]
+L_ = len(pk['cls'])
+out2 = dict(out, _packed=dict(cls=leaves[:L_], box=leaves[L_:], sizes=pk['sizes']))
+def crit():
+    loss = model.criterion(out2, g, names)['det_loss']
+    loss.backward()
+for _ in range(3): crit()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): crit()
+torch.cuda.synchronize()
+print(f'criterion fwd+bwd alone: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms')
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    crit(); torch.cuda.synchronize()
+ev = [e for e in prof.key_averages() if e.device_time_total > 0]
+print('criterion: %d kernel launches, %.2f ms of GPU time' % (sum(e.count for e in ev), sum(e.device_time_total for e in ev) / 1e3))

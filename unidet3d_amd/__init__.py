@@ -8,6 +8,7 @@ from .spconv_unet import SpConvUNet  # noqa: F401
 from .encoder import UniDet3DEncoder  # noqa: F401
 from .criterion import (UniDet3DCriterion, UniDet3DAxisAlignedIoULoss, UniDet3DRotatedIoU3DLoss,  # noqa: F401
                         UniMatcher, QueryClassificationCost, BboxCostJointTraining)
+from .data_preprocessor import Det3DDataPreprocessor_  # noqa: F401
 from .unidet3d import UniDet3D  # noqa: F401
 from .structures import InstanceData_  # noqa: F401
 from . import transforms, evaluation  # noqa: F401  (registers the pipeline transforms)

@@ -38,6 +38,4 @@ def scannet_model_cfg(num_channels: int = 32, voxel_size: float = 0.02) -> dict:
 
 def build_model(cfg: dict):
     from .registry import MODELS
-    cfg = dict(cfg)
-    cfg.pop('data_preprocessor', None)      # mmdet3d preprocessor: host-side list plumbing, not built here
-    return MODELS.build(dict(cfg, data_preprocessor=None))
+    return MODELS.build(dict(cfg))

@@ -246,7 +246,13 @@ class UniDet3DCriterion:
             weight = self.datasets_weights[self.datasets.index(name)]
             n_cls = cls_pred.shape[1] - 1
             target = cls_pred.new_full((len(cls_pred),), n_cls, dtype=torch.long)
-            target[idx_q] = inst.labels_3d[idx_gt]
+            # a query matched by several GTs: the reference's index assignment keeps the LAST pair (criterion.py:98-99; on a GPU
+            # the order of duplicate writes is undefined).  The matcher returns pairs sorted by (query, gt), so the last pair of
+            # every run of equal query ids is the winner -- written through unique indices, deterministic on any device.
+            if len(idx_q):
+                last = torch.ones_like(idx_q, dtype=torch.bool)
+                last[:-1] = idx_q[1:] != idx_q[:-1]
+                target[idx_q[last]] = inst.labels_3d[idx_gt[last]]
             cw = cls_pred.new_ones(n_cls + 1)
             cw[-1] = self.non_object_weight
             cls_losses.append(weight * F.cross_entropy(cls_pred, target, cw))

@@ -200,7 +200,21 @@ int u3d_vox_scene_stats(const float* points, const float* coord_src, const int64
     return check_launch("vox_scene_stats");
 }
 
-int64_t u3d_index_words(int B, int X, int Y, int Z) { return (int64_t)B * X * Y * ((Z + 63) / 64); }
+// The index is a direct-address table: its size follows the EXTENT of the grid, not the number of occupied voxels (12 bytes per
+// 64 cells along z).  Indoor scans at 2 cm stay in the tens of MB (8 scenes x 512 x 512 x 256 cells = 100 MB); a grid whose
+// table would pass U3D_INDEX_MAX_WORDS (2^31 words = 24 GiB of bitmap + rank) is refused instead of allocated -- outdoor-scale
+// extents need a sparse (hashed or two-level) index, which this library does not have.
+int64_t u3d_index_words(int B, int X, int Y, int Z) {
+    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return U3D_EINVAL;
+    const int64_t zw = (Z + 63) / 64;
+    const long double words = (long double)B * X * Y * zw;
+    if (words > (long double)U3D_INDEX_MAX_WORDS) {
+        set_error("occupancy index: grid %d x %d x %d x %d needs %.3Lg words (limit %lld): extent too large for the direct-address index",
+                  B, X, Y, Z, words, (long long)U3D_INDEX_MAX_WORDS);
+        return U3D_EUNSUPPORTED;
+    }
+    return (int64_t)B * X * Y * zw;
+}
 
 int u3d_vox_mark(const float* points, const float* coord_src, const int64_t* pt_offsets, int B, int64_t max_pts,
                  const float* stats, float voxel_size, int div_mode, int X, int Y, int Z, uint64_t* bitmap,

@@ -43,6 +43,8 @@ class OccupancyIndex:
     @staticmethod
     def alloc(B, shape, device):
         nw = L.lib().u3d_index_words(B, *[int(s) for s in shape])
+        if nw < 0:
+            raise L.U3DError(f'occupancy index refused (code {nw}): {L.lib().u3d_last_error().decode()}')
         bitmap = torch.zeros(nw, dtype=torch.int64, device=device)
         rank = torch.empty(nw + 1, dtype=torch.int32, device=device)
         return OccupancyIndex(bitmap, rank, B, shape)

@@ -30,6 +30,8 @@ class UniDet3D(nn.Module):
                  bbox_by_mask, target_by_distance, fast_nms, use_sync_bn=True, backbone=None, decoder=None,
                  criterion=None, train_cfg=None, test_cfg=None, data_preprocessor=None, init_cfg=None):
         super().__init__()
+        # mmengine BaseModel surface (train_step / val_step / test_step below): the runner feeds raw dataloader batches
+        self.data_preprocessor = MODELS.build(data_preprocessor) if isinstance(data_preprocessor, dict) else data_preprocessor
         if backbone is not None:
             self.unet = MODELS.build(backbone)
         self.decoder = MODELS.build(decoder)
@@ -242,6 +244,33 @@ class UniDet3D(nn.Module):
             ds.pred_instances_3d = InstanceData_(bboxes_3d=bboxes, scores_3d=scores, labels_3d=labels,
                                                  points=batch_inputs_dict['points'][0])
         return batch_data_samples
+
+    # ------------------------------------------------------------------ what an mmengine-style runner calls (BaseModel)
+    @staticmethod
+    def parse_losses(losses):
+        """mmengine ``BaseModel.parse_losses``: (total loss = sum of the entries whose key contains 'loss', log dict)."""
+        log = {k: (v.mean() if torch.is_tensor(v) else sum(t.mean() for t in v)) for k, v in losses.items()}
+        total = sum(v for k, v in log.items() if 'loss' in k)
+        log = dict(loss=total, **log)
+        return total, log
+
+    def _prep(self, data, training):
+        return self.data_preprocessor(data, training) if self.data_preprocessor is not None else data
+
+    def train_step(self, data, optim_wrapper):
+        """One optimisation step as ``BaseModel.train_step`` performs it: preprocess, forward(mode='loss'), parse the loss
+        dict, ``optim_wrapper.update_params(loss)`` (mmengine ``OptimWrapper`` / ``AmpOptimWrapper``, tools/train.py:86-99)."""
+        data = self._prep(data, True)
+        losses = self(data['inputs'], data['data_samples'], mode='loss')
+        total, log = self.parse_losses(losses)
+        optim_wrapper.update_params(total)
+        return log
+
+    def val_step(self, data):
+        data = self._prep(data, False)
+        return self(data['inputs'], data['data_samples'], mode='predict')
+
+    test_step = val_step
 
     def forward(self, inputs, data_samples=None, mode='loss', **kwargs):
         if mode == 'loss':

@@ -145,7 +145,8 @@ def test_subm_conv_bf16_self_consistent_and_close(cin, cout):
     if cout % 32 == 0:
         assert _rel(dxb, dxr) < 2e-5, 'input gradient is not the fp32 kernel on rounded operands'
     assert _rel(yb, yf) < 1e-2 and _rel(dxb, dxf) < 1e-2
-    assert _rel(dwb, dwr) < 2e-5, 'weight gradient is not the fp32 kernel on rounded operands'
+    if cin * cout >= 64 * 64:       # below that the gather-bound weight-gradient walk keeps fp32 operands (sparse.py)
+        assert _rel(dwb, dwr) < 2e-5, 'weight gradient is not the fp32 kernel on rounded operands'
     assert _rel(dwb, dwf) < 1e-2
 
 

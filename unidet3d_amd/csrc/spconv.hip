@@ -591,8 +591,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
 
 // rows per tile: as many tiles as a 64 MB partial buffer, a cap of 256 and >= 64 rows per tile allow
 static int plan_wgrad_rows(int K, int64_t n_rows, int Cs, int Cd) {
-    int64_t nt = (int64_t)(64 << 20) / ((int64_t)K * Cs * Cd * 4);
-    nt = nt > 256 ? 256 : (nt < 1 ? 1 : nt);      // 256 vs 512 tiles: the fixed-order reduce reads half as much, wgrad itself is unchanged
+    static const int64_t cap = [] { const char* e = getenv("U3D_WGRAD_TILES"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)256; }();
+    static const int64_t budget = [] { const char* e = getenv("U3D_WGRAD_PARTIAL_MB"); const int64_t v = e ? atoll(e) : 0; return (v > 0 ? v : (int64_t)64) << 20; }();
+    int64_t nt = budget / ((int64_t)K * Cs * Cd * 4);
+    nt = nt > cap ? cap : (nt < 1 ? 1 : nt);      // 256 vs 512 tiles: the fixed-order reduce reads half as much, wgrad itself is unchanged
     const int64_t by_len = ceil_div(n_rows, 64);
     if (nt > by_len) nt = by_len;
     return (int)ceil_div(n_rows, nt);

@@ -236,7 +236,9 @@ class _SparseConvFn(torch.autograd.Function):
             Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
             ws = L.scratch(L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout), weight.device)
             ts = rb.tile_starts(role, Tw)
-            wg = 'u3d_spconv_wgrad_bf16' if ctx.bf else 'u3d_spconv_wgrad'
+            # the weight-gradient walk is bound by its row gathers: bf16 operands pay off only where the matrix
+            # work is a visible share -- measured (tools/prof_wgrad.py): 32x32 channels 179 us fp32 vs 221 us bf16, 64x64 150 vs 104
+            wg = 'u3d_spconv_wgrad_bf16' if ctx.bf and cin * cout >= 64 * 64 else 'u3d_spconv_wgrad'
             # the weight gradient and the input gradient of a layer are independent: the former runs on a side stream so
             # the two kernels (neither fills the machine alone) share the GPU; joined before the layer's backward returns
             if _WGRAD_SIDE_STREAM and ctx.needs_input_grad[0]:

@@ -271,6 +271,15 @@ int u3d_linear_act(const float* X /*[M,K]*/, const float* W /*[N,K]*/, const flo
  * aux [M,N] = the ReLU output (act 1) or the GELU pre-activation (act 2). */
 int u3d_linear_dact(const float* dY /*[M,K]*/, const float* Wt /*[N,K]*/, const float* aux, int act, float* dX /*[M,N]*/,
                     int64_t M, int N, int K, double flops_hint, u3d_stream_t stream);
+/* C = A W^T + addend: a second gradient contribution folded into the GEMM that produces the first (flags: 0 or U3D_BF16_OPERANDS) */
+int u3d_gemm_nt_add(const float* A /*[M,K]*/, const float* W /*[N,K]*/, const float* addend /*[M,N]*/, int flags, float* C, int64_t M,
+                    int N, int K, double flops_hint, u3d_stream_t stream);
+/* SURVEY.md 8(b) `ln_linear`: NQ = LayerNorm(X (+ RES)) (u3d_layer_norm_fwd: SUM receives X + RES, STATS the row statistics), then
+ * Y = act(NQ W^T + bias) (u3d_linear_act) -- the head of the decoder (unidet3d/encoder.py:187-196: out_norm -> out_bboxes / outs_cls).
+ * Two launches: the decoder is post-norm and NQ has further consumers, so the normalised rows are written in any case. */
+int u3d_ln_linear(const float* X, const float* RES, const float* gamma, const float* beta, float eps, float* SUM, float* NQ, float* STATS,
+                  const float* W /*[N,C]*/, const float* bias, int act, float* PRE, float* Y /*[M,N]*/, int64_t M, int C, int N,
+                  double flops_hint, u3d_stream_t stream);
 /* SURVEY.md 8(b) `ffn`: Z = act(X W1^T + b1) W2^T + b2 in two launches -- the FFN block (encoder.py:55-61, act 2), input_proj
  * (:138-140, act 1) and the class head (:153-155, act 1).  A [M,hid] receives the activation, H [M,hid] the GELU
  * pre-activation (NULL for ReLU); both are what the backward pass needs (u3d_linear_dact, u3d_gemm_tn). */
@@ -321,6 +330,21 @@ int u3d_nms_rotated(const float* boxes, const int32_t* labels, int n, float iou_
  * (+inf / -inf when none, as in the reference); centre = (max+min)/2 and size = max-min are left to the caller. */
 int u3d_trim_boxes(const float* points, int64_t pt_ld, const int32_t* sp_list, const int32_t* sp_offsets, int S,
                    const float* boxes, int nb, int box_dim, float low_thr, float up_thr, float* minmax, u3d_stream_t stream);
+
+/* =====================================================================================
+ * R12  matcher + losses of a single-dataset batch on the device: forward value AND gradients in five launches
+ *      (unidet3d/criterion.py:44-178, :200-320; unidet3d/axis_aligned_iou_loss.py:14-53; yaw-free boxes).
+ *  cls [L][n_tot][C1], box [L][n_tot][6] (centre, size): outputs of the L decoder heads, scenes packed; cu int32 [B+1] first
+ *  query of a scene; gt_off int32 [B+1] first GT of a scene; gt_labels int64 [G]; gt_boxes [G][6]; qmask uint8: scene b's
+ *  [g_b][n_b] query mask at qm_off[b] (int64 [B+1] = prefix sums of n_b g_b, P = qm_off[B]); max_gt = max g_b (<= 64);
+ *  min_queries_with_gt = min n_b over scenes with g_b > 0 (must be >= topk + 1, as torch.topk requires in the reference).
+ *  loss [1] = sum over layers of lw_cls * mean_b(ds_w * CE_b) + lw_box * mean over scenes with matches (ds_w * DIoU_b);
+ *  dcls / dbox receive d loss / d cls, d loss / d box.  ws: u3d_criterion_ws_bytes. */
+int u3d_criterion_packed(const float* cls, const float* box, const int32_t* cu, const int32_t* gt_off, const int64_t* gt_labels,
+                         const float* gt_boxes, const uint8_t* qmask, const int64_t* qm_off, int L, int B, int64_t n_tot, int C1, int64_t G,
+                         int64_t P, int max_gt, int min_queries_with_gt, int topk, float w_cls, float w_box, float non_obj_w, float ds_w,
+                         float lw_cls, float lw_box, float* loss, float* dcls, float* dbox, void* ws, u3d_stream_t stream);
+int64_t u3d_criterion_ws_bytes(int L, int B, int64_t n_tot, int64_t G, int64_t P);
 
 #ifdef __cplusplus
 }

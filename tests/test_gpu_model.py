@@ -300,3 +300,26 @@ def test_train_step_and_val_step_drive_the_model_like_a_runner():
         res = model.val_step([batch[0]])
     pred = res[0].pred_instances_3d
     assert pred.bboxes_3d.tensor.shape[1] == 6 and len(pred.scores_3d) == len(pred.labels_3d) == len(pred.bboxes_3d)
+
+
+# ---------------------------------------------------------------------------- u3d_ln_linear / u3d_gemm_nt_add
+@pytest.mark.parametrize('M,N', [(2500, 8), (16001, 8), (333, 256), (1, 8)])
+def test_ln_linear_fwd_bwd(M, N):
+    """(nq, y) = (LayerNorm(x), nq W^T + b) with BOTH outputs consumed downstream (the decoder head): values and all gradients
+    against torch in float64; the two gradient contributions of nq meet in one GEMM epilogue."""
+    from unidet3d_amd.dense import ln_linear
+    C = 256
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, C, generator=g) * 2 + 0.3; gm = torch.rand(C, generator=g) + 0.5; bt = torch.randn(C, generator=g) * 0.1
+    w = torch.randn(N, C, generator=g) * 0.1; b = torch.randn(N, generator=g)
+    go_nq = torch.randn(M, C, generator=g); go_y = torch.randn(M, N, generator=g)
+    ref = [t.clone().double().requires_grad_() for t in (x, gm, bt, w, b)]
+    nq_o = torch.nn.functional.layer_norm(ref[0], (C,), ref[1], ref[2], 1e-5)
+    y_o = torch.nn.functional.linear(nq_o, ref[3], ref[4])
+    ((nq_o * go_nq.double()).sum() + (y_o * go_y.double()).sum()).backward()
+    dev = [t.clone().to(DEV).requires_grad_() for t in (x, gm, bt, w, b)]
+    nq, y = ln_linear(dev[0], dev[1], dev[2], 1e-5, dev[3], dev[4])
+    ((nq * go_nq.to(DEV)).sum() + (y * go_y.to(DEV)).sum()).backward()
+    assert _rel(nq, nq_o) < 1e-5 and _rel(y, y_o) < 1e-5
+    for name, d, r in zip(('x', 'gamma', 'beta', 'w', 'b'), dev, ref):
+        assert _rel(d.grad, r.grad) < 3e-5, name

@@ -15,11 +15,57 @@ DEV = 'cuda:0'
 C, D, T = R.C, R.D, R.T
 
 
-@pytest.mark.parametrize('tag,packed', [('C1', False), ('C1', True), ('C2', False), ('C3', False), ('C3', True)])
-def test_criterion_on_device_matches_reference(tag, packed):
-    worst = R.check_product_criterion(tag, DEV, packed)
+@pytest.mark.parametrize('tag,packed,fused', [('C1', False, False), ('C1', True, False), ('C1', True, True), ('C2', False, False), ('C3', False, False),
+                                              ('C3', True, False), ('C3', True, True)])
+def test_criterion_on_device_matches_reference(tag, packed, fused):
+    """per-scene loop, batched tensor ops and the fused kernel (csrc/criterion.hip) against the reference's values"""
+    worst = R.check_product_criterion(tag, DEV, packed, fused)
     import _parity as PA
-    PA.log_errors(f'criterion_golden_{tag}_{"packed" if packed else "loop"}', dict(grad_rel=worst))
+    PA.log_errors(f'criterion_golden_{tag}_{"fused" if fused else ("packed" if packed else "loop")}', dict(grad_rel=worst))
+
+
+@pytest.mark.parametrize('B,n_lo,n_hi,g_max,L', [(8, 1500, 2300, 12, 7), (3, 7, 40, 64, 2), (2, 3000, 3000, 1, 3)])
+def test_fused_criterion_matches_tensor_op_path_at_bench_sizes(B, n_lo, n_hi, g_max, L):
+    """csrc/criterion.hip vs the batched tensor-op formulation of the same arithmetic on random head outputs: loss and gradients
+    (the matcher's discrete choices must coincide -- any difference shows up as an O(1e-3) loss change)."""
+    from unidet3d_amd.structures import DepthInstance3DBoxes, InstanceData_
+    from unidet3d_amd.registry import MODELS
+    g = torch.Generator().manual_seed(B * 100 + L)
+    sizes = [int(torch.randint(n_lo, n_hi + 1, (1,), generator=g)) for _ in range(B)]
+    gts = [int(torch.randint(0, g_max + 1, (1,), generator=g)) for _ in range(B)]
+    gts[0] = g_max
+    if B > 2:
+        gts[1] = 0                                                         # a scene without ground truth
+    insts, cls, box = [], [[] for _ in range(L)], [[] for _ in range(L)]
+    for n, k in zip(sizes, gts):
+        gtb = torch.cat((torch.rand(k, 3, generator=g) * 3, torch.rand(k, 3, generator=g) + 0.2), 1)
+        qm = torch.rand(k, n, generator=g) < 0.3
+        if k:
+            qm[0, 3:] = False                                              # a GT with fewer allowed queries than topk + 1
+        insts.append(InstanceData_(labels_3d=torch.randint(0, 18, (k,), generator=g).to(DEV), query_masks=qm.to(DEV),
+                                   bboxes_3d=DepthInstance3DBoxes(gtb, with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5)).to(DEV)))
+        for l in range(L):
+            cls[l].append(torch.randn(n, 19, generator=g) * 1.5)
+            b = torch.cat((torch.rand(n, 3, generator=g) * 3, torch.rand(n, 3, generator=g) + 0.2), 1)
+            if k:
+                near = gtb[torch.randint(0, k, (n,), generator=g)] + torch.randn(n, 6, generator=g) * 0.08
+                near[:, 3:] = near[:, 3:].abs() + 0.05
+                b = torch.where((torch.rand(n, generator=g) < 0.5)[:, None], near, b)
+            box[l].append(b)
+    res = {}
+    for fused in (True, False):
+        pc_ = [torch.cat(c).to(DEV).requires_grad_() for c in cls]
+        pb_ = [torch.cat(b).to(DEV).requires_grad_() for b in box]
+        pred = dict(cls_preds=list(pc_[0].split(sizes)), bboxes=list(pb_[0].split(sizes)), aux_outputs=[None] * (L - 1),
+                    _packed=dict(cls=pc_, box=pb_, sizes=sizes))
+        crit = MODELS.build(R.SCANNET_CRIT)
+        crit.fused = fused
+        loss = crit(pred, insts, ['scannet'] * B)['det_loss']
+        (loss * 1.7).backward()
+        res[fused] = (loss.detach(), [t.grad for t in pc_], [t.grad for t in pb_])
+    assert abs(float(res[True][0]) - float(res[False][0])) < 2e-6 * abs(float(res[False][0])), (res[True][0], res[False][0])
+    for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+        assert R.rel(a, b) < 2e-5
 
 
 def test_rotated_diou_values_and_gradients_on_device():

@@ -68,9 +68,13 @@ PROTOTYPES = {
     'u3d_segment_gather_sum': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     'u3d_segment_mean_xyz': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     'u3d_segment_minmax_xyz': (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    'u3d_criterion_packed': (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_criterion_ws_bytes': (_i64, [_i32, _i32, _i64, _i64, _i64]),
     'u3d_gemm_nt': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
     'u3d_linear_act': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
     'u3d_linear_dact': (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _vp]),
+    'u3d_gemm_nt_add': (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _vp]),
+    'u3d_ln_linear': (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
     'u3d_ffn_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp]),
     'u3d_gelu_fwd': (_i32, [_vp, _vp, _i64, _vp]),
     'u3d_gelu_bwd': (_i32, [_vp, _vp, _vp, _i64, _vp]),

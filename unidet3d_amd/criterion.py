@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib as L
 from ._lib import h2d as _h2d
 from .registry import MODELS, TASK_UTILS
 from .structures import InstanceData_
@@ -214,6 +215,29 @@ class UniMatcher:
         return ids[:, 0], ids[:, 1]
 
 
+class _FusedCriterionFn(torch.autograd.Function):
+    """include/u3d.h u3d_criterion_packed: the loss AND its gradients w.r.t. the stacked head outputs in five launches."""
+
+    @staticmethod
+    def forward(ctx, cls, box, g, consts):
+        cls, box = cls.contiguous(), box.contiguous()
+        Ln, n_tot, C1 = cls.shape
+        dev = cls.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dcls, dbox = torch.empty_like(cls), torch.empty_like(box)
+        ws = L.scratch(L.lib().u3d_criterion_ws_bytes(Ln, g['B'], n_tot, g['G'], g['P']), dev)
+        L.call('u3d_criterion_packed', L.ptr(cls), L.ptr(box), L.ptr(g['cu']), L.ptr(g['gt_off']), L.ptr(g['labels']), L.ptr(g['boxes']),
+               L.ptr(g['qmask']), L.ptr(g['qm_off']), Ln, g['B'], n_tot, C1, g['G'], g['P'], g['max_gt'], g['min_q'], *consts,
+               L.ptr(loss), L.ptr(dcls), L.ptr(dbox), L.ptr(ws), L.stream())
+        ctx.save_for_backward(dcls, dbox)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        dcls, dbox = ctx.saved_tensors
+        return dcls * go, dbox * go, None, None
+
+
 def _gt_boxes(b):
     return torch.cat((b.gravity_center, b.tensor[:, 3:] if b.with_yaw else b.tensor[:, 3:6]), dim=1)
 
@@ -354,9 +378,49 @@ class UniDet3DCriterion:
         bbox_loss = (per_scene * has).sum(1) / has.sum(1).clamp(min=1)             # [L]
         return (self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss).sum()
 
+    # ---- fused device path (csrc/criterion.hip) ---------------------------------------------------
+    def _flat_gt(self, insts, sizes, device, topk):
+        """Ragged GT of the batch as flat device arrays for u3d_criterion_packed; None when the kernel's limits do not hold
+        (> 64 GTs in a scene, or a scene with GT but fewer than topk + 1 queries -- left to the tensor-op path)."""
+        gs = [len(i) for i in insts]
+        if max(gs, default=0) > 64 or any(g and n < topk + 1 for g, n in zip(gs, sizes)):
+            return None
+        cu, go, qo = [0], [0], [0]
+        for n, g in zip(sizes, gs):
+            cu.append(cu[-1] + n); go.append(go[-1] + g); qo.append(qo[-1] + n * g)
+        with_gt = [i for i in insts if len(i)]
+        labels = torch.cat([i.labels_3d for i in with_gt]) if with_gt else None
+        boxes = torch.cat([_gt_boxes(i.bboxes_3d) for i in with_gt]).float().contiguous() if with_gt else None
+        qmask = torch.cat([i.query_masks.reshape(-1) for i in with_gt]).contiguous().view(torch.uint8) if with_gt else None
+        return dict(B=len(insts), G=go[-1], P=qo[-1], max_gt=max(gs, default=0), min_q=min([n for g, n in zip(gs, sizes) if g], default=0),
+                    cu=_h2d(cu, torch.int32, device), gt_off=_h2d(go, torch.int32, device), qm_off=_h2d(qo, torch.int64, device),
+                    labels=labels, boxes=boxes, qmask=qmask)
+
+    def _loss_fused(self, pk, insts, name):
+        idx = self.datasets.index(name)
+        cls, box = torch.stack(pk['cls']), torch.stack(pk['box'])
+        g = self._flat_gt(insts, pk['sizes'], cls.device, self.topk[idx])
+        if g is None:
+            return None
+        consts = (int(self.topk[idx]), float(self.matcher.costs[0].weight), float(self.matcher.costs[1].weight),
+                  float(self.non_object_weight), float(self.datasets_weights[idx]), float(self.loss_weight[0]), float(self.loss_weight[1]))
+        return _FusedCriterionFn.apply(cls, box, g, consts)
+
+    def _fusable(self):
+        c = self.matcher.costs[1]
+        return (isinstance(c.loss_simple, UniDet3DAxisAlignedIoULoss) and c.loss_simple.mode == 'diou' and c.loss_simple.loss_weight == 1.0 and
+                isinstance(self.bbox_loss_simple, UniDet3DAxisAlignedIoULoss) and self.bbox_loss_simple.mode == 'diou' and
+                self.bbox_loss_simple.loss_weight == 1.0 and self.bbox_loss_simple.reduction == 'none')
+
+    fused = True        # device kernel for single-dataset yaw-free batches; False forces the tensor-op formulation (tests)
+
     def __call__(self, pred, insts, datasets_names):
         if self._can_pack(pred, insts, datasets_names):
             pk = pred['_packed']
+            if self.fused and pk['cls'][0].is_cuda and self._fusable():
+                loss = self._loss_fused(pk, insts, datasets_names[0])
+                if loss is not None:
+                    return {'det_loss': loss}
             gt = self._pack_gt(insts, pk['sizes'], pk['cls'][0].device)
             # final layer + the aux layers, each re-matched (iter_matcher), in one batched pass
             return {'det_loss': self._loss_packed(torch.stack(pk['cls']), torch.stack(pk['box']), gt, datasets_names[0])}

@@ -37,6 +37,7 @@ constexpr int GLD = GK + 4;    // padded LDS row of the NT tiles
 //   2  pre = acc + bias, C = gelu(pre)                  Linear + GELU (erf form, torch's default); pre is kept for backward
 //   3  C = aux > 0 ? acc : 0                            input gradient through ReLU   (aux = the ReLU output)
 //   4  C = acc * gelu'(aux)                             input gradient through GELU   (aux = the pre-activation)
+//   5  C = acc + aux                                    a second gradient contribution added in place of a separate add kernel
 // erf GELU with ONE exponential per element: erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2
 // (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 -- below fp32 resolution of the products it enters), and exp(-z^2) =
 // exp(-x^2 / 2) is also the Gaussian of the derivative.  libm's erff costs ~3x the VALU instructions, and VALU time in a
@@ -79,9 +80,9 @@ __device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[2][TN / 64], flo
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rs_x, vc, row * N * 4, 0);
                     v = gelu_f(v);
                 }
-                if constexpr (EPI == 3 || EPI == 4) {       // rows / columns outside the tile read as 0 through the descriptor
+                if constexpr (EPI == 3 || EPI == 4 || EPI == 5) {       // rows / columns outside the tile read as 0 through the descriptor
                     const float x = __builtin_bit_cast(float, bload32(rs_x, vc, row * N * 4));
-                    v = EPI == 3 ? (x > 0.f ? v : 0.f) : v * gelu_grad_f(x);
+                    v = EPI == 3 ? (x > 0.f ? v : 0.f) : (EPI == 4 ? v * gelu_grad_f(x) : v + x);
                 }
                 asm volatile("" : "+v"(v));          // see gemm_tn_k: keeps the store builtin from mis-selecting the vector element
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, vc, row * N * 4, 0);
@@ -525,7 +526,7 @@ static int gemm_nt_epi(const float* A, const float* W, const float* bias, float*
                        float* pre, double flops_hint, hipStream_t s) {
     const bool bf = (epi & 8) != 0;
     epi &= 7;
-    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 4 || (epi == 2 && !pre) || (epi >= 3 && !aux)) return U3D_EINVAL;
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 5 || (epi == 2 && !pre) || (epi >= 3 && !aux)) return U3D_EINVAL;
     if (K % (bf ? GKH : GK)) { set_error("gemm_nt: K=%d must be a multiple of %d", K, bf ? GKH : GK); return U3D_EUNSUPPORTED; }
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
     if ((int64_t)GT * K * 4 >= 0x7fffffffLL || (int64_t)GT * N * 4 >= 0x7fffffffLL) { set_error("gemm_nt: N=%d / K=%d too large for 32-bit tile offsets", N, K); return U3D_EUNSUPPORTED; }
@@ -534,7 +535,8 @@ static int gemm_nt_epi(const float* A, const float* W, const float* bias, float*
         case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
         case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
         case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
-        default: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
+        case 4: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
+        default: launch_nt<5>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
     }
     return check_launch("gemm_nt");
 }
@@ -566,6 +568,20 @@ int u3d_linear_dact(const float* dY, const float* Wt, const float* aux, int act,
     act &= ~U3D_BF16_OPERANDS;
     if (act < 0 || act > 2) return U3D_EINVAL;
     return gemm_nt_epi(dY, Wt, nullptr, dX, M, N, K, (act == 0 ? 0 : act + 2) | bf, aux, nullptr, flops_hint, (hipStream_t)stream);
+}
+
+int u3d_gemm_nt_add(const float* A, const float* W, const float* addend, int flags, float* C, int64_t M, int N, int K, double flops_hint,
+                    u3d_stream_t stream) {
+    return gemm_nt_epi(A, W, nullptr, C, M, N, K, 5 | ((flags & U3D_BF16_OPERANDS) ? 8 : 0), addend, nullptr, flops_hint, (hipStream_t)stream);
+}
+
+int u3d_ln_linear(const float* X, const float* RES, const float* gamma, const float* beta, float eps, float* SUM, float* NQ, float* STATS,
+                  const float* W, const float* bias, int act, float* PRE, float* Y, int64_t M, int C, int N, double flops_hint,
+                  u3d_stream_t stream) {
+    if (!NQ || !Y || !W) return U3D_EINVAL;
+    int rc = u3d_layer_norm_fwd(X, RES, gamma, beta, M, C, eps, SUM, NQ, STATS, stream);
+    if (rc || M == 0) return rc;
+    return u3d_linear_act(NQ, W, bias, act, PRE, Y, M, N, C, flops_hint, stream);
 }
 
 int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, int act, float* H, float* A, float* Z,

@@ -238,6 +238,70 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     return _LayerNormFn.apply(x, res, weight, bias, eps)
 
 
+class _LNLinearFn(torch.autograd.Function):
+    """(nq, y) = (LayerNorm(x), nq W^T + b)  -- include/u3d.h u3d_ln_linear.  Backward folds the two gradient contributions of
+    ``nq`` (its own consumers + this Linear) into the GEMM that produces the second (u3d_gemm_nt_add), then runs the
+    LayerNorm backward once."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, weight, bias):
+        x = x.contiguous()
+        M, C = x.shape
+        N = weight.shape[0]
+        dev = x.device
+        nq = torch.empty_like(x)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=dev)
+        y = torch.empty(M, N, dtype=torch.float32, device=dev)
+        w = weight.contiguous()
+        ctx.bf = P.bf16() and C % 32 == 0
+        if M:
+            L.call('u3d_ln_linear', L.ptr(x), None, L.ptr(gamma), L.ptr(beta), float(eps), None, L.ptr(nq), L.ptr(stats), L.ptr(w),
+                   L.ptr(bias), P.BF16_FLAG if ctx.bf else 0, None, L.ptr(y), M, C, N, _flops(M, N, C), L.stream())
+        ctx.save_for_backward(x, gamma, stats, nq, w)
+        ctx.has_bias = bias is not None
+        return nq, y
+
+    @staticmethod
+    def backward(ctx, dnq, dy):
+        x, gamma, stats, nq, w = ctx.saved_tensors
+        M, C = x.shape
+        N = w.shape[0]
+        dev = x.device
+        dw = db = None
+        if dy is not None:
+            dy = dy.contiguous()
+            dw, db = _weight_grad(dy, nq, ctx.has_bias, ctx.bf)
+            if dnq is None:
+                dtot = _input_grad(dy, w, bf=ctx.bf)
+            else:                                        # dtot = dy W + dnq in one GEMM
+                q = 32 if ctx.bf else 16
+                Np = (N + q - 1) // q * q
+                wt = torch.zeros(C, Np, dtype=torch.float32, device=dev)
+                wt[:, :N] = w.t()
+                dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
+                dtot = torch.empty(M, C, dtype=torch.float32, device=dev)
+                if M:
+                    L.call('u3d_gemm_nt_add', L.ptr(dyp), L.ptr(wt), L.ptr(dnq.contiguous()), P.BF16_FLAG if ctx.bf else 0, L.ptr(dtot),
+                           M, C, Np, _flops(M, C, Np, extra_mn=1), L.stream())
+        else:
+            dtot = dnq.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        if M:
+            ws = L.scratch(L.lib().u3d_layer_norm_ws_bytes(M, C), dev)
+            L.call('u3d_layer_norm_bwd', L.ptr(x), L.ptr(dtot), L.ptr(gamma), L.ptr(stats), M, C, L.ptr(dx), L.ptr(dg), L.ptr(dbeta),
+                   L.ptr(ws), L.stream())
+        else:
+            dg.zero_(); dbeta.zero_()
+        return dx, dg, dbeta, None, dw, db
+
+
+def ln_linear(x, gamma, beta, eps, weight, bias):
+    """-> (LayerNorm(x), LayerNorm(x) W^T + b) for 2-D x [M, C]."""
+    return _LNLinearFn.apply(x, gamma, beta, eps, weight, bias)
+
+
 class LayerNorm(torch.nn.LayerNorm):
     """``nn.LayerNorm(d_model)`` of the reference (same parameters / state_dict keys) on the HIP kernels, optionally fused with the
     residual add in front of it."""

@@ -24,7 +24,7 @@ from torch import nn
 from . import _lib as L
 from . import precision as P
 from . import account
-from .dense import LayerNorm, linear, mlp
+from .dense import LayerNorm, linear, ln_linear, mlp
 from .registry import MODELS
 
 
@@ -126,9 +126,12 @@ class PredBBox(nn.Module):                    # encoder.py:82-111
         if bbox_init_normal:
             nn.init.normal_(self.linear.weight, std=.01)
 
-    def forward(self, x):
-        x = linear(x, self.linear.weight, self.linear.bias)
+    @staticmethod
+    def decode(x):                                # encoder.py:108-111
         return torch.hstack((torch.exp(x[:, :6]), x[:, 6:]))
+
+    def forward(self, x):
+        return self.decode(linear(x, self.linear.weight, self.linear.bias))
 
 
 def _bbox_pred_to_bbox(points, bbox_pred):    # encoder.py:241-283
@@ -175,8 +178,10 @@ class UniDet3DEncoder(nn.Module):
         """Packed head: one LayerNorm / class MLP / box Linear over all scenes (encoder.py:165-201).
         With a single dataset in the batch the class-column select and the box decode also run once
         on the packed matrix and the per-scene outputs are views of it."""
-        nq = self.out_norm(feats)
-        box_all = self.out_bboxes(nq)
+        # out_norm -> out_bboxes.linear as one op (u3d_ln_linear); nq also feeds the class MLP
+        nq, box_raw = ln_linear(feats, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, self.out_bboxes.linear.weight,
+                                self.out_bboxes.linear.bias)
+        box_all = self.out_bboxes.decode(box_raw)
         w1, b1, w2, b2 = self.outs_cls[0].weight, self.outs_cls[0].bias, self.outs_cls[2].weight, self.outs_cls[2].bias
         if len(set(datasets_names)) == 1:
             # the dataset's class columns (encoder.py:192-194) are selected as ROWS of the [n_cls, d] output weight: the packed

@@ -100,7 +100,45 @@ __global__ __launch_bounds__(256) void bn_sum_partials_k(const double* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0 && set_rows) sums[C2] = rows;
 }
 
-__global__ void bn_copy_count_k(const double* __restrict__ from, double* __restrict__ to, int i) { to[i] = from[i]; }
+// bn_sum_partials_k for the two statistics of channel c + bn_finalize_k of that channel in one launch (one wave per channel)
+__global__ __launch_bounds__(256) void bn_sum_finalize_k(const double* __restrict__ partial, int nblk, int C, double rows, double* __restrict__ sums,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                         float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                                         float* shift, int64_t* num_batches_tracked) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sums[2 * C] = rows;
+        if (num_batches_tracked) *num_batches_tracked += 1;
+    }
+    if (c >= C) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        t1 += partial[(int64_t)b * 2 * C + c];
+        t2 += partial[(int64_t)b * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { t1 += __shfl_xor(t1, d, 64); t2 += __shfl_xor(t2, d, 64); }
+    if (lane) return;
+    sums[c] = t1;
+    sums[C + c] = t2;
+    const double m = t1 / rows;
+    double var = t2 / rows - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float mf = (float)m;
+    mean[c] = mf;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mf * sc;
+    if (running_mean) {
+        const double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 
 __global__ void bn_finalize_k(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float eps, float momentum, float* running_mean,
@@ -144,9 +182,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                       const double* __restrict__ sums, double inv_count, int64_t n4, int C,
-                                                      float* dx, float* dgamma, float* dbeta) {
+                                                      float* dx, float* dgamma, float* dbeta, const double* __restrict__ count_src) {
     const int C4 = C >> 2;
-    if (!(inv_count > 0.0)) inv_count = 1.0 / sums[2 * C];
+    if (!(inv_count > 0.0)) inv_count = 1.0 / (count_src ? count_src[0] : sums[2 * C]);
     if (blockIdx.x == 0 && dgamma) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             dbeta[c] = (float)sums[c];
@@ -250,18 +288,26 @@ int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const f
     ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
     const int64_t n4 = n * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, sums,
-                       1.0 / count, n4, C, dx, dgamma, dbeta);
+                       1.0 / count, n4, C, dx, dgamma, dbeta, (const double*)nullptr);
     return check_launch("bn_bwd_apply");
 }
 
 int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st, double* sums,
                    void* ws, u3d_stream_t stream) {
-    int rc = u3d_bn_stats(x, n, C, sums, ws, stream);
-    if (rc) return rc;
-    rc = u3d_bn_finalize(sums, -1.0, gamma, beta, eps, momentum, running_mean, running_var, C, st, st + C, st + 2 * C,
-                         st + 3 * C, num_batches_tracked, stream);
-    if (rc) return rc;
+    // statistics (per-block partials) -> one launch that sums the partials of a channel AND finalises it -> apply
+    if (!x || !sums || !ws || !gamma || !beta || !st || !y || !bn_ok(n, C)) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
+        const int g = bn_grid(n, C);
+        hipLaunchKernelGGL(bn_reduce_k<0>, dim3(g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws);
+        hipLaunchKernelGGL(bn_sum_finalize_k, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)ws, g, C, (double)n, sums, gamma, beta, eps,
+                           momentum, running_mean, running_var, st, st + C, st + 2 * C, st + 3 * C, num_batches_tracked);
+        int rc = check_launch("bn_forward");
+        if (rc) return rc;
+    }
     return u3d_bn_apply(x, st + 2 * C, st + 3 * C, relu, n, C, y, stream);
 }
 
@@ -271,8 +317,13 @@ int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, 
     if (!fwd_sums) return U3D_EINVAL;
     int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_copy_count_k, dim3(1), dim3(1), 0, (hipStream_t)stream, fwd_sums, sums, 2 * C);
-    return u3d_bn_bwd_apply(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, sums, -1.0, n, C, dx, dgamma, dbeta, stream);
+    if (!dx) return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;       // the row count is read from the forward pass's vector (no copy launch)
+    ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
+    const int64_t n4 = n * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, (const float*)st, (const float*)(st + C), (const float*)(st + 2 * C),
+                       (const float*)(st + 3 * C), relu, (const double*)sums, -1.0, n4, C, dx, dgamma, dbeta, fwd_sums + 2 * C);
+    return check_launch("bn_backward");
 }
 
 }  // extern "C"

@@ -135,6 +135,10 @@ int u3d_spconv_gmm_bf16(const float* src, int64_t n_src, const void* w_rows_bf16
                         const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
                         int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream);
 int u3d_weight_pack_bf16(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream);
+/* all packs of a model in one launch: desc = device array of n_desc records of eight int64
+ * {src pointer, dst pointer, Cd, K, Cs, transposed, bf16 (0/1), first block}; record i owns blocks [first_i, first_{i+1}) of 256
+ * threads, one 16-byte output vector per thread (Cd*K*Cs/4 vectors in fp32 form, Cd*K*Cs/8 in bf16 form). */
+int u3d_weight_pack_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream);
 /* Launch plan for a shape: tile_rows (rows per wave-tile = the tile height to pass to u3d_tile_starts) and
  * k_groups (kernel offsets are split into that many groups when the level has too few rows to fill the chip;
  * the groups' partial sums go through ws = k_groups*n_dst*Cd*4 bytes and a fixed-order reduce).
@@ -345,6 +349,11 @@ int u3d_criterion_packed(const float* cls, const float* box, const int32_t* cu, 
                          int64_t P, int max_gt, int min_queries_with_gt, int topk, float w_cls, float w_box, float non_obj_w, float ds_w,
                          float lw_cls, float lw_box, float* loss, float* dcls, float* dbox, void* ws, u3d_stream_t stream);
 int64_t u3d_criterion_ws_bytes(int L, int B, int64_t n_tot, int64_t G, int64_t P);
+/* box decode of a yaw-free head in one pass each way: PredBBox's exp of the six face distances + _bbox_pred_to_bbox
+ * (unidet3d/encoder.py:99-111, :241-271): raw [M][8] (Linear output), centers [M][3] -> box [M][6] (centre, size);
+ * backward: draw [M][8] from dbox [M][6] (the angle columns receive 0). */
+int u3d_box_decode_fwd(const float* raw, const float* centers, int64_t M, float* box, u3d_stream_t stream);
+int u3d_box_decode_bwd(const float* raw, const float* dbox, int64_t M, float* draw, u3d_stream_t stream);
 
 #ifdef __cplusplus
 }

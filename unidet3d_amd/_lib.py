@@ -39,6 +39,7 @@ PROTOTYPES = {
     'u3d_tile_starts': (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp]),
     'u3d_spconv_gmm': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _f64, _vp]),
     'u3d_spconv_gmm_bf16': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _f64, _vp]),
+    'u3d_weight_pack_batch': (_i32, [_vp, _i32, _i64, _vp]),
     'u3d_weight_pack_bf16': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_spconv_plan': (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
     'u3d_spconv_wgrad': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
@@ -69,6 +70,8 @@ PROTOTYPES = {
     'u3d_segment_mean_xyz': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     'u3d_segment_minmax_xyz': (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     'u3d_criterion_packed': (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_box_decode_fwd': (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    'u3d_box_decode_bwd': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'u3d_criterion_ws_bytes': (_i64, [_i32, _i32, _i64, _i64, _i64]),
     'u3d_gemm_nt': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
     'u3d_linear_act': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),

@@ -273,11 +273,56 @@ __global__ __launch_bounds__(256) void crit_grad_k(CritParams p) {
     for (int a = 0; a < 3; ++a) { db[a] = gc[a]; db[3 + a] = gs[a]; }
 }
 
+// ---- box decode of a yaw-free head: PredBBox's exp + _bbox_pred_to_bbox (unidet3d/encoder.py:99-111, :241-271) in one pass ----
+// raw [M][8] (Linear output; the two angle columns are unused here), centres [M][3] -> box [M][6]:
+//   e_i = exp(raw_i), i < 6;  centre_a = c_a + (e_{2a+1} - e_{2a}) / 2;  size_a = e_{2a} + e_{2a+1}
+__global__ __launch_bounds__(256) void box_decode_fwd_k(const float* __restrict__ raw, const float* __restrict__ cen, int64_t M, float* __restrict__ box) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float4 r0 = reinterpret_cast<const float4*>(raw + i * 8)[0], r1 = reinterpret_cast<const float4*>(raw + i * 8)[1];
+    const float e[6] = {expf(r0.x), expf(r0.y), expf(r0.z), expf(r0.w), expf(r1.x), expf(r1.y)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        box[i * 6 + a] = cen[i * 3 + a] + (e[2 * a + 1] - e[2 * a]) / 2;
+        box[i * 6 + 3 + a] = e[2 * a] + e[2 * a + 1];
+    }
+}
+__global__ __launch_bounds__(256) void box_decode_bwd_k(const float* __restrict__ raw, const float* __restrict__ dbox, int64_t M, float* __restrict__ draw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float4 r0 = reinterpret_cast<const float4*>(raw + i * 8)[0], r1 = reinterpret_cast<const float4*>(raw + i * 8)[1];
+    const float e[6] = {expf(r0.x), expf(r0.y), expf(r0.z), expf(r0.w), expf(r1.x), expf(r1.y)};
+    float g[8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float dc = dbox[i * 6 + a], ds = dbox[i * 6 + 3 + a];
+        g[2 * a] = e[2 * a] * (ds - dc / 2);
+        g[2 * a + 1] = e[2 * a + 1] * (ds + dc / 2);
+    }
+    g[6] = 0.f; g[7] = 0.f;
+    reinterpret_cast<float4*>(draw + i * 8)[0] = make_float4(g[0], g[1], g[2], g[3]);
+    reinterpret_cast<float4*>(draw + i * 8)[1] = make_float4(g[4], g[5], g[6], g[7]);
+}
+
 }  // namespace u3d
 
 using namespace u3d;
 
 extern "C" {
+
+int u3d_box_decode_fwd(const float* raw, const float* centers, int64_t M, float* box, u3d_stream_t stream) {
+    if (!raw || !centers || !box || M < 0) return U3D_EINVAL;
+    if (M == 0) return U3D_OK;
+    hipLaunchKernelGGL(box_decode_fwd_k, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, raw, centers, M, box);
+    return check_launch("box_decode_fwd");
+}
+
+int u3d_box_decode_bwd(const float* raw, const float* dbox, int64_t M, float* draw, u3d_stream_t stream) {
+    if (!raw || !dbox || !draw || M < 0) return U3D_EINVAL;
+    if (M == 0) return U3D_OK;
+    hipLaunchKernelGGL(box_decode_bwd_k, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, raw, dbox, M, draw);
+    return check_launch("box_decode_bwd");
+}
 
 static inline int64_t al64(int64_t x) { return (x + 63) & ~(int64_t)63; }
 

@@ -665,6 +665,54 @@ __global__ __launch_bounds__(256) void weight_pack_bf16_k(const float* __restric
     wp[idx] = v;
 }
 
+// every convolution weight of the model, both orientations, in ONE launch (the weights change once per optimizer step; 89 single
+// packs cost 0.38 ms of launch latency per step).  desc[i] = {src, dst, Cd, K, Cs, transposed, bf16, first block}: block b belongs
+// to the last descriptor whose first block is <= b.
+struct PackDesc { const float* src; void* dst; int64_t Cd, K, Cs, transposed, bf, block0; };
+__global__ __launch_bounds__(256) void weight_pack_batch_k(const PackDesc* __restrict__ desc, int n_desc) {
+    int lo = 0, hi = n_desc;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[mid].block0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const PackDesc d = desc[lo];
+    const int64_t idx = ((int64_t)blockIdx.x - d.block0) * 256 + threadIdx.x;
+    const int Cd = (int)d.Cd, K = (int)d.K, Cs = (int)d.Cs;
+    const int lane = (int)(idx & 63);
+    int64_t t = idx >> 6;
+    const int nb = (int)(t & 1); t >>= 1;
+    if (d.bf) {
+        const int cs32 = Cs / 32;
+        if (idx >= (int64_t)(Cd / 32) * K * cs32 * 2 * 64) return;
+        const int jj = (int)(t % cs32); t /= cs32;
+        const int k = (int)(t % K), slice = (int)(t / K);
+        const int n = slice * 32 + nb * 16 + (lane & 15), q = lane >> 4;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (2 * jj + (e >> 2)) * 16 + q * 4 + (e & 3);
+            v[e] = (__bf16)(d.transposed ? d.src[((int64_t)c * K + k) * Cd + n] : d.src[((int64_t)n * K + k) * Cs + c]);
+        }
+        reinterpret_cast<bf16x8*>(d.dst)[idx] = v;
+    } else {
+        const int cs16 = Cs / 16;
+        if (idx >= (int64_t)(Cd / 32) * K * cs16 * 2 * 64) return;
+        const int j = (int)(t % cs16); t /= cs16;
+        const int k = (int)(t % K), slice = (int)(t / K);
+        const int n = slice * 32 + nb * 16 + (lane & 15), c = j * 16 + (lane >> 4) * 4;
+        float4 v;
+        if (!d.transposed) {
+            v = *reinterpret_cast<const float4*>(d.src + ((int64_t)n * K + k) * Cs + c);
+        } else {
+            v.x = d.src[((int64_t)(c + 0) * K + k) * Cd + n];
+            v.y = d.src[((int64_t)(c + 1) * K + k) * Cd + n];
+            v.z = d.src[((int64_t)(c + 2) * K + k) * Cd + n];
+            v.w = d.src[((int64_t)(c + 3) * K + k) * Cd + n];
+        }
+        reinterpret_cast<float4*>(d.dst)[idx] = v;
+    }
+}
+
 __global__ void weight_transpose_k(const float* __restrict__ w, float* __restrict__ wt, int Cd, int K, int Cs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)Cd * K * Cs;
@@ -808,6 +856,12 @@ int u3d_spconv_wgrad_bf16(const float* x, int64_t n_rows_x, const float* dy, con
                           const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
                           float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
     return spconv_wgrad_impl(x, n_rows_x, dy, rows_x, rows_dy, tile_starts, K, cap, n_rows_dy, tile_rows, Cs, Cd, dW, ws, flops_hint, stream, true);
+}
+
+int u3d_weight_pack_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream) {
+    if (!desc || n_desc <= 0 || total_blocks <= 0 || total_blocks >= 0x7fffffffLL) return U3D_EINVAL;
+    hipLaunchKernelGGL(weight_pack_batch_k, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)desc, n_desc);
+    return check_launch("weight_pack_batch");
 }
 
 int u3d_weight_pack(const float* w, float* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {

@@ -134,6 +134,25 @@ class PredBBox(nn.Module):                    # encoder.py:82-111
         return self.decode(linear(x, self.linear.weight, self.linear.bias))
 
 
+class _BoxDecodeFn(torch.autograd.Function):
+    """PredBBox's exp + _bbox_pred_to_bbox for a yaw-free head as one kernel each way (include/u3d.h u3d_box_decode_*)."""
+
+    @staticmethod
+    def forward(ctx, raw, centers):
+        raw, centers = raw.contiguous(), centers.contiguous()
+        box = torch.empty(raw.shape[0], 6, dtype=torch.float32, device=raw.device)
+        L.call('u3d_box_decode_fwd', L.ptr(raw), L.ptr(centers), raw.shape[0], L.ptr(box), L.stream())
+        ctx.save_for_backward(raw)
+        return box
+
+    @staticmethod
+    def backward(ctx, dbox):
+        raw, = ctx.saved_tensors
+        draw = torch.empty_like(raw)
+        L.call('u3d_box_decode_bwd', L.ptr(raw), L.ptr(dbox.contiguous()), raw.shape[0], L.ptr(draw), L.stream())
+        return draw, None
+
+
 def _bbox_pred_to_bbox(points, bbox_pred):    # encoder.py:241-283
     if bbox_pred.shape[0] == 0:
         return bbox_pred
@@ -181,15 +200,17 @@ class UniDet3DEncoder(nn.Module):
         # out_norm -> out_bboxes.linear as one op (u3d_ln_linear); nq also feeds the class MLP
         nq, box_raw = ln_linear(feats, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, self.out_bboxes.linear.weight,
                                 self.out_bboxes.linear.bias)
-        box_all = self.out_bboxes.decode(box_raw)
         w1, b1, w2, b2 = self.outs_cls[0].weight, self.outs_cls[0].bias, self.outs_cls[2].weight, self.outs_cls[2].bias
-        if len(set(datasets_names)) == 1:
+        single = len(set(datasets_names)) == 1
+        yaw_free = single and not self.angles[self.datasets.index(datasets_names[0])]
+        box_all = None if yaw_free else self.out_bboxes.decode(box_raw)
+        if single:
             # the dataset's class columns (encoder.py:192-194) are selected as ROWS of the [n_cls, d] output weight: the packed
             # [sum n_i, n_cls] logit matrix is never gathered (nor scattered back in backward)
             idx = self.datasets.index(datasets_names[0])
             cidx = self._cidx(idx, feats.device)
             cls_p = mlp(nq, w1, b1, w2[cidx], b2[cidx], 'relu')
-            box_p = _bbox_pred_to_bbox(centers_packed, box_all if self.angles[idx] else box_all[:, :6])
+            box_p = _BoxDecodeFn.apply(box_raw, centers_packed) if yaw_free else _bbox_pred_to_bbox(centers_packed, box_all)
             return list(cls_p.split(sizes)), list(box_p.split(sizes)), (cls_p, box_p)
         cls_all = mlp(nq, w1, b1, w2, b2, 'relu')
         cls_preds, boxes = [], []

@@ -153,6 +153,61 @@ def _plan(Cs, Cd, K, n_dst):
     return R.value, G.value
 
 
+# ---- all weight packs of a model in one launch ------------------------------------------------------------------------------
+_PACKED: Dict = {}          # (weight data_ptr, transposed, bf16) -> (buffer, weight tensor, version at pack time)
+
+
+class WeightPacks:
+    """MFMA-fragment-order copies (u3d_weight_pack[_bf16]) of every convolution weight of a module tree, both orientations,
+    refreshed by ONE launch (u3d_weight_pack_batch) whenever a weight changed since the last refresh -- i.e. once per optimizer
+    step -- instead of one pack launch in front of each of the ~90 convolution launches of a step."""
+
+    def __init__(self, root: nn.Module):
+        self.convs = [m for m in root.modules() if isinstance(m, _ConvBase) and m.in_channels % 16 == 0 and m.kernel_size != 1]
+        self.state = None
+        self.bufs: Dict = {}
+        self.desc = None
+        self.blocks = 0
+
+    def __del__(self):
+        for key in list(getattr(self, 'bufs', {})):
+            _PACKED.pop(key, None)
+
+    def refresh(self):
+        if not self.convs:
+            return
+        bf = P.bf16()
+        dev = self.convs[0].weight.device
+        state = (bf, str(dev), tuple((m.weight.data_ptr(), m.weight._version) for m in self.convs))
+        if state == self.state:
+            return
+        rebuild = self.state is None or self.state[0] != bf or self.state[1] != str(dev) or \
+            [a for a, _ in self.state[2]] != [a for a, _ in state[2]]
+        if rebuild:
+            rows, blocks = [], 0
+            for key in [k for k in _PACKED if k in self.bufs]:
+                _PACKED.pop(key, None)
+            self.bufs = {}
+            for m in self.convs:
+                w = m.weight
+                K = m.kernel_size ** 3
+                for transposed, (Cd, Cs) in ((0, (m.out_channels, m.in_channels)), (1, (m.in_channels, m.out_channels))):
+                    if Cd % 32 or Cs % 16:
+                        continue
+                    use_bf = bf and Cs % 32 == 0
+                    buf = torch.empty(w.numel() // (2 if use_bf else 1), dtype=torch.float32, device=dev)
+                    nvec = w.numel() // (8 if use_bf else 4)
+                    rows.append([w.data_ptr(), buf.data_ptr(), Cd, K, Cs, transposed, int(use_bf), blocks])
+                    blocks += (nvec + 255) // 256
+                    self.bufs[(w.data_ptr(), transposed, use_bf)] = (buf, w)
+            self.desc = L.h2d(rows, torch.int64, dev)
+            self.blocks = blocks
+        L.call('u3d_weight_pack_batch', L.ptr(self.desc), self.desc.shape[0], self.blocks, L.stream())
+        for key, (buf, w) in self.bufs.items():
+            _PACKED[key] = (buf, w, w._version)
+        self.state = state
+
+
 def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=False):
     """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in).
     ``bf``: bf16 MFMA operands (precision.py); source channel counts that are not a multiple of 32 (the 6 -> 32 input
@@ -165,8 +220,12 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
             account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
         bf = bf and Cs % 32 == 0
-        wp = torch.empty(weight.numel() // (2 if bf else 1), dtype=torch.float32, device=src.device)       # MFMA-fragment order
-        L.call('u3d_weight_pack_bf16' if bf else 'u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
+        hit = _PACKED.get((weight.data_ptr(), int(transposed), bf))
+        if hit is not None and hit[2] == weight._version and hit[1].device == src.device:
+            wp = hit[0]                                   # packed with all the model's weights by WeightPacks.refresh()
+        else:
+            wp = torch.empty(weight.numel() // (2 if bf else 1), dtype=torch.float32, device=src.device)       # MFMA-fragment order
+            L.call('u3d_weight_pack_bf16' if bf else 'u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
         L.call('u3d_spconv_gmm_bf16' if bf else 'u3d_spconv_gmm', L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
                rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
     return dst

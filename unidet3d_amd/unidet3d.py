@@ -51,6 +51,7 @@ class UniDet3D(nn.Module):
         self.voxel_div_mode = 0
         self._init_layers(in_channels, num_channels)
         self._vb: Optional[ops.VoxelBatch] = None
+        self._packs = None
 
     def _init_layers(self, in_channels, num_channels):          # unidet3d.py:95-111
         self.input_conv = SparseSequential(
@@ -76,6 +77,10 @@ class UniDet3D(nn.Module):
         prebuilt ``ops.PoolPlan``."""
         if hasattr(self.unet, 'prepare_geometry'):
             self.unet.prepare_geometry(x)
+        if self._packs is None:
+            from .sparse import WeightPacks
+            self._packs = WeightPacks(self)
+        self._packs.refresh()                 # all convolution weights -> MFMA fragment order in one launch, when they changed
         x = self.input_conv(x)
         x, _ = self.unet(x)
         x = self.output_layer(x)

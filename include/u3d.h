@@ -194,7 +194,8 @@ int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const f
  * count <= 0: read from sums[2C]. */
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd,
                      const float* scale, const float* shift, int relu, const double* sums, double count,
-                     int64_t n, int C, float* dx, float* dgamma, float* dbeta, u3d_stream_t stream);
+                     int64_t n, int C, float* dx, float* dgamma, float* dbeta, const float* addend /* nullable [n][C]: added to dx (a second gradient of x, e.g. the residual identity branch) */,
+                     u3d_stream_t stream);
 
 /* Single-call forms for the non-distributed case (stats -> finalize -> apply; bwd_stats -> bwd_apply).
  * st float [4C] = mean, invstd, scale, shift (saved for backward); sums double [2C+1]. */
@@ -203,7 +204,7 @@ int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const f
                    double* sums, void* ws, u3d_stream_t stream);
 /* fwd_sums: the forward call's sums vector (its entry [2C] is the row count the backward divides by) */
 int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n,
-                    int C, float* dx, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
+                    int C, float* dx, float* dgamma, float* dbeta, const float* addend /* nullable, as in u3d_bn_bwd_apply */, void* ws, u3d_stream_t stream);
 
 /* =====================================================================================
  * K11/K12  superpoint pooling -- replaces x.features[inverse_mapping] + torch_scatter.scatter_mean

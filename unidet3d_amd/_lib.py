@@ -58,11 +58,11 @@ PROTOTYPES = {
     'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'u3d_bn_ws_bytes': (_i64, [_i32]),
     'u3d_bn_forward': (_i32, [_vp, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
-    'u3d_bn_backward': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_backward': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_bn_finalize': (_i32, [_vp, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_bn_apply': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     'u3d_bn_bwd_stats': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
-    'u3d_bn_bwd_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'u3d_bn_bwd_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     'u3d_csr_build_ws_bytes': (_i64, [_i64, _i64]),
     'u3d_gather_i64_to_i32': (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                       const double* __restrict__ sums, double inv_count, int64_t n4, int C,
-                                                      float* dx, float* dgamma, float* dbeta, const double* __restrict__ count_src) {
+                                                      float* dx, float* dgamma, float* dbeta, const double* __restrict__ count_src,
+                                                      const float* __restrict__ addend) {
     const int C4 = C >> 2;
     if (!(inv_count > 0.0)) inv_count = 1.0 / (count_src ? count_src[0] : sums[2 * C]);
     if (blockIdx.x == 0 && dgamma) {
@@ -215,6 +216,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
         o.y = sc.y * (g.y - m1y - (v.y - mu.y) * is.y * m2y);
         o.z = sc.z * (g.z - m1z - (v.z - mu.z) * is.z * m2z);
         o.w = sc.w * (g.w - m1w - (v.w - mu.w) * is.w * m2w);
+        if (addend) {        // a second gradient of x (the identity branch of a residual block / U-Net skip) joins here instead of in an add kernel
+            const float4 e = reinterpret_cast<const float4*>(addend)[i];
+            o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
         reinterpret_cast<float4*>(dx)[i] = o;
     }
 }
@@ -282,13 +287,13 @@ int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const f
 
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
                      const float* shift, int relu, const double* sums, double count, int64_t n, int C, float* dx,
-                     float* dgamma, float* dbeta, u3d_stream_t stream) {
+                     float* dgamma, float* dbeta, const float* addend, u3d_stream_t stream) {
     if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !dx || !bn_ok(n, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
     const int64_t n4 = n * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, sums,
-                       1.0 / count, n4, C, dx, dgamma, dbeta, (const double*)nullptr);
+                       1.0 / count, n4, C, dx, dgamma, dbeta, (const double*)nullptr, addend);
     return check_launch("bn_bwd_apply");
 }
 
@@ -312,7 +317,7 @@ int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const f
 }
 
 int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n, int C,
-                    float* dx, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
+                    float* dx, float* dgamma, float* dbeta, const float* addend, void* ws, u3d_stream_t stream) {
     // sums[0..2C) are overwritten; sums[2C] (the row count) is taken from the forward pass's vector
     if (!fwd_sums) return U3D_EINVAL;
     int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, stream);
@@ -322,7 +327,7 @@ int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, 
     ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
     const int64_t n4 = n * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, (const float*)st, (const float*)(st + C), (const float*)(st + 2 * C),
-                       (const float*)(st + 3 * C), relu, (const double*)sums, -1.0, n4, C, dx, dgamma, dbeta, fwd_sums + 2 * C);
+                       (const float*)(st + 3 * C), relu, (const double*)sums, -1.0, n4, C, dx, dgamma, dbeta, fwd_sums + 2 * C, addend);
     return check_launch("bn_backward");
 }
 

@@ -340,7 +340,7 @@ def allreduce_bn_sums(sums: torch.Tensor, group=None):
 
 class _BNReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync, nbt=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync, nbt=None, want_skip=False):
         x = x.contiguous()
         n, C = x.shape
         dev = x.device
@@ -373,13 +373,22 @@ class _BNReLUFn(torch.autograd.Function):
             if n:
                 L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
         ctx.save_for_backward(x, st, sums)
-        ctx.relu, ctx.training, ctx.sync = relu, training, sync
+        ctx.relu, ctx.training, ctx.sync, ctx.want_skip = relu, training, sync, want_skip
+        ctx.set_materialize_grads(False)          # an unused skip output sends None, not a zero tensor
+        if want_skip:
+            # second output = x itself, for the identity branch that leaves the block input next to this norm (residual skip,
+            # U-Net concat): its gradient then arrives HERE, together with dy, and is added inside the backward kernel
+            # instead of by autograd's accumulation kernel
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, st, fsums = ctx.saved_tensors
+        if dy is None:                                 # only the identity branch carried a gradient
+            return (dskip,) + (None,) * 11
         dy = dy.contiguous()
+        dskip = None if dskip is None else dskip.contiguous()
         n, C = x.shape
         dev = x.device
         dx = torch.empty_like(x)
@@ -388,7 +397,7 @@ class _BNReLUFn(torch.autograd.Function):
         if not n:
             if ctx.training and fsums is not None and ctx.sync and _dist_on():     # keep the collective sequence of the other ranks
                 dist.all_reduce(torch.zeros(2 * C, dtype=torch.float64, device=dev), op=dist.ReduceOp.SUM)
-            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None
+            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None, None
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
         if ctx.training and fsums is not None:
@@ -400,10 +409,10 @@ class _BNReLUFn(torch.autograd.Function):
                 dgb[0] = sums[C:2 * C].to(torch.float32)
                 dist.all_reduce(sums[:2 * C], op=dist.ReduceOp.SUM)
                 L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                       int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.stream())
+                       int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.ptr(dskip), L.stream())
             else:                                    # one call: bwd_stats -> bwd_apply (+ dgamma / dbeta)
                 L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(fsums), L.ptr(sums), n, C, L.ptr(dx),
-                       L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(ws), L.stream())
+                       L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(dskip), L.ptr(ws), L.stream())
         else:                                        # eval: statistics are constants -> dx = scale * dy'
             L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
                    int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
@@ -412,8 +421,8 @@ class _BNReLUFn(torch.autograd.Function):
             sums.zero_()
             sums[2 * C] = 1.0
             L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                   int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.stream())
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None
+                   int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.ptr(dskip), L.stream())
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
 
 
 class SparseBatchNorm(nn.Module):
@@ -431,11 +440,13 @@ class SparseBatchNorm(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, relu: bool = False, skip: bool = False):
+        """``skip=True`` -> (y, x_id): ``x_id`` is x for a second consumer (the identity branch next to this norm); the gradient that
+        consumer sends back is added to dx inside this layer's backward kernel."""
         # num_batches_tracked is incremented by the statistics kernel (one launch less per layer)
         return _BNReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                self.momentum, relu, self.training, self.sync,
-                               self.num_batches_tracked if self.training and (x.shape[0] or (self.sync and _dist_on())) else None)
+                               self.num_batches_tracked if self.training and (x.shape[0] or (self.sync and _dist_on())) else None, skip)
 
 
 # ----------------------------------------------------------------------------------------

@@ -48,13 +48,16 @@ class ResidualBlock(SparseModule):
                                                 conv2, norm_fn(out_channels), nn.ReLU())
 
     def forward(self, input: SparseConvTensor) -> SparseConvTensor:
-        skip = self.i_branch(input).features
         if not self.normalize_before:
+            skip = self.i_branch(input).features
             out = self.conv_branch(input)
             return out.replace_feature(out.features + skip)
         mods = list(self.conv_branch._modules.values())
-        x = input
-        x = x.replace_feature(mods[0](x.features, relu=True))
+        # the block input feeds the first norm AND the skip branch: the norm hands the input back as a second output so that
+        # both gradients meet inside its backward kernel (no accumulation kernel)
+        y, x_id = mods[0](input.features, relu=True, skip=True)
+        skip = self.i_branch(input.replace_feature(x_id)).features
+        x = input.replace_feature(y)
         x = mods[2](x)
         x = x.replace_feature(mods[3](x.features, relu=True))
         return mods[5](x, addend=skip)          # conv + residual in one kernel
@@ -114,7 +117,13 @@ class SpConvUNet(nn.Module):
         output = self.blocks(input)
         identity = output
         if len(self.num_planes) > 1:
-            dec = self.conv(output)
+            cm = list(self.conv._modules.values())
+            if isinstance(cm[0], SparseBatchNorm) and len(cm) == 3:       # normalize_before: the skip connection leaves next to a norm
+                y, x_id = cm[0](output.features, relu=True, skip=True)
+                identity = output.replace_feature(x_id)
+                dec = cm[2](output.replace_feature(y))
+            else:
+                dec = self.conv(output)
             if self.return_blocks:
                 dec, previous_outputs = self.u(dec, previous_outputs)
             else:

@@ -129,20 +129,33 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_k(const float* __restrict_
     }
 }
 
-__global__ void layer_norm_reduce_k(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;       // over 2*C
-    if (j >= 2 * C) return;
-    const int which = j / C, c = j % C;
+// dgamma / dbeta = sum of the per-workgroup partials, fixed order.  One workgroup of 16 waves per 64 columns of the [2C] output:
+// wave w adds partial rows w, w+16, ... (256-byte coalesced reads, four independent accumulators), then the 16 wave sums are
+// combined in LDS in a fixed order.  (The single-thread-per-column form walked all 512 rows serially: 33 us per call.)
+__global__ __launch_bounds__(1024) void layer_norm_reduce_k(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;                        // over 2*C: [0, C) = dgamma, [C, 2C) = dbeta (C % 64 == 0 not required)
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        v0 += partial[((int64_t)(b + 0) * 2 + which) * C + c];
-        v1 += partial[((int64_t)(b + 1) * 2 + which) * C + c];
-        v2 += partial[((int64_t)(b + 2) * 2 + which) * C + c];
-        v3 += partial[((int64_t)(b + 3) * 2 + which) * C + c];
+    if (j < 2 * C) {
+        const int which = j / C, c = j % C;
+        int b = wave;
+        for (; b + 48 < nblocks; b += 64) {
+            v0 += partial[((int64_t)(b + 0) * 2 + which) * C + c];
+            v1 += partial[((int64_t)(b + 16) * 2 + which) * C + c];
+            v2 += partial[((int64_t)(b + 32) * 2 + which) * C + c];
+            v3 += partial[((int64_t)(b + 48) * 2 + which) * C + c];
+        }
+        for (; b < nblocks; b += 16) v0 += partial[((int64_t)b * 2 + which) * C + c];
     }
-    for (; b < nblocks; ++b) v0 += partial[((int64_t)b * 2 + which) * C + c];
-    (which ? dbeta : dgamma)[c] = (v0 + v1) + (v2 + v3);
+    red[wave][lane] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (wave == 0 && j < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        (j / C ? dbeta : dgamma)[j % C] = t;
+    }
 }
 
 static int ln_blocks(int64_t M) {
@@ -182,7 +195,7 @@ int u3d_layer_norm_bwd(const float* s_in, const float* dy, const float* gamma, c
 #define U3D_LN(NV) hipLaunchKernelGGL(layer_norm_bwd_k<NV>, dim3(nb), dim3(256), 0, s, s_in, dy, gamma, stats, M, C, dx, (float*)ws)
     if (nv == 1) U3D_LN(1); else if (nv == 2) U3D_LN(2); else U3D_LN(4);
 #undef U3D_LN
-    hipLaunchKernelGGL(layer_norm_reduce_k, dim3((unsigned)ceil_div(2 * C, 256)), dim3(256), 0, s, (const float*)ws, nb, C, dgamma, dbeta);
+    hipLaunchKernelGGL(layer_norm_reduce_k, dim3((unsigned)ceil_div(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb, C, dgamma, dbeta);
     return check_launch("layer_norm_bwd");
 }
 

@@ -72,8 +72,15 @@ def test_two_ranks_equal_one_process_with_both_scenes():
     loss = model.loss(inputs, samples)['det_loss']
     loss.backward()
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad]).cpu()
-    rel = float((got['flat'] - ref).abs().max() / ref.abs().max())
-    assert rel < 2e-2, rel          # same bound family as the single-GPU gradient parity (BN chain + matcher)
+    n_dec = sum(p.numel() for p in model.decoder.parameters())            # the decoder's parameters come last in the flat buffer
+    rel_dec = float((got['flat'][-n_dec:] - ref[-n_dec:]).abs().max() / ref[-n_dec:].abs().max())
+    rel_bb = float((got['flat'][:-n_dec] - ref[:-n_dec]).abs().max() / ref[:-n_dec].abs().max())
+    import _parity as PA
+    PA.log_errors('ddp_2ranks_vs_1process', dict(decoder_grad_rel=rel_dec, backbone_grad_rel=rel_bb))
+    # decoder side: the north-star tolerance; backbone side: summation order changes (two partial BN sums instead of one pass) move
+    # these ill-conditioned gradients as they move the CPU oracle's (tests/_parity.py: 5e-4 median / 4e-2 worst on the CPU alone)
+    assert rel_dec < 1e-3, rel_dec
+    assert rel_bb < 5e-2, rel_bb
     # synchronized statistics: running stats after one step equal the single-process ones
     assert torch.allclose(got['rm'], model.output_layer[0].running_mean.cpu(), rtol=1e-3, atol=1e-5)
     assert torch.allclose(got['rv'], model.unet.u.u.blocks[0].conv_branch[0].running_var.cpu(), rtol=1e-3, atol=1e-5)

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL over xGMI); 'gloo' lets two ranks "
                     "share one GPU to exercise the N>1 code path on a single-GPU box")
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (diagnostic, not the reported config)')
+    ap.add_argument('--no-prefetch', action='store_true',
+                    help="build the next step's voxel grid / rulebooks at the start of that step instead of on a side stream")
     return ap.parse_args()
 
 
@@ -168,6 +170,11 @@ def main():
         if not args.no_optimizer:
             bucket.clip_grad_norm_(10.0)     # clip_grad max_norm=10, norm_type=2 (configs :713) on the flat buffer
             opt.step()
+        if not args.no_prefetch:
+            # the batch-only part of the NEXT step (voxelisation, superpoint CSR, ground-truth boxes, rulebooks: integer kernels
+            # and host read-backs) goes to a side stream now, while this step's backward is still executing; every step
+            # still does this work exactly once inside the timed region (K steps issue K of them)
+            model.prefetch(inputs, samples)
         return loss
 
     def fence():
@@ -256,7 +263,10 @@ def main():
                                    f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, '
                                    + ('bf16 MFMA operands (sparse conv fwd/dgrad, Linear fwd/dX, attention), fp32 accumulate/BN/softmax/optimizer; '
                                       if bf else 'fp32; ') +
-                                   'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else '+clip+AdamW'),
+                                   'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else '+clip+AdamW')
+                                   + ('' if args.no_prefetch else "; each step's voxelise+rulebook part is queued on a side stream during "
+                                      "the previous step's backward"),
+                       'front_prefetch': not args.no_prefetch,
                        'global_batch': args.batch * world, 'points_per_scene': args.points,
                        'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val},
             'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',

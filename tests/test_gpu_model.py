@@ -323,3 +323,52 @@ def test_ln_linear_fwd_bwd(M, N):
     assert _rel(nq, nq_o) < 1e-5 and _rel(y, y_o) < 1e-5
     for name, d, r in zip(('x', 'gamma', 'beta', 'w', 'b'), dev, ref):
         assert _rel(d.grad, r.grad) < 3e-5, name
+
+
+def test_prefetch_on_side_stream_gives_the_same_step():
+    """``UniDet3D.prefetch`` (voxelisation / GT boxes / rulebooks of the next batch on a side stream while the main stream is busy)
+    must not change anything: losses of alternating batches are bit-identical to the inline path and gradients equal up to the
+    run-to-run noise of the inline path itself, also with the main stream kept busy and the allocator under churn between prefetch and use."""
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd.config import build_model, scannet_model_cfg
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = scannet_model_cfg(voxel_size=0.05)
+    cfg['decoder']['num_layers'] = 2
+    model = fill_state_dict(build_model(cfg), tag0=3100, scale=0.06).to(DEV)
+    model.train()
+    batches = [make_batch_inputs([make_scene(90 + 3 * b + i, n_points=9000 + 1000 * b) for i in range(3)], DEV) for b in range(2)]
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def run(prefetch):
+        out = []
+        if prefetch:
+            model.prefetch(*batches[0])
+        for it in range(4):
+            inputs, samples = batches[it % 2]
+            for p in params:
+                p.grad = None
+            loss = model.loss(inputs, samples)['det_loss']
+            loss.backward()
+            if prefetch:
+                model.prefetch(*batches[(it + 1) % 2])
+                junk = [torch.randn(1 << 18, device=DEV) @ torch.randn(1 << 18, device=DEV) for _ in range(8)]      # churn + busy main stream
+                del junk
+            out.append((loss.detach().clone(), [p.grad.clone() for p in params if p.grad is not None]))
+        torch.cuda.synchronize()
+        return out
+    a, a2, b = run(False), run(False), run(True)
+    assert model._prefetched is not None                     # the last prefetch is still waiting to be used
+    model._prefetched = None
+
+    def diff(u, v):
+        worst_l, worst_g = 0.0, 0.0
+        for (lu, gu), (lv, gv) in zip(u, v):
+            assert len(gu) == len(gv)
+            worst_l = max(worst_l, abs(float(lu) - float(lv)) / abs(float(lv)))
+            worst_g = max([worst_g] + [_rel(x, y) for x, y in zip(gu, gv)])
+        return worst_l, worst_g
+    (l_base, g_base), (l_pref, g_pref) = diff(a, a2), diff(a, b)
+    print(f'prefetch: inline vs inline loss {l_base:.1e} grads {g_base:.1e}; inline vs prefetched loss {l_pref:.1e} grads {g_pref:.1e}')
+    # equal up to the run-to-run noise of the inline path (summation order of atomics in the torch ops around the kernels)
+    assert l_pref <= max(5 * l_base, 1e-6) and g_pref <= max(5 * g_base, 1e-5)

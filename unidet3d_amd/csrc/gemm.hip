@@ -241,52 +241,66 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
     nt_epilogue<TN, EPI>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
 }
 
-constexpr int TLD = GT + 4;    // padded LDS row of the TN tiles ([16 rows][128 cols])
-
-// partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k]
+// partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k].  T = 128 or 64 output rows AND columns per workgroup:
+// the weight gradients of this decoder are small (256 x 256, 768 x 256, 256 x 32, 19 x 256 ...) -- with 128 x 128 tiles a
+// 256 x 256 output has 4 tiles and needs ~96 row splits to fill 256 CUs, i.e. 25 MB of partials written and read back for 0.26 MB
+// of result; 64 x 64 tiles quarter the splits and the partial traffic at the price of twice the LDS reads per MFMA.
+template <int T>
 __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
-                                                 int colsum, int64_t M, int N, int K, int64_t rows_per_split) {
-    __shared__ __attribute__((aligned(16))) float As[2][GK * TLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK * TLD];
+                                                 int colsum, int64_t M, int N, int K, int64_t rows_per_split, int S) {
+    // workgroup -> (row split, output tile), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with its
+    // own L2; every tile of one row split reads the same rows of A and B, so all of them are placed on ONE XCD (ids congruent
+    // mod 8, adjacent in that XCD's order) and the operands come from HBM once instead of once per tile
+    const int tiles_n = (N + T - 1) / T, tiles = tiles_n * ((K + T - 1) / T);
+    const int slot = blockIdx.x >> 3, tile = slot % tiles;
+    const int split = (slot / tiles) * 8 + (blockIdx.x & 7);
+    if (split >= S) return;
+    constexpr int LD = T + 4;                   // padded LDS row of the tiles ([16 rows][T cols])
+    constexpr int NF = T / 64;                  // 32-wide MFMA tiles per wave and operand
+    constexpr int TPR = T / 4;                  // staging threads per tile row (float4 each)
+    constexpr int RPP = 256 / TPR;              // rows per staging pass
+    constexpr int NP = GK / RPP;                // staging passes per K-step
+    __shared__ __attribute__((aligned(16))) float As[2][GK * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
-    const int n0 = blockIdx.x * GT, k0 = blockIdx.y * GT;
-    const int64_t mlo = (int64_t)blockIdx.z * rows_per_split;
+    const int n0 = (tile % tiles_n) * T, k0 = (tile / tiles_n) * T;
+    const int64_t mlo = (int64_t)split * rows_per_split;
     const int64_t mhi = min(M, mlo + rows_per_split);
     const int rows = (int)max((int64_t)0, mhi - mlo);
-    // staging map: thread -> (row = tid>>5 (+8), float4 column = tid&31); buffer loads from descriptors based at this split's
-    // first row: the row block of a step is the scalar offset, rows past the split and columns past N / K read as zeros
-    const int srow = tid >> 5, sc4 = tid & 31;
+    // buffer loads from descriptors based at this split's first row: the row block of a step is the scalar offset, rows past
+    // the split and columns past N / K read as zeros
+    const int srow = tid / TPR, sc4 = tid % TPR;
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + mlo * N, (int64_t)rows * N * 4);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + mlo * K, (int64_t)rows * K * 4);
     const int va = n0 + sc4 * 4 < N ? (srow * N + n0 + sc4 * 4) * 4 : 0x7fffffff;
     const int vb = k0 + sc4 * 4 < K ? (srow * K + k0 + sc4 * 4) * 4 : 0x7fffffff;
     const bool ca = va != 0x7fffffff, cb = vb != 0x7fffffff;
-    f32x4 ra[2], rb[2];
+    f32x4 ra[NP], rb[NP];
     auto gload = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            ra[j] = bload128(rs_a, ca ? va + j * 8 * N * 4 : va, t * (GK * N * 4));
-            rb[j] = bload128(rs_b, cb ? vb + j * 8 * K * 4 : vb, t * (GK * K * 4));
+        for (int j = 0; j < NP; ++j) {
+            ra[j] = bload128(rs_a, ca ? va + j * RPP * N * 4 : va, t * (GK * N * 4));
+            rb[j] = bload128(rs_b, cb ? vb + j * RPP * K * 4 : vb, t * (GK * K * 4));
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<f32x4*>(&As[buf][(srow + 8 * j) * TLD + sc4 * 4]) = ra[j];
-            *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 8 * j) * TLD + sc4 * 4]) = rb[j];
+        for (int j = 0; j < NP; ++j) {
+            *reinterpret_cast<f32x4*>(&As[buf][(srow + RPP * j) * LD + sc4 * 4]) = ra[j];
+            *reinterpret_cast<f32x4*>(&Bs[buf][(srow + RPP * j) * LD + sc4 * 4]) = rb[j];
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[NF][NF];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NF; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NF; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int nt = (rows + GK - 1) / GK;
-    const bool sums = colsum && blockIdx.y == 0 && tid < GT;       // column sums of A (the bias gradient) ride along
+    const bool sums = colsum && k0 == 0 && tid < T;       // column sums of A (the bias gradient) ride along
     float csum = 0.f;
     if (nt > 0) {
         gload(0);
@@ -299,31 +313,35 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int m = kh * 8 + s;                       // reduction index of this lane at step s
-            const float a0 = As[buf][m * TLD + wr * 64 + i32], a1 = As[buf][m * TLD + wr * 64 + 32 + i32];
-            const float b0 = Bs[buf][m * TLD + wc * 64 + i32], b1 = Bs[buf][m * TLD + wc * 64 + 32 + i32];
-            acc[0][0] = U3D_MFMA32(a0, b0, acc[0][0]);
-            acc[0][1] = U3D_MFMA32(a0, b1, acc[0][1]);
-            acc[1][0] = U3D_MFMA32(a1, b0, acc[1][0]);
-            acc[1][1] = U3D_MFMA32(a1, b1, acc[1][1]);
+            float av[NF], bv[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                av[u] = As[buf][m * LD + wr * (T / 2) + u * 32 + i32];
+                bv[u] = Bs[buf][m * LD + wc * (T / 2) + u * 32 + i32];
+            }
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+#pragma unroll
+                for (int b = 0; b < NF; ++b) acc[a][b] = U3D_MFMA32(av[a], bv[b], acc[a][b]);
         }
         if (sums) {
 #pragma unroll
-            for (int m = 0; m < GK; ++m) csum += As[buf][m * TLD + tid];
+            for (int m = 0; m < GK; ++m) csum += As[buf][m * LD + tid];
         }
         if (t + 1 < nt) lstore(buf ^ 1);
         __syncthreads();
     }
     const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
-    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)blockIdx.z * pstride, (int64_t)N * K * 4);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)split * pstride, (int64_t)N * K * 4);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int k = k0 + wc * 64 + b * 32 + i32;
+    for (int b = 0; b < NF; ++b) {
+        const int k = k0 + wc * (T / 2) + b * 32 + i32;
         const int vo = k < K ? ((n0 + 4 * kh) * K + k) * 4 : 0x7fffffff;        // rows past N fall off the end of the descriptor
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NF; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                const int row = wr * (T / 2) + a * 32 + (r & 3) + 8 * (r >> 2);
                 // the element goes through an opaque VGPR copy: handed a vector element directly, this compiler's buffer-store
                 // builtin stores element 0 of the accumulator sixteen times (seen in the ISA, caught by the parity test)
                 float v = acc[a][b][r];
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, row * K * 4, 0);
             }
     }
-    if (sums && n0 + tid < N) partial[(int64_t)blockIdx.z * pstride + (int64_t)N * K + n0 + tid] = csum;
+    if (sums && n0 + tid < N) partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = csum;
 }
 
 // bf16-operand form of gemm_tn_k (weight gradients of the Linear layers under BASELINE configs[2]): A (= dY) and B (= X) are
@@ -498,9 +516,14 @@ __global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in,
         if (bx + j < Ccols && by + tx < R) out[(int64_t)(bx + j) * R + by + tx] = tile[tx][j];
 }
 
-static int tn_splits(int64_t M, int N, int K) {
-    const int64_t tiles = ceil_div(N, GT) * ceil_div(K, GT);
-    int64_t s = ceil_div(384, tiles);      // ~1.5 workgroups per CU; every extra split costs N*K*4 bytes in the reduce
+// 64 x 64 tiles while 128 x 128 ones would be fewer than 16 (every decoder weight except the FFN's 1024 x 256)
+static int tn_tile(int N, int K) { return ceil_div(N, GT) * ceil_div(K, GT) < 16 ? 64 : GT; }
+static int tn_splits(int64_t M, int N, int K, int T, bool bf) {
+    const int64_t tiles = ceil_div(N, T) * ceil_div(K, T);
+    // workgroups aimed at: ~3 per CU for the fp32 kernels (measured best of 384 / 768 / 1536), 1.5 for the bf16 one (its
+    // workgroups are 16x shorter); every extra split costs N*K*4 bytes written and read again by the reduce
+    static const int target = [] { const char* e = getenv("U3D_TN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+    int64_t s = ceil_div(bf ? 384 : target, tiles);
     const int64_t max_s = ceil_div(M, 4 * GK);
     if (s > max_s) s = max_s;
     return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
@@ -596,7 +619,7 @@ int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W
     return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, bf, nullptr, nullptr, f2, (hipStream_t)stream);
 }
 
-int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K) * ((int64_t)N * K + N) * 4 + 256; }
+int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K, GT, false) * ((int64_t)N * K + N) * 4 + 256; }   // the case with the most splits
 
 static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
                         u3d_stream_t stream, bool bf) {
@@ -604,14 +627,19 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     if (N % 4 || K % 4) { set_error("gemm_tn: N=%d, K=%d must be multiples of 4", N, K); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
-    const int S = tn_splits(M, N, K);
+    const int S = tn_splits(M, N, K, bf ? GT : tn_tile(N, K), bf);
     const int64_t rps = ceil_div(ceil_div(M, S), GK) * GK;
     if ((int64_t)(rps + GK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + GK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
         set_error("gemm_tn: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
         return U3D_EUNSUPPORTED;
     }
     if (bf) hipLaunchKernelGGL(gemm_tn_bf16_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
-    else hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
+    else {
+        const int T = tn_tile(N, K);
+        const unsigned grid = (unsigned)(ceil_div(S, 8) * 8 * ceil_div(N, T) * ceil_div(K, T));       // whole groups of 8 splits
+        if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+        else hipLaunchKernelGGL(gemm_tn_k<GT>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+    }
     const int64_t n4_main = (int64_t)N * K / 4, n4 = n4_main + (colsum_A ? N / 4 : 0);
     int64_t grid = ceil_div(n4, 256);
     grid = grid > 1024 ? 1024 : grid;

@@ -24,6 +24,26 @@ from .sparse import SparseBatchNorm, SparseConvTensor, SparseSequential, SubMCon
 from .structures import DepthInstance3DBoxes, InstanceData_
 
 
+def _tensors_of(obj, _seen=None, _depth=0):
+    """every CUDA tensor reachable from ``obj`` through lists / tuples / dicts / object attributes"""
+    if _seen is None:
+        _seen = set()
+    if id(obj) in _seen or _depth > 8:
+        return
+    _seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors_of(o, _seen, _depth + 1)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors_of(o, _seen, _depth + 1)
+    elif hasattr(obj, '__dict__') and not isinstance(obj, (nn.Module, type)):
+        yield from _tensors_of(vars(obj), _seen, _depth + 1)
+
+
 @MODELS.register_module()
 class UniDet3D(nn.Module):
     def __init__(self, in_channels, num_channels, voxel_size, min_spatial_shape, query_thr, use_superpoints,
@@ -52,6 +72,8 @@ class UniDet3D(nn.Module):
         self._init_layers(in_channels, num_channels)
         self._vb: Optional[ops.VoxelBatch] = None
         self._packs = None
+        self._side_stream = None
+        self._prefetched = None
 
     def _init_layers(self, in_channels, num_channels):          # unidet3d.py:95-111
         self.input_conv = SparseSequential(
@@ -168,7 +190,10 @@ class UniDet3D(nn.Module):
         return vb, plan, batch_offsets, sp_centers, names
 
     # ------------------------------------------------------------------ training step (unidet3d.py:277-364)
-    def loss(self, batch_inputs_dict, batch_data_samples, query_perms=None, **kwargs):
+    def _prepare_train(self, batch_inputs_dict, batch_data_samples):
+        """Everything of a training step that depends on the batch alone -- voxelisation, superpoint CSR and centres, ground-truth
+        boxes / targets in the training frame (unidet3d.py:295-341) and the rulebooks of all U-Net levels: integer and
+        geometry kernels with a handful of host read-backs, no parameters involved."""
         vb, plan, batch_offsets, sp_centers, names = self._front(batch_inputs_dict, batch_data_samples, True)
         B = len(batch_data_samples)
         sp_gt_instances = []
@@ -206,6 +231,45 @@ class UniDet3D(nn.Module):
                 inst.sp_masks = self.get_targets(inst.sp_centers, inst.bboxes_3d, self.train_cfg['topk'])
             sp_gt_instances.append(inst)
         x = self._sparse_input(B)
+        if hasattr(self.unet, 'prepare_geometry'):
+            self.unet.prepare_geometry(x)
+        return dict(vb=vb, plan=plan, batch_offsets=batch_offsets, names=names, sp_gt_instances=sp_gt_instances, x=x)
+
+    def prefetch(self, batch_inputs_dict, batch_data_samples, ready_event=None):
+        """Run ``_prepare_train`` for the NEXT batch on a side stream so that its small kernels and host read-backs overlap the
+        backward pass still executing on the main stream (a training loop calls this right after ``optimizer.step()`` has
+        been queued; ``loss`` picks the result up when it is handed the same two objects).  Without it every step starts
+        with the GPU idle: the first read-back of the voxeliser drains the queue and ~3 ms of launch-latency-bound
+        integer work follow.  The batch tensors must be complete on the device (``ready_event``: an event the side stream
+        waits for, e.g. the end of their upload); they are only read."""
+        dev = batch_inputs_dict['points'][0].device
+        if dev.type != 'cuda':
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self._side_stream):
+            if ready_event is not None:
+                self._side_stream.wait_event(ready_event)
+            prep = self._prepare_train(batch_inputs_dict, batch_data_samples)
+            done = torch.cuda.Event()
+            done.record(self._side_stream)
+        # the tensors were allocated from the side stream's pool but will be read by main-stream kernels: tell the caching
+        # allocator, or a block freed after step i could be handed to the prefetch of step i+2 while step i+1 still reads it
+        for t in _tensors_of(prep):
+            t.record_stream(main)
+        self._prefetched = (batch_inputs_dict, batch_data_samples, prep, done)
+
+    def loss(self, batch_inputs_dict, batch_data_samples, query_perms=None, **kwargs):
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is batch_inputs_dict and pre[1] is batch_data_samples:
+            torch.cuda.current_stream().wait_event(pre[3])
+            prep = pre[2]
+        else:
+            prep = self._prepare_train(batch_inputs_dict, batch_data_samples)
+        vb, plan, batch_offsets, names = prep['vb'], prep['plan'], prep['batch_offsets'], prep['names']
+        sp_gt_instances, x = prep['sp_gt_instances'], prep['x']
+        self._vb = vb
         feats = self.extract_feat(x, plan, vb.inverse, batch_offsets)
         queries, sp_centers_q, sp_gt_instances = self._select_queries(feats, sp_gt_instances, query_perms)
         out = self.decoder(queries, sp_centers_q, names)

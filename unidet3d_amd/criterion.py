@@ -396,9 +396,16 @@ class UniDet3DCriterion:
                     cu=_h2d(cu, torch.int32, device), gt_off=_h2d(go, torch.int32, device), qm_off=_h2d(qo, torch.int64, device),
                     labels=labels, boxes=boxes, qmask=qmask)
 
+    @staticmethod
+    def _stacked(pk):
+        """[L, sum n_i, .] head outputs: the decoder's own stacked views when it evaluated the head once over all layers"""
+        if 'cls_stacked' in pk:
+            return pk['cls_stacked'], pk['box_stacked']
+        return torch.stack(pk['cls']), torch.stack(pk['box'])
+
     def _loss_fused(self, pk, insts, name):
         idx = self.datasets.index(name)
-        cls, box = torch.stack(pk['cls']), torch.stack(pk['box'])
+        cls, box = self._stacked(pk)
         g = self._flat_gt(insts, pk['sizes'], cls.device, self.topk[idx])
         if g is None:
             return None
@@ -423,7 +430,7 @@ class UniDet3DCriterion:
                     return {'det_loss': loss}
             gt = self._pack_gt(insts, pk['sizes'], pk['cls'][0].device)
             # final layer + the aux layers, each re-matched (iter_matcher), in one batched pass
-            return {'det_loss': self._loss_packed(torch.stack(pk['cls']), torch.stack(pk['box']), gt, datasets_names[0])}
+            return {'det_loss': self._loss_packed(*self._stacked(pk), gt, datasets_names[0])}
         loss = self.get_layer_loss(pred, insts, datasets_names)
         if 'aux_outputs' in pred:
             indices = None        # iter_matcher=True re-matches per layer; the reference leaves `indices`

@@ -532,8 +532,10 @@ static int tn_splits(int64_t M, int N, int K, int T, bool bf) {
 template <int EPI>
 static void launch_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, const float* aux, float* pre,
                       bool bf16_operands, hipStream_t s) {
-    // 128x64 tiles when 128x128 would leave the 256 CUs with fewer than two workgroups each
-    const bool narrow = ceil_div(M, GT) * ceil_div(N, GT) < 512;
+    // 128x64 tiles unless 128x128 ones still give every CU ~9 workgroups: with 3-4 big tiles per CU the last, partly filled round of
+    // workgroups costs more than the narrow tile's extra LDS reads (measured on the step: threshold 512 -> 2200: 7.07 -> 6.76 ms of GEMMs)
+    static const int64_t narrow_below = [] { const char* e = getenv("U3D_NT_NARROW_BELOW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)2200; }();
+    const bool narrow = ceil_div(M, GT) * ceil_div(N, GT) < narrow_below;
     const dim3 grid((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, narrow ? 64 : GT));
     if (bf16_operands) {
         if (narrow) hipLaunchKernelGGL((gemm_nt_bf16_k<64, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);

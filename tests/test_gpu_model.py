@@ -372,3 +372,47 @@ def test_prefetch_on_side_stream_gives_the_same_step():
     print(f'prefetch: inline vs inline loss {l_base:.1e} grads {g_base:.1e}; inline vs prefetched loss {l_pref:.1e} grads {g_pref:.1e}')
     # equal up to the run-to-run noise of the inline path (summation order of atomics in the torch ops around the kernels)
     assert l_pref <= max(5 * l_base, 1e-6) and g_pref <= max(5 * g_base, 1e-5)
+
+
+def test_prefetch_step_feeds_train_step():
+    """``prefetch_step(next_data)`` + ``train_step(next_data, ...)`` == plain ``train_step`` calls: same losses over three
+    optimisation steps on alternating raw host batches (the upload and the batch-only kernels of the next batch run on the side stream)."""
+    import copy
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd.config import build_model, scannet_model_cfg
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = scannet_model_cfg(voxel_size=0.05)
+    cfg['decoder']['num_layers'] = 2
+    base = fill_state_dict(build_model(cfg), tag0=3200, scale=0.06)
+    raw = []
+    for b in range(2):
+        inputs, samples = make_batch_inputs([make_scene(120 + 2 * b + i, n_points=7000) for i in range(2)], 'cpu')
+        raw.append([dict(inputs=dict(points=inputs['points'][i].numpy()), data_samples=samples[i]) for i in range(2)])
+
+    class OptimWrapper:
+        def __init__(self, params):
+            self.opt = torch.optim.SGD(params, lr=1e-3)
+
+        def update_params(self, loss):
+            loss.backward(); self.opt.step(); self.opt.zero_grad()
+
+    def run(prefetch):
+        model = copy.deepcopy(base).to(DEV).train()
+        ow = OptimWrapper(model.parameters())
+        batches = copy.deepcopy(raw)
+        losses = []
+        if prefetch:
+            model.prefetch_step(batches[0])
+        for it in range(3):
+            log = model.train_step(batches[it % 2], ow)
+            if prefetch:
+                model.prefetch_step(batches[(it + 1) % 2])
+                assert model._staged is not None and model._prefetched is not None
+            losses.append(float(log['loss'].detach()))
+        torch.cuda.synchronize()
+        return losses
+    a, b = run(False), run(True)
+    print('train_step losses inline', a, 'prefetched', b)
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 2e-5 * abs(x)          # after the first step the weights carry the backward's run-to-run noise

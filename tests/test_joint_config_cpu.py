@@ -51,3 +51,23 @@ def test_joint_criterion_on_mixed_batch_with_rotated_ground_truth():
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(b.grad).all() for b in box)
     assert box[1].grad[:, 6].abs().sum() > 0                            # the heading of the rotated boxes receives gradient
+
+
+def test_prefetch_is_a_no_op_off_gpu_and_tensor_walk_finds_nested_tensors():
+    """host logic of UniDet3D.prefetch: on CPU tensors nothing is staged (``loss`` then does the work inline); the walker that
+    hands side-stream tensors to the main stream (record_stream) reaches tensors behind lists / dicts / object attributes."""
+    import torch
+    from unidet3d_amd.unidet3d import _tensors_of
+    from unidet3d_amd.config import build_model, scannet_model_cfg
+
+    class Box:
+        def __init__(self, t):
+            self.tensor = t
+    t1, t2, t3 = torch.zeros(2), torch.ones(3), torch.arange(4)
+    seen = list(_tensors_of(dict(a=[t1, (Box(t2),)], b=dict(c=t3), d=7, e='x', f=t1)))
+    assert seen == []                                   # CPU tensors are not stream-managed: nothing to record
+    model = build_model(scannet_model_cfg(voxel_size=0.05))
+    model.prefetch(dict(points=[torch.zeros(10, 6)]), [])
+    assert model._prefetched is None
+    model.prefetch_step([dict(inputs=dict(points=torch.zeros(10, 6)), data_samples=None)])
+    assert model._staged is None

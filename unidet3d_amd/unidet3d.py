@@ -74,6 +74,7 @@ class UniDet3D(nn.Module):
         self._packs = None
         self._side_stream = None
         self._prefetched = None
+        self._staged = None
 
     def _init_layers(self, in_channels, num_channels):          # unidet3d.py:95-111
         self.input_conv = SparseSequential(
@@ -329,11 +330,29 @@ class UniDet3D(nn.Module):
     def train_step(self, data, optim_wrapper):
         """One optimisation step as ``BaseModel.train_step`` performs it: preprocess, forward(mode='loss'), parse the loss
         dict, ``optim_wrapper.update_params(loss)`` (mmengine ``OptimWrapper`` / ``AmpOptimWrapper``, tools/train.py:86-99)."""
-        data = self._prep(data, True)
+        staged, self._staged = self._staged, None
+        data = staged[1] if staged is not None and staged[0] is data else self._prep(data, True)
         losses = self(data['inputs'], data['data_samples'], mode='loss')
         total, log = self.parse_losses(losses)
         optim_wrapper.update_params(total)
         return log
+
+    def prefetch_step(self, data):
+        """``prefetch`` for loops that drive the model through ``train_step``: preprocess the NEXT raw batch (host -> device copies
+        included) and queue its batch-only kernels, all on the side stream; the next ``train_step`` on the same ``data`` object
+        picks both up."""
+        if not torch.cuda.is_available() or next(self.parameters()).device.type != 'cuda':
+            return
+        dev = next(self.parameters()).device
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self._side_stream):
+            prepped = self._prep(data, True)
+        self.prefetch(prepped['inputs'], prepped['data_samples'])          # same side stream: ordered after the uploads
+        for t in _tensors_of(prepped):
+            t.record_stream(main)
+        self._staged = (data, prepped)
 
     def val_step(self, data):
         data = self._prep(data, False)

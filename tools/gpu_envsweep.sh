@@ -7,5 +7,5 @@ for s in "$@"; do
   env $e timeout 200 python bench.py --no-cpu-baseline $BENCH_ARGS > $OUT/b$i.json 2> $OUT/b$i.log
   python -c "
 import json
-d = json.load(open('$OUT/b$i.json')); print('$s', round(d['value'], 1), round(d['ms_per_step'], 2), {k: round(v['ms_per_step'], 2) for k, v in d['kernels'].items()})"
+d = json.load(open('$OUT/b$i.json')); print('$s', round(d['value'], 1), round(d['ms_per_step'], 2), d['config']['loss'], {k: round(v['ms_per_step'], 2) for k, v in d['kernels'].items()})"
 done

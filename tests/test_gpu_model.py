@@ -370,8 +370,10 @@ def test_prefetch_on_side_stream_gives_the_same_step():
         return worst_l, worst_g
     (l_base, g_base), (l_pref, g_pref) = diff(a, a2), diff(a, b)
     print(f'prefetch: inline vs inline loss {l_base:.1e} grads {g_base:.1e}; inline vs prefetched loss {l_pref:.1e} grads {g_pref:.1e}')
-    # equal up to the run-to-run noise of the inline path (summation order of atomics in the torch ops around the kernels)
-    assert l_pref <= max(5 * l_base, 1e-6) and g_pref <= max(5 * g_base, 1e-5)
+    # equal up to the run-to-run noise of the inline path (summation order of atomics in the torch ops around the kernels: one ulp
+    # on the loss, and through the ill-conditioned backbone up to ~5e-4 on single gradient tensors -- measured inline vs inline;
+    # the yardstick is one sample, hence the floors).  A stale or recycled buffer shows up as O(1) differences.
+    assert l_pref <= max(5 * l_base, 1e-5) and g_pref <= max(5 * g_base, 5e-3)
 
 
 def test_prefetch_step_feeds_train_step():

@@ -1,3 +1,5 @@
+"""BASELINE configs[4] probe: ONE scene of 1 M points (a large room, ~10x the ScanNet footprint) through a full training step on cuda:0 --
+memory and time of the path far outside the benchmark shape.  usage (GPU box): python tools/cfg5_stress.py"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from unidet3d_amd.config import build_model, scannet_model_cfg

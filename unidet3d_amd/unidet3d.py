@@ -243,9 +243,10 @@ class UniDet3D(nn.Module):
         with the GPU idle: the first read-back of the voxeliser drains the queue and ~3 ms of launch-latency-bound
         integer work follow.  The batch tensors must be complete on the device (``ready_event``: an event the side stream
         waits for, e.g. the end of their upload); they are only read."""
-        dev = batch_inputs_dict['points'][0].device
-        if dev.type != 'cuda':
+        pts = batch_inputs_dict['points']
+        if not len(pts) or pts[0].device.type != 'cuda':
             return
+        dev = pts[0].device
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(dev)
         main = torch.cuda.current_stream(dev)

@@ -2,14 +2,18 @@
 """Headline benchmark: scenes/sec forward+backward of UniDet3D's detection hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1 without a torchrun environment (WORLD_SIZE unset): the script re-executes itself under
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`
+  (tools/train.py:49-52,73 of the reference selects its launcher the same way); launched BY torchrun it reads
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 Workload (BASELINE.json configs[1]): 8 synthetic ScanNet-shape scenes per GPU, 100k points each,
 0.02 m voxels, fp32, the ScanNet model config (5-level sparse U-Net 32..160 ch, 6-layer 256-d decoder).
 One step = one pass of the hot path over the batch with the points already resident in HBM:
 voxelise -> rulebooks -> backbone -> superpoint pooling -> decoder -> matcher/loss -> backward ->
 (gradient all-reduce when N > 1) -> grad clip + AdamW.  Weak scaling: every rank runs its own 8 scenes.
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  The line's headline is the fp32 cfg2 measurement; a `cfg3` block (BASELINE.json configs[2]:
+bf16 MFMA operands, 16 scenes per GPU) measured right after it in the same process rides along (--no-cfg3 skips it).
 """
 from __future__ import annotations
 
@@ -39,17 +43,49 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=None, help='scenes per GPU (cfg2: 8; cfg3 = --dtype bf16: 16)')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
-                    help="MFMA operand precision: fp32 = BASELINE configs[1] (the headline line), bf16 = configs[2] "
+                    help="MFMA operand precision of the HEADLINE: fp32 = BASELINE configs[1] (default), bf16 = configs[2] "
                          "(bf16 operands, fp32 accumulate / statistics / optimizer; unidet3d_amd/precision.py)")
+    ap.add_argument('--no-cfg3', action='store_true', help='skip the cfg3 block (bf16 operands, 16 scenes/GPU) appended to the fp32 line')
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--voxel-size', type=float, default=0.02)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL over xGMI); 'gloo' lets two ranks "
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL over xGMI); 'gloo' lets several ranks "
                     "share one GPU to exercise the N>1 code path on a single-GPU box")
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (diagnostic, not the reported config)')
+    ap.add_argument('--optimizer', default='adamw', choices=['adamw', 'sgd'],
+                    help='adamw = configs/unidet3d_1xb8_scannet.py:710-713 (the reported config); sgd = diagnostic (DESIGN.md section 2: '
+                         "AdamW's first updates are lr*sign(g), which turns rounding-level gradient differences into different trajectories)")
     ap.add_argument('--no-prefetch', action='store_true',
                     help="build the next step's voxel grid / rulebooks at the start of that step instead of on a side stream")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(gpus: int, argv, port: int):
+    """The torchrun command `python bench.py --gpus N` turns itself into (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: become the launcher (the reference picks its
+    launcher in tools/train.py:49-52,73; here the only multi-process form is one rank per GPU on one node)."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    cmd = launch_command(args.gpus, sys.argv[1:], _free_port())
+    log('self-launch: ' + ' '.join(cmd))
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', str(max(1, usable_cores() // args.gpus))))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
 
 
 def usable_cores() -> int:
@@ -66,7 +102,8 @@ def usable_cores() -> int:
 
 
 def _cpu_baseline_child(points: int, voxel_size: float, cores: int):
-    """Runs in a child process (bounded by a timeout in the parent)."""
+    """Runs in a child process (bounded by a timeout in the parent).  SURVEY.md 8(d) protocol: 2 warm-up iterations, then
+    >= 5 timed ones, median; an iteration = one scene of the bench batch, forward + loss + backward."""
     from oracle import criterion as oc
     from oracle import model as om
     from unidet3d_amd.config import scannet_model_cfg
@@ -78,6 +115,7 @@ def _cpu_baseline_child(points: int, voxel_size: float, cores: int):
     det.train()
 
     def run(sc):
+        t = time.perf_counter()
         p = [torch.from_numpy(sc.points)]
         s = [torch.from_numpy(sc.superpoints)]
         feats, _ = det.extract_feat(p, s)
@@ -87,35 +125,36 @@ def _cpu_baseline_child(points: int, voxel_size: float, cores: int):
         loss = oc.criterion(out, [inst])
         det.zero_grad()
         loss.backward()
-        return float(loss.detach())
+        return time.perf_counter() - t
 
-    run(make_scene(900, n_points=max(points // 20, 2000)))      # warm the thread pool / allocator
-    scenes = [make_scene(i, n_points=points) for i in range(8)]  # the bench batch; as many of them as fit ~12 s of CPU work
-    t0, k = time.perf_counter(), 0
-    while k < len(scenes) and (k == 0 or time.perf_counter() - t0 < 12.0):
-        run(scenes[k])
+    scenes = [make_scene(i, n_points=points) for i in range(8)]  # the bench batch
+    warm = [run(scenes[6]), run(scenes[7])]
+    times, t0, k = [], time.perf_counter(), 0
+    while k < 6 and (k < 5 or time.perf_counter() - t0 < 14.0):
+        times.append(run(scenes[k]))
         k += 1
-    print(json.dumps({'seconds': time.perf_counter() - t0, 'scenes': k}))
+    times.sort()
+    print(json.dumps({'median_s': times[len(times) // 2], 'times': times, 'warm': warm, 'seconds': time.perf_counter() - t0}))
 
 
 def cpu_baseline(points: int, voxel_size: float):
-    """The oracle (a PyTorch-CPU restatement of the algorithm spconv's CPU path uses) timed on this
-    box's host cores on a bounded sample: scenes of the same batch, forward + loss + backward each, for about 12 s."""
+    """The oracle (a PyTorch-CPU restatement of the algorithm spconv's CPU path uses) timed on this box's host cores on a
+    bounded sample of the bench batch: 2 warm-up scenes, then >= 5 timed scenes (forward + loss + backward each), median."""
     import subprocess
     cores = usable_cores()
-    for pts, limit in ((points, 150), (max(points // 5, 2000), 90)):
+    for pts, limit in ((points, 200), (max(points // 5, 2000), 90)):
         code = f'import sys; sys.path.insert(0, {ROOT!r}); import bench; bench._cpu_baseline_child({pts}, {voxel_size}, {cores})'
         try:
             res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=limit,
                                  env=dict(os.environ, OMP_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES=''))
             rec = json.loads(res.stdout.strip().splitlines()[-1])
-            dt, k = rec['seconds'], rec['scenes']
         except Exception as e:  # noqa: BLE001  (timeout / parse error -> try the smaller sample)
             log(f'cpu_baseline sample of {pts} pts failed: {type(e).__name__}')
             continue
-        return dict(value=k / dt, unit='scenes/s', cores=cores, kind='port',
-                    sample=f'{k} scene(s) ({pts} pts, {voxel_size} m voxels) of the bench batch, fwd+loss+bwd each, fp32, '
-                           f'{dt:.1f} s with torch CPU threads={cores}' +
+        return dict(value=1.0 / rec['median_s'], unit='scenes/s', cores=cores, kind='port',
+                    sample=f'median of {len(rec["times"])} timed scenes after 2 warm-up scenes ({pts} pts, {voxel_size} m voxels; scenes of the '
+                           f'bench batch, fwd+loss+bwd each, fp32), {rec["seconds"]:.1f} s of timed CPU work with torch CPU threads={cores}; '
+                           f'per-scene seconds min/median/max = {rec["times"][0]:.2f}/{rec["median_s"]:.2f}/{rec["times"][-1]:.2f}' +
                            ('' if pts == points else f' (reduced from {points} pts to stay inside the time bound)'))
     return dict(value=None, unit='scenes/s', cores=cores, kind='port', sample='timed out')
 
@@ -124,31 +163,39 @@ def log(msg: str):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
-def main():
-    args = parse()
-    if args.batch is None:
-        args.batch = 16 if args.dtype == 'bf16' else 8
+FAMILY_NAMES = ('conv_gmm', 'conv_wgrad', 'attn_fwd', 'attn_bwd', 'gemm')
+
+
+def _pmc_traffic(bf: bool):
+    """HBM bytes per spconv_gmm_k launch from the newest committed PMC pass of this command whose spconv.hip hash matches the
+    kernel timed here (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950)."""
+    import glob
+    import hashlib
+    if bf:
+        return None, None
+    sha = hashlib.sha256(open(os.path.join(ROOT, 'unidet3d_amd', 'csrc', 'spconv.hip'), 'rb').read()).hexdigest()[:16]
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_traffic.json')), reverse=True)
+    for f in files:
+        rec = json.load(open(f))
+        if rec.get('_meta', {}).get('spconv_hip_sha16') == sha and '_spconv_gmm_k_all' in rec:
+            return (rec['_spconv_gmm_k_all']['hbm_MB_per_launch'] * 1e6,
+                    f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command at commit "
+                    f"{rec['_meta'].get('git_head', '?')}; spconv.hip sha256/16 {sha} matches the kernel timed here)")
+    return None, (f'{len(files)} PMC file(s) under profiles/ were measured on a different spconv.hip: not reported' if files else None)
+
+
+def measure(args, dtype: str, batch: int, rank: int, world: int, dev):
+    """W untimed + K timed steps of one configuration (model, optimizer, scenes built here); returns the fields of the JSON line
+    that describe it.  Collective when world > 1 (every rank calls it with the same arguments)."""
     from unidet3d_amd import _lib as L
     from unidet3d_amd import account, precision
     from unidet3d_amd import sparse
     from unidet3d_amd.config import build_model, scannet_model_cfg
     from unidet3d_amd.data import make_batch_inputs
-    from unidet3d_amd.dist import FlatGradBucket, broadcast_params, init_from_env
+    from unidet3d_amd.dist import FlatGradBucket, broadcast_params
     from unidet3d_amd.synthetic import make_scene
 
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
-    L.lib()                                           # fail loudly if the HIP library is missing
-    if args.backend != 'nccl':
-        os.environ['LOCAL_RANK_DEVICE'] = str(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
-    local_dev = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
-    torch.cuda.set_device(local_dev)
-    rank, world, local = init_from_env(args.backend)
-    if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    dev = torch.device('cuda', local_dev)
-
-    precision.set_operand_dtype(args.dtype)
+    precision.set_operand_dtype(dtype)
     torch.manual_seed(0)
     model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)
     model.train()
@@ -158,10 +205,13 @@ def main():
     if world > 1:
         bucket.enable_overlap()              # 16 MB buckets, all-reduced over RCCL as backward completes them (a collective
                                              # call: every rank takes the same path, a failure is fatal on all of them)
-    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)      # configs/unidet3d_1xb8_scannet.py:712
+    if args.optimizer == 'sgd':
+        opt = torch.optim.SGD(params, lr=1e-3)
+    else:
+        opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)      # configs/unidet3d_1xb8_scannet.py:712
 
-    log(f'rank {rank}/{world}: model built, generating {args.batch} scenes')
-    scenes = [make_scene(rank * args.batch + i, n_points=args.points) for i in range(args.batch)]
+    log(f'rank {rank}/{world}: [{dtype}] model built, generating {batch} scenes')
+    scenes = [make_scene(rank * batch + i, n_points=args.points) for i in range(batch)]
     inputs, samples = make_batch_inputs(scenes, dev)                              # resident in HBM before timing
 
     inflight = collections.deque()
@@ -194,14 +244,15 @@ def main():
         torch.cuda.synchronize()
 
     sparse.set_profile_flops(True)      # launches carry their algorithmic flops (pair counts cached during warm-up)
-    log('inputs resident, warm-up')
+    log(f'[{dtype}] inputs resident, warm-up')
+    warm_losses = []
     for i in range(max(args.warmup, 1)):
         loss = step()
         torch.cuda.synchronize()
-        log(f'warm-up step {i} done, loss {float(loss.detach()):.4f}')
+        warm_losses.append(float(loss.detach()))
+        log(f'[{dtype}] warm-up step {i} done, loss {warm_losses[-1]:.4f}')
     assert bucket.check_views(), 'p.grad does not alias the flat gradient buffer'
-    FAMILIES = (('conv_gmm', L.K_CONV_FWD), ('conv_wgrad', L.K_CONV_WGRAD), ('attn_fwd', L.K_ATTN_FWD), ('attn_bwd', L.K_ATTN_BWD),
-                ('gemm', L.K_GEMM))
+    families = tuple(zip(FAMILY_NAMES, (L.K_CONV_FWD, L.K_CONV_WGRAD, L.K_ATTN_FWD, L.K_ATTN_BWD, L.K_GEMM)))
     # ---- the timed region: exactly K steps, nothing instrumented -------------------------------------------------------
     fence()
     t0 = time.perf_counter()
@@ -209,11 +260,11 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step')
+    log(f'[{dtype}] timed region done: {dt / args.steps * 1e3:.2f} ms/step')
     # ---- per-family kernel times: HIP events around every launch of a family, on the stream it runs on, over extra steps
     # OUTSIDE the timed region (recording ~300 event pairs per step costs ~1 ms/step of host time) ----------------------
     prof_steps = max(1, min(args.steps, 5))
-    for _, c in FAMILIES:
+    for _, c in families:
         L.prof_enable(c, True)
     account.reset()
     for _ in range(prof_steps):
@@ -221,86 +272,113 @@ def main():
     torch.cuda.synchronize()
     prof = {}
     acc = account.snapshot()
-    for name, c in FAMILIES:
+    for name, c in families:
         ms, n, work = L.prof_collect(c)
         L.prof_enable(c, False)
         prof[name] = dict(ms=ms, launches=n, flops=work, bytes=acc.get(name, {}).get('bytes', 0.0),
                           flops_booked=acc.get(name, {}).get('flops', 0.0))
+    sparse.set_profile_flops(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(loss.item())
+    n_vox = int(model._vb.coords.shape[0])
+    inflight.clear()
+    del model, opt, bucket, params, inputs, samples
+    torch.cuda.empty_cache()
+
+    bf = dtype == 'bf16'
+    # which MFMA peak prices a family: the bf16-operand kernels exist for the sparse conv forward / input gradient, the
+    # decoder's NT GEMMs and attention; weight gradients keep fp32 operands below 64x64 channels
+    peak = {k: (PEAK_BF16_MFMA_TFLOPS if bf and k in ('conv_gmm', 'attn_fwd', 'attn_bwd') else PEAK_F32_MFMA_TFLOPS) for k in prof}
+    kernels = {}
+    for k, v in prof.items():
+        t = v['ms'] * 1e-3
+        tf = v['flops'] / t / 1e12 if t > 0 and v['flops'] > 0 else None
+        gbs = v['bytes'] / t / 1e9 if t > 0 and v['bytes'] > 0 else None
+        kernels[k] = {'ms_per_step': v['ms'] / prof_steps, 'launches_per_step': v['launches'] / prof_steps,
+                      'algorithmic_gflop_per_step': v['flops'] / prof_steps / 1e9, 'algorithmic_MB_per_step': v['bytes'] / prof_steps / 1e6,
+                      'tflops': tf, 'mfma_peak': peak[k] if k != 'gemm' else ('mixed' if bf else PEAK_F32_MFMA_TFLOPS),
+                      'frac_mfma': (tf / peak[k] if tf and (k != 'gemm' or not bf) else None),
+                      'hbm_gbs': gbs, 'frac_hbm': gbs / PEAK_HBM_GBS if gbs else None}
+    g = prof['conv_gmm']
+    ach = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
+    traffic, traffic_src = _pmc_traffic(bf)
+    fam_ms = sum(v['ms'] for v in prof.values())
+    return {
+        'value': batch * world * args.steps / dt,
+        'unit': 'scenes/s',
+        'ms_per_step': dt / args.steps * 1e3,
+        'dtype': 'bf16' if bf else 'f32',
+        'config': {'workload': f'{"cfg3" if bf else "cfg2"}: {batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
+                               f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, '
+                               + ('bf16 MFMA operands (sparse conv fwd/dgrad/wgrad, Linear fwd/dX/dW, attention), fp32 accumulate/BN/softmax/optimizer; '
+                                  if bf else 'fp32; ') +
+                               'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else f'+clip+{args.optimizer}')
+                               + ('' if args.no_prefetch else "; each step's voxelise+rulebook part is queued on a side stream during "
+                                  "the previous step's backward"),
+                   'front_prefetch': not args.no_prefetch,
+                   'global_batch': batch * world, 'points_per_scene': args.points,
+                   'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val, 'warmup_losses': warm_losses},
+        'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
+                     'bound': 'mfma', 'achieved': ach, 'peak': peak['conv_gmm'], 'unit': 'TFLOP/s',
+                     'frac': ach / peak['conv_gmm'], 'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
+                     'traffic_source': traffic_src,
+                     'algorithmic_bytes_per_launch': g['bytes'] / max(g['launches'], 1),
+                     'hbm_achieved_gbs': kernels['conv_gmm']['hbm_gbs'], 'hbm_frac': kernels['conv_gmm']['frac_hbm'],
+                     'launches': g['launches'], 'avg_launch_us': g['ms'] * 1e3 / max(g['launches'], 1),
+                     'algorithmic_gflop_per_launch': g['flops'] / max(g['launches'], 1) / 1e9,
+                     'share_of_step': (g['ms'] / prof_steps) / (dt / args.steps * 1e3),
+                     'timing': f'HIP events around each launch over {prof_steps} instrumented steps run after the timed region'},
+        'kernels': kernels,
+        'step_roofline': {
+            'note': 'all five timed families: sum of algorithmic flops / (sum of their time); HBM side: sum of algorithmic bytes / time',
+            'families_ms_per_step': fam_ms / prof_steps,
+            'tflops': sum(v['flops'] for v in prof.values()) / max(fam_ms * 1e-3, 1e-12) / 1e12,
+            'hbm_gbs': sum(v['bytes'] for v in prof.values()) / max(fam_ms * 1e-3, 1e-12) / 1e9,
+            'share_of_step': (fam_ms / prof_steps) / (dt / args.steps * 1e3)},
+    }
+
+
+def main():
+    args = parse()
+    self_launch(args)                                  # N > 1 outside torchrun: does not return
+    from unidet3d_amd import _lib as L
+    from unidet3d_amd.dist import init_from_env
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    L.lib()                                           # fail loudly if the HIP library is missing
+    n_dev = torch.cuda.device_count()
+    if args.backend == 'nccl' and args.gpus > n_dev:
+        raise SystemExit(f'--gpus {args.gpus} with the RCCL backend needs {args.gpus} GPUs, this node shows {n_dev} '
+                         "(--backend gloo lets ranks share a GPU to exercise the code path)")
+    local_dev = int(os.environ.get('LOCAL_RANK', '0')) % n_dev
+    torch.cuda.set_device(local_dev)
+    rank, world, local = init_from_env(args.backend)
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    dev = torch.device('cuda', local_dev)
+
+    head_batch = args.batch if args.batch is not None else (16 if args.dtype == 'bf16' else 8)
+    head = measure(args, args.dtype, head_batch, rank, world, dev)
+    cfg3 = None
+    if args.dtype == 'fp32' and not args.no_cfg3:
+        # BASELINE.json configs[2] right behind the headline, same process, same protocol (W warm-up + K timed steps)
+        cfg3 = measure(args, 'bf16', 16, rank, world, dev)
 
     if rank == 0:
-        bf = args.dtype == 'bf16'
-        # which MFMA peak prices a family: the bf16-operand kernels exist for the sparse conv forward / input gradient, the
-        # decoder's NT GEMMs and attention; weight gradients (sparse and dense) keep fp32 operands
-        peak = {k: (PEAK_BF16_MFMA_TFLOPS if bf and k in ('conv_gmm', 'attn_fwd', 'attn_bwd') else PEAK_F32_MFMA_TFLOPS) for k in prof}
-        kernels = {}
-        for k, v in prof.items():
-            t = v['ms'] * 1e-3
-            tf = v['flops'] / t / 1e12 if t > 0 and v['flops'] > 0 else None
-            gbs = v['bytes'] / t / 1e9 if t > 0 and v['bytes'] > 0 else None
-            kernels[k] = {'ms_per_step': v['ms'] / prof_steps, 'launches_per_step': v['launches'] / prof_steps,
-                          'algorithmic_gflop_per_step': v['flops'] / prof_steps / 1e9, 'algorithmic_MB_per_step': v['bytes'] / prof_steps / 1e6,
-                          'tflops': tf, 'mfma_peak': peak[k] if k != 'gemm' else ('mixed' if bf else PEAK_F32_MFMA_TFLOPS),
-                          'frac_mfma': (tf / peak[k] if tf and (k != 'gemm' or not bf) else None),
-                          'hbm_gbs': gbs, 'frac_hbm': gbs / PEAK_HBM_GBS if gbs else None}
-        g = prof['conv_gmm']
-        ach = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
-        n_vox = int(model._vb.coords.shape[0])
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'round2_pmc_traffic.json')
-        if os.path.exists(tpath) and not bf:   # PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KB) of this same command, tools/pmc_bench.sh
-            import hashlib
-            rec = json.load(open(tpath))
-            sha = hashlib.sha256(open(os.path.join(ROOT, 'unidet3d_amd', 'csrc', 'spconv.hip'), 'rb').read()).hexdigest()[:16]
-            if rec.get('_meta', {}).get('spconv_hip_sha16') == sha:        # stale counters are not reported
-                traffic = rec['_spconv_gmm_k_all']['hbm_MB_per_launch'] * 1e6
-                traffic_src = (f"profiles/round2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
-                               f"command at commit {rec['_meta'].get('git_head', '?')}; spconv.hip sha256/16 {sha} matches the kernel timed here)")
-            else:
-                traffic_src = 'profiles/round2_pmc_traffic.json was measured on a different spconv.hip: not reported'
-        out = {
-            'metric': METRIC,
-            'value': args.batch * world * args.steps / dt,
-            'unit': 'scenes/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if bf else 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{"cfg3" if bf else "cfg2"}: {args.batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
-                                   f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, '
-                                   + ('bf16 MFMA operands (sparse conv fwd/dgrad, Linear fwd/dX, attention), fp32 accumulate/BN/softmax/optimizer; '
-                                      if bf else 'fp32; ') +
-                                   'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else '+clip+AdamW')
-                                   + ('' if args.no_prefetch else "; each step's voxelise+rulebook part is queued on a side stream during "
-                                      "the previous step's backward"),
-                       'front_prefetch': not args.no_prefetch,
-                       'global_batch': args.batch * world, 'points_per_scene': args.points,
-                       'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val},
-            'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
-                         'bound': 'mfma', 'achieved': ach, 'peak': peak['conv_gmm'], 'unit': 'TFLOP/s',
-                         'frac': ach / peak['conv_gmm'], 'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
-                         'traffic_source': traffic_src,
-                         'algorithmic_bytes_per_launch': g['bytes'] / max(g['launches'], 1),
-                         'hbm_achieved_gbs': kernels['conv_gmm']['hbm_gbs'], 'hbm_frac': kernels['conv_gmm']['frac_hbm'],
-                         'launches': g['launches'], 'avg_launch_us': g['ms'] * 1e3 / max(g['launches'], 1),
-                         'algorithmic_gflop_per_launch': g['flops'] / max(g['launches'], 1) / 1e9,
-                         'share_of_step': (g['ms'] / prof_steps) / (dt / args.steps * 1e3),
-                         'timing': f'HIP events around each launch over {prof_steps} instrumented steps run after the timed region'},
-            'kernels': kernels,
-            'step_roofline': {
-                'note': 'all five timed families: sum of algorithmic flops / (sum of their time); HBM side: sum of algorithmic bytes / time',
-                'families_ms_per_step': sum(v['ms'] for v in prof.values()) / prof_steps,
-                'tflops': sum(v['flops'] for v in prof.values()) / max(sum(v['ms'] for v in prof.values()) * 1e-3, 1e-12) / 1e12,
-                'hbm_gbs': sum(v['bytes'] for v in prof.values()) / max(sum(v['ms'] for v in prof.values()) * 1e-3, 1e-12) / 1e9,
-                'share_of_step': (sum(v['ms'] for v in prof.values()) / prof_steps) / (dt / args.steps * 1e3)},
-        }
+        out = {'metric': METRIC, 'value': head['value'], 'unit': head['unit'], 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': head['dtype'], 'data': 'synthetic', 'config': head['config'], 'roofline': head['roofline'],
+               'kernels': head['kernels'], 'step_roofline': head['step_roofline']}
+        if cfg3 is not None:
+            out['cfg3'] = dict(note='BASELINE.json configs[2] measured after the headline in the same process: bf16 MFMA operands, 16 scenes/GPU; '
+                                    'families priced against the bf16 dense MFMA peak where their operands are bf16', **cfg3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.points, args.voxel_size)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,7 +17,34 @@ def test_defaults_are_one_gpu_and_a_run_of_minutes(monkeypatch):
     a = bench.parse()
     assert bench.METRIC == json.load(open(os.path.join(ROOT, 'BASELINE.json')))['metric']
     assert a.gpus == 1 and 1 <= a.steps <= 50 and a.warmup >= 1 and a.dtype == 'fp32' and a.points == 100_000
-    assert not a.no_prefetch and not a.no_optimizer and not a.no_cpu_baseline
+    assert not a.no_prefetch and not a.no_optimizer and not a.no_cpu_baseline and not a.no_cfg3 and a.optimizer == 'adamw'
+
+
+def test_gpus_n_turns_itself_into_a_torchrun_launch(monkeypatch):
+    """`python bench.py --gpus N` (how the driver invokes it) must not need an outer torchrun: with WORLD_SIZE unset it execs
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`; inside a
+    torchrun environment (WORLD_SIZE set) and for N = 1 it does nothing."""
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    cmd = bench.launch_command(4, argv, 12345)
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '12345'
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, 'bench.py') and cmd[-len(argv):] == argv
+    seen = {}
+    monkeypatch.setattr(os, 'execvpe', lambda f, a, e: seen.update(file=f, args=a, env=e))
+    monkeypatch.setattr(sys, 'argv', ['bench.py'] + argv)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    bench.self_launch(bench.parse())
+    assert seen['args'][-len(argv):] == argv and '--nproc-per-node=4' in seen['args'] and seen['file'] == sys.executable
+    seen.clear()
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    bench.self_launch(bench.parse())                       # already inside torchrun
+    assert not seen
+    monkeypatch.delenv('WORLD_SIZE')
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    bench.self_launch(bench.parse())                       # N = 1
+    assert not seen
 
 
 def test_kept_bench_lines_follow_the_contract():

@@ -84,3 +84,22 @@ def test_two_ranks_equal_one_process_with_both_scenes():
     # synchronized statistics: running stats after one step equal the single-process ones
     assert torch.allclose(got['rm'], model.output_layer[0].running_mean.cpu(), rtol=1e-3, atol=1e-5)
     assert torch.allclose(got['rv'], model.unet.u.u.blocks[0].conv_branch[0].running_var.cpu(), rtol=1e-3, atol=1e-5)
+
+
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` exactly as the driver would call it for N > 1 -- no outer torchrun; gloo lets the two ranks share
+    this box's single GPU -- must come back with ONE JSON line for n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                          '--points', '20000', '--no-cpu-baseline', '--no-cfg3'], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 16
+    assert d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert abs(d['value'] - 16 / d['ms_per_step'] * 1e3) < 1e-6 * d['value']

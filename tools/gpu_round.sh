@@ -15,5 +15,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o b -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /dev/null
 cd $R
 S=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
-[ -n "$S" ] && cp $S $OUT/kernel_stats.csv && python tools/stats_summary.py $OUT/kernel_stats.csv 8 45 > $OUT/summary.txt && head -12 $OUT/summary.txt
+[ -n "$S" ] && cp $S $OUT/kernel_stats.csv && python tools/stats_summary.py $OUT/kernel_stats.csv auto 45 > $OUT/summary.txt && head -12 $OUT/summary.txt
 find $OUT/prof -name "*.csv" -size +1M -delete

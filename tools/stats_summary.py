@@ -1,17 +1,30 @@
-"""Summarise a rocprofv3 --stats kernel_stats.csv: python tools/stats_summary.py file.csv n_steps"""
+"""Summarise a rocprofv3 --stats kernel_stats.csv: python tools/stats_summary.py file.csv [n_steps|auto] [n_rows]
+The number of profiled steps is derived from the trace itself (auto, the default): the decoder runs attn_fwd_k once per layer and
+step, so steps = calls(attn_fwd*_k) / 6 for the 6-layer ScanNet model (U3D_DECODER_LAYERS overrides 6) -- a hand-passed count
+was wrong by one step in round 2 (warm-up + timed + instrumented steps all appear in the trace)."""
 import collections
 import csv
 import re
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+import os
+arg = sys.argv[2] if len(sys.argv) > 2 else 'auto'
+if arg == 'auto':
+    layers = int(os.environ.get('U3D_DECODER_LAYERS', '6'))
+    calls = sum(int(r['Calls']) for r in rows if re.search(r'attn_fwd(_bf16)?_k', r['Name']))
+    assert calls and calls % layers == 0, f'cannot derive the step count: {calls} attn_fwd launches for {layers} layers'
+    steps = calls / layers
+    print(f'steps in this trace: {steps:.0f} (= {calls} attn_fwd launches / {layers} decoder layers)')
+else:
+    steps = float(arg)
 tot = sum(int(r['TotalDurationNs']) for r in rows)
 print(f'GPU busy {tot / steps / 1e6:.2f} ms/step, {sum(int(r["Calls"]) for r in rows) / steps:.0f} kernels/step')
 
 
 def grp(n):
-    if 'spconv_gmm' in n or 'gmm_reduce' in n: return 'u3d conv fwd+dgrad (spconv_gmm_k)'
+    if 'spconv_gmm' in n: return 'u3d conv fwd+dgrad (spconv_gmm_k)'
+    if 'gmm_reduce' in n: return 'u3d conv offset-group reduce (gmm_reduce_k)'
     if 'spconv_wgrad' in n: return 'u3d conv wgrad'
     if 'attn_' in n: return 'u3d attention'
     if 'bn_' in n: return 'u3d batch norm'

@@ -66,6 +66,20 @@ def test_prefetch_is_a_no_op_off_gpu_and_tensor_walk_finds_nested_tensors():
     t1, t2, t3 = torch.zeros(2), torch.ones(3), torch.arange(4)
     seen = list(_tensors_of(dict(a=[t1, (Box(t2),)], b=dict(c=t3), d=7, e='x', f=t1)))
     assert seen == []                                   # CPU tensors are not stream-managed: nothing to record
+
+    class Slotted:                                      # no __dict__: attributes live in __slots__
+        __slots__ = ('t', 'more')
+
+        def __init__(self, t, more):
+            self.t, self.more = t, more
+    deep = t3
+    for _ in range(40):                                 # far beyond any fixed depth cap
+        deep = [dict(x=deep)]
+    found = list(_tensors_of(dict(a=[t1, (Box(t2),)], s=Slotted(t1, Slotted(t2, None)), deep=deep, f=t1), cuda_only=False))
+    assert len(found) == 3 and {id(t) for t in found} == {id(t1), id(t2), id(t3)}
+    import pytest
+    with pytest.raises(TypeError):                      # an object the walk cannot look into must not be skipped silently
+        list(_tensors_of([object()], cuda_only=False))
     model = build_model(scannet_model_cfg(voxel_size=0.05))
     model.prefetch(dict(points=[torch.zeros(10, 6)]), [])
     assert model._prefetched is None

@@ -289,7 +289,8 @@ class UniDet3DCriterion:
         # no match anywhere in the batch: the reference adds the Python int 0 (criterion.py:137-138).  Same value here, but
         # connected to the graph so that every parameter receives a gradient on every rank (the data-parallel bucket
         # schedule relies on it)
-        bbox_loss = torch.stack(bbox_losses).mean() if bbox_losses else sum(b.sum() for b in pred_bboxes) * 0
+        # (b * 0 would turn an overflowed box parameter -- exp() of a large prediction -- into NaN where the reference returns 0)
+        bbox_loss = torch.stack(bbox_losses).mean() if bbox_losses else sum(torch.nan_to_num(b, nan=0.0, posinf=0.0, neginf=0.0).sum() for b in pred_bboxes) * 0
         return self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss
 
     # ---- packed fast path ---------------------------------------------------------------------
@@ -414,7 +415,14 @@ class UniDet3DCriterion:
         return _FusedCriterionFn.apply(cls, box, g, consts)
 
     def _fusable(self):
-        c = self.matcher.costs[1]
+        """The fused kernel hard-codes the ScanNet config's matcher (configs/unidet3d_1xb8_scannet.py:75-84): exactly
+        [QueryClassificationCost, BboxCostJointTraining] in this order, DIoU with weight 1 and no reduction inside the cost."""
+        costs = self.matcher.costs
+        if len(costs) != 2 or not isinstance(costs[0], QueryClassificationCost) or not isinstance(costs[1], BboxCostJointTraining):
+            return False
+        c = costs[1]
+        if getattr(c.loss_simple, 'reduction', None) != 'none':
+            return False
         return (isinstance(c.loss_simple, UniDet3DAxisAlignedIoULoss) and c.loss_simple.mode == 'diou' and c.loss_simple.loss_weight == 1.0 and
                 isinstance(self.bbox_loss_simple, UniDet3DAxisAlignedIoULoss) and self.bbox_loss_simple.mode == 'diou' and
                 self.bbox_loss_simple.loss_weight == 1.0 and self.bbox_loss_simple.reduction == 'none')

@@ -621,7 +621,12 @@ int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W
     return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, bf, nullptr, nullptr, f2, (hipStream_t)stream);
 }
 
-int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) { return (int64_t)tn_splits(M, N, K, GT, false) * ((int64_t)N * K + N) * 4 + 256; }   // the case with the most splits
+int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) {
+    // the fp32 and the bf16 kernel pick their split counts independently (U3D_TN_WGS moves only the former): size for the larger
+    const int s32 = tn_splits(M, N, K, GT, false), s32b = tn_splits(M, N, K, tn_tile(N, K), false), s16 = tn_splits(M, N, K, GT, true);
+    const int smax = s32 > s16 ? (s32 > s32b ? s32 : s32b) : (s16 > s32b ? s16 : s32b);
+    return (int64_t)(smax + 8) * ((int64_t)N * K + N) * 4 + 256;       // + 8: the fp32 grid is padded to whole groups of 8 splits
+}
 
 static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_A, int64_t M, int N, int K, void* ws, double flops_hint,
                         u3d_stream_t stream, bool bf) {

@@ -51,4 +51,10 @@ class Det3DDataPreprocessor_(nn.Module):
                         for k, v in list(vars(obj).items()):
                             if torch.is_tensor(v) or isinstance(v, np.ndarray) or hasattr(v, 'tensor'):
                                 setattr(obj, k, _to_device(v, dev))
+        if dev.type == 'cuda':
+            # the uploads above are asynchronous on the current stream: a consumer on another stream (UniDet3D.prefetch) waits
+            # for this event before it reads the batch
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            out['ready_event'] = ev
         return dict(inputs=out, data_samples=samples)

@@ -173,7 +173,7 @@ def nms_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Ten
     bboxes, scores, labels = bboxes[sel], scores[sel], labels[sel]
     n = bboxes.shape[0]
     if n == 0:
-        return bboxes.new_zeros((0, bboxes.shape[1])), bboxes.new_zeros((0,)), labels.new_zeros((0,))
+        return bboxes.new_zeros((0, bboxes.shape[1])), bboxes.new_zeros((0,)), bboxes.new_zeros((0,))      # unidet3d.py:645-648: all three from `bboxes`
     order = torch.sort(labels, stable=True).indices            # (label asc, score desc)
     b = bboxes[order].contiguous().float()
     lab = labels[order].to(torch.int32).contiguous()

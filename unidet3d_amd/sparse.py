@@ -159,10 +159,17 @@ _PACKED: Dict = {}          # (weight data_ptr, transposed, bf16) -> (buffer, we
 
 class WeightPacks:
     """MFMA-fragment-order copies (u3d_weight_pack[_bf16]) of every convolution weight of a module tree, both orientations,
-    refreshed by ONE launch (u3d_weight_pack_batch) whenever a weight changed since the last refresh -- i.e. once per optimizer
-    step -- instead of one pack launch in front of each of the ~90 convolution launches of a step."""
+    refreshed by ONE launch (u3d_weight_pack_batch) instead of one pack launch in front of each of the ~90 convolution launches
+    of a step.
+
+    Validity contract: in TRAINING mode every ``refresh()`` repacks (one launch per step -- what a changed weight costs anyway),
+    so no writer can leave a stale pack behind.  In eval mode a pack is reused while ``(data_ptr, Tensor._version)`` of every
+    weight is unchanged; ``_version`` is bumped by optimizers, ``load_state_dict`` and in-place ops on the parameter, but NOT by
+    writes through ``.data`` (``p.data.copy_()``, mmengine's EMAHook parameter swap, legacy optimizers): such a writer must
+    call ``invalidate()`` (``UniDet3D.invalidate_weight_packs()``) afterwards."""
 
     def __init__(self, root: nn.Module):
+        self.root = root
         self.convs = [m for m in root.modules() if isinstance(m, _ConvBase) and m.in_channels % 16 == 0 and m.kernel_size != 1]
         self.state = None
         self.bufs: Dict = {}
@@ -173,13 +180,20 @@ class WeightPacks:
         for key in list(getattr(self, 'bufs', {})):
             _PACKED.pop(key, None)
 
+    def invalidate(self):
+        """Forget the packs (for writers that bypass ``Tensor._version``, see the class docstring)."""
+        if self.state is not None:
+            self.state = self.state[:2] + (tuple((a, -1) for a, _ in self.state[2]),)
+        for key, (buf, w) in self.bufs.items():
+            _PACKED[key] = (buf, w, -1)
+
     def refresh(self):
         if not self.convs:
             return
         bf = P.bf16()
         dev = self.convs[0].weight.device
         state = (bf, str(dev), tuple((m.weight.data_ptr(), m.weight._version) for m in self.convs))
-        if state == self.state:
+        if state == self.state and not self.root.training:
             return
         rebuild = self.state is None or self.state[0] != bf or self.state[1] != str(dev) or \
             [a for a, _ in self.state[2]] != [a for a, _ in state[2]]

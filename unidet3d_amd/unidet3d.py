@@ -12,8 +12,10 @@ preprocessor: ``batch_inputs_dict['points']`` = List[Tensor[N_i, 6]] on the devi
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List, Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -24,24 +26,40 @@ from .sparse import SparseBatchNorm, SparseConvTensor, SparseSequential, SubMCon
 from .structures import DepthInstance3DBoxes, InstanceData_
 
 
-def _tensors_of(obj, _seen=None, _depth=0):
-    """every CUDA tensor reachable from ``obj`` through lists / tuples / dicts / object attributes"""
-    if _seen is None:
-        _seen = set()
-    if id(obj) in _seen or _depth > 8:
-        return
-    _seen.add(id(obj))
-    if isinstance(obj, torch.Tensor):
-        if obj.is_cuda:
-            yield obj
-    elif isinstance(obj, (list, tuple)):
-        for o in obj:
-            yield from _tensors_of(o, _seen, _depth + 1)
-    elif isinstance(obj, dict):
-        for o in obj.values():
-            yield from _tensors_of(o, _seen, _depth + 1)
-    elif hasattr(obj, '__dict__') and not isinstance(obj, (nn.Module, type)):
-        yield from _tensors_of(vars(obj), _seen, _depth + 1)
+def _tensors_of(obj, cuda_only: bool = True):
+    """Every CUDA tensor reachable from ``obj`` through lists / tuples / sets / dicts and object attributes (``__dict__`` and
+    ``__slots__``), to any depth.  The walk exists to ``record_stream`` tensors that cross from the side stream to the main one:
+    a tensor it missed could be recycled by the caching allocator while still in use, so an object it cannot look into raises."""
+    seen, stack = set(), [obj]
+    while stack:
+        o = stack.pop()
+        if id(o) in seen:
+            continue
+        seen.add(id(o))
+        if isinstance(o, torch.Tensor):
+            if o.is_cuda or not cuda_only:
+                yield o
+        elif o is None or isinstance(o, (str, bytes, int, float, complex, bool, type, range, slice, nn.Module, torch.device, torch.dtype,
+                                         torch.Size, np.generic, np.ndarray, torch.cuda.Event, torch.cuda.Stream)):
+            continue
+        elif isinstance(o, dict):
+            stack.extend(o.values())
+        elif isinstance(o, (list, tuple, set, frozenset)):
+            stack.extend(o)
+        else:
+            found = False
+            if hasattr(o, '__dict__'):
+                stack.extend(vars(o).values())
+                found = True
+            for klass in type(o).__mro__:
+                slots = klass.__dict__.get('__slots__', ())
+                for name in ((slots,) if isinstance(slots, str) else slots):
+                    found = True
+                    if name not in ('__dict__', '__weakref__') and hasattr(o, name):
+                        stack.append(getattr(o, name))
+            if not found and not callable(o):
+                raise TypeError(f'prefetch: cannot look for tensors inside a {type(o).__name__}; hand batches over as '
+                                'lists / dicts / attribute objects')
 
 
 @MODELS.register_module()
@@ -241,8 +259,10 @@ class UniDet3D(nn.Module):
         backward pass still executing on the main stream (a training loop calls this right after ``optimizer.step()`` has
         been queued; ``loss`` picks the result up when it is handed the same two objects).  Without it every step starts
         with the GPU idle: the first read-back of the voxeliser drains the queue and ~3 ms of launch-latency-bound
-        integer work follow.  The batch tensors must be complete on the device (``ready_event``: an event the side stream
-        waits for, e.g. the end of their upload); they are only read."""
+        integer work follow.  The batch tensors are only read, but they must be complete on the device before the side
+        stream touches them: pass ``ready_event`` (an event recorded after their upload) or put it into the batch as
+        ``batch_inputs_dict['ready_event']`` (``Det3DDataPreprocessor_`` does); without either the tensors must have been
+        produced before the call by work the host has already waited for, or on the side stream itself (``prefetch_step``)."""
         pts = batch_inputs_dict['points']
         if not len(pts) or pts[0].device.type != 'cuda':
             return
@@ -250,6 +270,8 @@ class UniDet3D(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(dev)
         main = torch.cuda.current_stream(dev)
+        if ready_event is None:
+            ready_event = batch_inputs_dict.get('ready_event')
         with torch.cuda.stream(self._side_stream):
             if ready_event is not None:
                 self._side_stream.wait_event(ready_event)
@@ -332,11 +354,21 @@ class UniDet3D(nn.Module):
         """One optimisation step as ``BaseModel.train_step`` performs it: preprocess, forward(mode='loss'), parse the loss
         dict, ``optim_wrapper.update_params(loss)`` (mmengine ``OptimWrapper`` / ``AmpOptimWrapper``, tools/train.py:86-99)."""
         staged, self._staged = self._staged, None
-        data = staged[1] if staged is not None and staged[0] is data else self._prep(data, True)
-        losses = self(data['inputs'], data['data_samples'], mode='loss')
-        total, log = self.parse_losses(losses)
+        # mmengine enters optim_wrapper.optim_context(self) around preprocessing + forward + parse_losses: AmpOptimWrapper turns
+        # autocast on there, and with accumulative_counts > 1 it is where DDP's no_sync / the accumulation bookkeeping live
+        ctx = optim_wrapper.optim_context(self) if hasattr(optim_wrapper, 'optim_context') else contextlib.nullcontext()
+        with ctx:
+            data = staged[1] if staged is not None and staged[0] is data else self._prep(data, True)
+            losses = self(data['inputs'], data['data_samples'], mode='loss')
+            total, log = self.parse_losses(losses)
         optim_wrapper.update_params(total)
         return log
+
+    def invalidate_weight_packs(self):
+        """For code that writes convolution weights through ``.data`` (which does not bump ``Tensor._version``; e.g. an EMA
+        parameter swap) while the model is in eval mode: the MFMA-order weight copies are rebuilt at the next forward."""
+        if self._packs is not None:
+            self._packs.invalidate()
 
     def prefetch_step(self, data):
         """``prefetch`` for loops that drive the model through ``train_step``: preprocess the NEXT raw batch (host -> device copies

@@ -88,10 +88,19 @@ def oracle_forward(orac, scenes, names, crit_cfg=None, det_cfg=None, gt_boxes=No
     return dict(feats=feats, out=out, loss=loss, coords=x.indices, centers=cent, insts=insts)
 
 
-def product_forward(prod, inputs, samples):
-    """One training pass of the product with the decoder input / output captured (the tensors the loss really used)."""
+def product_forward(prod, inputs, samples, relu_masks=False):
+    """One training pass of the product with the decoder input / output captured (the tensors the loss really used).
+    ``relu_masks``: also record, for every BatchNorm+ReLU of the backbone, which units came out positive (``P['relu_masks']``:
+    module name -> bool [rows, C] on the CPU; rows are in canonical order, the same as the oracle's)."""
+    from unidet3d_amd.sparse import SparseBatchNorm
     seen = {}
     orig = prod.extract_feat
+    hooks, masks = [], {}
+    if relu_masks:
+        for name, m in prod.named_modules():
+            if isinstance(m, SparseBatchNorm):
+                hooks.append(m.register_forward_hook(
+                    lambda mod, i, o, name=name: masks.__setitem__(name, ((o[0] if isinstance(o, tuple) else o) > 0).cpu())))
 
     def spy(*a, **k):
         r = orig(*a, **k)
@@ -103,8 +112,68 @@ def product_forward(prod, inputs, samples):
         loss = prod.loss(inputs, samples)['det_loss']
     finally:
         h.remove()
+        for hk in hooks:
+            hk.remove()
         prod.extract_feat = orig
-    return dict(loss=loss, feats=seen['feats'], out=seen['out'], coords=prod._vb.coords)
+    return dict(loss=loss, feats=seen['feats'], out=seen['out'], coords=prod._vb.coords, relu_masks=masks)
+
+
+class _MaskedReLU(torch.nn.Module):
+    """ReLU with the on/off decision of every unit given from outside: y = x * mask."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        assert x.shape == self.mask.shape, (x.shape, self.mask.shape)
+        return x * self.mask.to(x.dtype)
+
+
+def bn_relu_pairs(model):
+    """(name of the BatchNorm1d, its container, key of the ReLU behind it) for every BatchNorm -> ReLU pair of an oracle model."""
+    for sname, seq in model.named_modules():
+        if isinstance(seq, torch.nn.Sequential):
+            keys = list(seq._modules)
+            for a, b in zip(keys, keys[1:]):
+                if isinstance(seq._modules[a], torch.nn.BatchNorm1d) and isinstance(seq._modules[b], (torch.nn.ReLU, _MaskedReLU)):
+                    yield (f'{sname}.{a}' if sname else a), seq, b
+
+
+def oracle_relu_masks(orac, run):
+    """The ReLU decisions of an oracle run (fp32 or fp64): name -> bool [rows, C]; also returns the run's output dict."""
+    mods, masks, hooks = dict(orac.named_modules()), {}, []
+    for name, _, _ in bn_relu_pairs(orac):
+        hooks.append(mods[name].register_forward_hook(lambda m, i, o, name=name: masks.__setitem__(name, (o > 0).detach())))
+    try:
+        O = run(orac)
+    finally:
+        for h in hooks:
+            h.remove()
+    return masks, O
+
+
+def oracle_fp64_grads_same_activation_pattern(orac, run, masks):
+    """fp64 gradients of the oracle on the SAME piece of the piecewise-smooth function the product evaluated: every
+    BatchNorm -> ReLU of the backbone takes its on/off decisions from ``masks`` (the product's own forward, product_forward(...,
+    relu_masks=True)) instead of re-deciding them in fp64.
+    Why: the backbone has ~10^6 BN+ReLU units per scene, so a few pre-activations always lie within fp32 rounding of zero (cfg1:
+    one unit at 3e-8 in fp64, -2.5e-6 in fp32, in a level of 61 voxels).  Which side such a unit falls on differs between fp64 and
+    ANY fp32 evaluation (the CPU oracle at 1 / 8 / 16 threads falls on the product's side, at 4 threads on the other), and one
+    flip in a level of a few dozen voxels moves that level's weight gradients by up to 14 % (training-mode BN couples all rows).
+    With the decisions fixed the function is smooth and the fp32 CPU oracle is within 2e-4 of fp64 on every parameter
+    (profiles/round3_relu_flip_analysis.txt) -- so the product can be held to the plain 1e-3 north-star bound."""
+    import copy
+    o64 = copy.deepcopy(orac).double().train()
+    n = 0
+    for name, seq, key in list(bn_relu_pairs(o64)):
+        seq._modules[key] = _MaskedReLU(masks[name])
+        n += 1
+    assert n == len(masks), f'{n} BatchNorm+ReLU pairs in the oracle, {len(masks)} masks from the product'
+    o64.zero_grad()
+    O = run(o64)
+    O['loss'].backward()
+    return {k: p.grad for k, p in o64.named_parameters() if p.grad is not None}, O
 
 
 def oracle_fp64_grads(orac, run):
@@ -135,15 +204,55 @@ def oracle_perturbed_grads(orac, run, rel_sigma=2e-7, seed=1):
     return {k: p.grad for k, p in op.named_parameters() if p.grad is not None}
 
 
-def compare(name, P, O, prod, orac, g64=None, gpert=None):
-    """Asserts the north-star tolerances (features, logits, boxes, loss <= 1e-3 relative against the fp32 oracle) and returns /
-    logs the measured errors.  Backbone parameter gradients pass through ~90 batch-norm layers whose backward cancels the
-    mean and scale components of the incoming gradient: they are ill-conditioned in fp32 -- the CPU oracle itself moves by
-    5e-4 (median) to 4e-2 (worst parameter) of the largest entry when only the summation ORDER changes (two scenes swapped),
-    and a single ReLU unit that switches in a 20-voxel level moves a deep weight gradient by 10 %.
-    With ``g64`` (fp64 gradients of the oracle) and ``gpert`` (fp32 gradients of the oracle under a one-rounding weight
-    perturbation) the product's error against fp64 is judged against the error of that perturbed fp32 CPU run: median and
-    90th percentile over the parameters (single-unit flips make the maximum a lottery; it is logged, not asserted)."""
+def _flat(gd, keys):
+    return torch.cat([torch.as_tensor(gd[k]).detach().double().cpu().flatten() for k in keys])
+
+
+def flat_gradient_stats(runs: dict, g64: dict, keys, seed=7, n_dirs=3):
+    """L2 view of a gradient over the parameter set ``keys`` (flattened, concatenated) against the fp64 oracle:
+    cosine, relative L2 error, and the error of ``n_dirs`` random directional derivatives <g, d> (d ~ N(0, 1); and with d scaled
+    per parameter tensor by 1 / ||g64_k|| so that every tensor weighs the same whatever the size of its gradient).  ``runs``: tag -> {name: grad}.
+    A systematic error of a backward kernel (a wrong factor on one operand, a dropped term) moves the cosine and EVERY
+    directional derivative; the per-parameter max-norm statistics also react to single ReLU units that switch sides."""
+    ref = _flat(g64, keys)
+    gen = torch.Generator().manual_seed(seed)
+    dirs = [torch.randn(ref.numel(), generator=gen, dtype=torch.float64) for _ in range(n_dirs)]
+    scale = torch.cat([torch.full((g64[k].numel(),), 1.0 / (float(g64[k].double().norm()) + 1e-300), dtype=torch.float64) for k in keys])
+    out = {}
+    for tag, gd in runs.items():
+        v = _flat(gd, keys)
+        rec = dict(cos=float(torch.dot(v, ref) / (v.norm() * ref.norm() + 1e-300)), l2_rel=float((v - ref).norm() / (ref.norm() + 1e-300)))
+        # error of <g, d> relative to the TYPICAL size of a directional derivative, ||g64|| (= the standard deviation of <g64, d>
+        # over d; the realised |<g64, d>| of a single random d can be small by chance)
+        rec['dir_rel'] = [float(abs(torch.dot(v - ref, d)) / (ref.norm() + 1e-300)) for d in dirs]
+        rec['dir_rel_equalised'] = [float(abs(torch.dot(v - ref, d * scale)) / ((ref * scale).norm() + 1e-300)) for d in dirs]
+        # per-tensor cosines: the smallest one names the tensor a kernel bug would sit in
+        cs = {k: float(torch.dot(torch.as_tensor(gd[k]).double().cpu().flatten(), g64[k].double().cpu().flatten()) /
+                       (float(torch.as_tensor(gd[k]).double().norm()) * float(g64[k].double().norm()) + 1e-300)) for k in keys}
+        rec['tensor_cos_min'] = min(cs.values())
+        rec['tensor_cos_worst'] = sorted(cs.items(), key=lambda kv: kv[1])[:3]
+        out[tag] = rec
+    return out
+
+
+# Backbone-gradient acceptance against the fp64 oracle on the product's activation pattern (every bound is absolute -- no additive
+# floor, no multiple of a CPU run): each parameter tensor within 1e-3 (max-norm relative, the north-star tolerance), plus
+COS_MIN = 0.9999            # cosine of the flat backbone gradient with the fp64 oracle's
+DIR_TOL = 1e-3              # relative error of each of three random directional derivatives <g, d>
+SOFT = os.environ.get('U3D_PARITY_SOFT', '0') == '1'        # measuring runs: log everything, assert only the forward quantities
+
+
+def compare(name, P, O, prod, orac, g64=None, gpert=None, g64m=None):
+    """Asserts the north-star tolerances (features, logits, boxes, loss <= 1e-3 relative against the fp32 oracle; decoder-side
+    parameter gradients <= 1e-3) and returns / logs the measured errors.
+    Backbone parameter gradients pass through ~90 training-mode batch norms whose backward cancels the mean and scale components
+    of the incoming gradient, the deepest over a few dozen voxels: single ReLU units that switch sides move single entries by
+    several per cent -- in the CPU fp32 oracle as well (``oracle32`` below, measured against the same fp64 ground truth ``g64``:
+    identical statistics to the product's at 1 / 8 / 16 CPU threads, profiles/round3_relu_flip_analysis.txt).  Against ``g64`` (the
+    fp64 oracle deciding every ReLU itself) the errors are therefore LOGGED (per-parameter statistics, cosine, directional
+    derivatives, next to the CPU fp32 run's).  The assertion uses ``g64m``: the fp64 oracle evaluated on the product's own
+    activation pattern (``oracle_fp64_grads_same_activation_pattern``) -- there the function is smooth and every parameter
+    gradient must be within 1e-3, cosine >= COS_MIN, three random directional derivatives <= DIR_TOL."""
     n = len(O['feats'])
     assert torch.equal(P['coords'].cpu(), O['coords']), 'voxel coordinates differ from the oracle'
     err = dict(n_scenes=n, n_voxels=int(O['coords'].shape[0]),
@@ -171,28 +280,44 @@ def compare(name, P, O, prod, orac, g64=None, gpert=None):
     err['grad_backbone_max'] = max(v for k, v in grads.items() if not k.startswith('decoder.'))
     if g64 is not None:
         pp = dict(prod.named_parameters())
-        runs = {'product': {k: rel(pp[k].grad, g) for k, g in g64.items()}, 'oracle32': {k: rel(og[k].grad, g) for k, g in g64.items()}}
+        gsets = {'product': {k: pp[k].grad for k in g64}, 'oracle32': {k: og[k].grad for k in g64}}
         if gpert is not None:
-            runs['oracle32_perturbed'] = {k: rel(gpert[k], g) for k, g in g64.items()}
+            gsets['oracle32_perturbed'] = gpert
+        runs = {tag: {k: rel(gd[k], g) for k, g in g64.items()} for tag, gd in gsets.items()}
         v = {}
+        bb = [k for k in g64 if not k.startswith('decoder.')]
+        dd = [k for k in g64 if k.startswith('decoder.')]
         for tag, e in runs.items():
-            for part, keys in (('backbone', [k for k in g64 if not k.startswith('decoder.')]), ('decoder', [k for k in g64 if k.startswith('decoder.')])):
+            for part, keys in (('backbone', bb), ('decoder', dd)):
                 vals = np.array([e[k] for k in keys])
                 v[f'{tag}_{part}_median'], v[f'{tag}_{part}_p90'], v[f'{tag}_{part}_max'] = float(np.median(vals)), float(np.percentile(vals, 90)), float(vals.max())
             v[f'{tag}_worst'] = sorted(e.items(), key=lambda kv: -kv[1])[:3]
         err['vs_fp64'] = v
+        err['flat_backbone'] = flat_gradient_stats(gsets, g64, bb)
+        err['flat_decoder'] = flat_gradient_stats(gsets, g64, dd)
+    if g64m is not None:
+        # THE gradient assertion: fp64 oracle on the product's own activation pattern (oracle_fp64_grads_same_activation_pattern)
+        pp = dict(prod.named_parameters())
+        e = {k: rel(pp[k].grad, g) for k, g in g64m.items()}
+        bb = [k for k in g64m if not k.startswith('decoder.')]
+        dd = [k for k in g64m if k.startswith('decoder.')]
+        gs = {'product': {k: pp[k].grad for k in g64m}, 'oracle32': {k: og[k].grad for k in g64m}}
+        m = dict(backbone_median=float(np.median([e[k] for k in bb])), backbone_p90=float(np.percentile([e[k] for k in bb], 90)),
+                 backbone_max=max(e[k] for k in bb), decoder_max=max(e[k] for k in dd), worst=sorted(e.items(), key=lambda kv: -kv[1])[:3],
+                 flat_backbone=flat_gradient_stats(gs, g64m, bb), flat_decoder=flat_gradient_stats(gs, g64m, dd))
+        if g64 is not None:      # how many decisions differ between the product's forward and the fp64 oracle's own
+            m['l2_rel_between_fp64_patterns'] = flat_gradient_stats({'own': g64}, g64m, bb)['own']['l2_rel']
+        err['same_activation_pattern'] = m
     log_errors(name, err)
     print(name, json.dumps({k: v for k, v in err.items() if k != 'grad_worst'}))
     assert err['feats'] < 1e-3 and err['logits'] < 1e-3 and err['boxes'] < 1e-3 and err['loss'] < 1e-3, err
     assert err['grad_decoder_max'] < 1e-3, err              # well-conditioned part: the north-star tolerance applies as is
     if g64 is not None:
-        v = err['vs_fp64']
-        assert v['product_decoder_max'] < 1e-3, v
-        # ill-conditioned part: no worse than a small multiple of what fp32 arithmetic on the CPU delivers for the same quantity
-        # (the larger of the two CPU fp32 runs: which side of a ReLU threshold a run falls on is a coin toss per run)
-        def base(stat):
-            return max(v[f'oracle32_{stat}'], v.get(f'oracle32_perturbed_{stat}', 0.0))
-        assert v['product_backbone_median'] < 5 * base('backbone_median') + 2e-3, v
-        assert v['product_backbone_p90'] < 5 * base('backbone_p90') + 1e-2, v
-        assert v['product_decoder_median'] < 5 * base('decoder_median') + 1e-5, v
+        assert err['vs_fp64']['product_decoder_max'] < 1e-3, err['vs_fp64']
+    if g64m is not None and not SOFT:
+        m = err['same_activation_pattern']
+        # every parameter gradient, backbone included, at the north-star tolerance -- no additive floor, no multiple of a CPU run
+        assert m['backbone_max'] < 1e-3 and m['decoder_max'] < 1e-3, m
+        fb = m['flat_backbone']['product']
+        assert fb['cos'] >= COS_MIN and max(fb['dir_rel']) <= DIR_TOL, m['flat_backbone']
     return err

@@ -163,10 +163,13 @@ class WeightPacks:
     of a step.
 
     Validity contract: in TRAINING mode every ``refresh()`` repacks (one launch per step -- what a changed weight costs anyway),
-    so no writer can leave a stale pack behind.  In eval mode a pack is reused while ``(data_ptr, Tensor._version)`` of every
-    weight is unchanged; ``_version`` is bumped by optimizers, ``load_state_dict`` and in-place ops on the parameter, but NOT by
-    writes through ``.data`` (``p.data.copy_()``, mmengine's EMAHook parameter swap, legacy optimizers): such a writer must
-    call ``invalidate()`` (``UniDet3D.invalidate_weight_packs()``) afterwards."""
+    and the first eval-mode ``refresh()`` after a training-mode one repacks too, so no optimizer can leave a stale pack behind.
+    Otherwise (eval mode) a pack is reused while ``(data_ptr, Tensor._version)`` of every weight is unchanged.  ``_version`` is
+    bumped by torch's for-loop / foreach optimizers, ``load_state_dict`` and in-place ops on the parameter, but NOT by
+    ``torch.optim.AdamW(fused=True)`` (``_fused_adamw_`` leaves it alone -- round 2's version-keyed cache therefore ran the
+    backbone of every bench step after the first on the step-0 weights) and NOT by writes through ``.data``
+    (``p.data.copy_()``, mmengine's EMAHook parameter swap): a writer of that kind in eval mode must call ``invalidate()``
+    (``UniDet3D.invalidate_weight_packs()``) afterwards."""
 
     def __init__(self, root: nn.Module):
         self.root = root
@@ -175,6 +178,7 @@ class WeightPacks:
         self.bufs: Dict = {}
         self.desc = None
         self.blocks = 0
+        self.dirty = False          # a training-mode refresh happened: an optimizer may have stepped since
 
     def __del__(self):
         for key in list(getattr(self, 'bufs', {})):
@@ -182,6 +186,7 @@ class WeightPacks:
 
     def invalidate(self):
         """Forget the packs (for writers that bypass ``Tensor._version``, see the class docstring)."""
+        self.dirty = True
         if self.state is not None:
             self.state = self.state[:2] + (tuple((a, -1) for a, _ in self.state[2]),)
         for key, (buf, w) in self.bufs.items():
@@ -193,8 +198,9 @@ class WeightPacks:
         bf = P.bf16()
         dev = self.convs[0].weight.device
         state = (bf, str(dev), tuple((m.weight.data_ptr(), m.weight._version) for m in self.convs))
-        if state == self.state and not self.root.training:
+        if state == self.state and not self.root.training and not self.dirty:
             return
+        self.dirty = bool(self.root.training)
         rebuild = self.state is None or self.state[0] != bf or self.state[1] != str(dev) or \
             [a for a, _ in self.state[2]] != [a for a, _ in state[2]]
         if rebuild:

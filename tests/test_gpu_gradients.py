@@ -105,33 +105,35 @@ def test_eval_mode_packs_follow_data_writes_after_invalidate():
     cfg = _small_cfg()
     cfg['decoder']['num_layers'] = 1
     model = fill_state_dict(build_model(cfg), tag0=3400, scale=0.06).to(DEV)
-    inputs, samples = make_batch_inputs([make_scene(42, n_points=8000)], DEV)
+    sc = make_scene(42, n_points=8000)
+    inputs, samples = make_batch_inputs([sc], DEV)
+    sp = torch.from_numpy(sc.superpoints).to(DEV)
+    S = int(sc.superpoints.max()) + 1
 
-    def feats():
+    def run(m):
+        """per-superpoint backbone features (eval mode: batch norm on the running statistics)"""
         with torch.no_grad():
-            out = model.predict_raw(inputs, samples)
-        return out['cls_preds'][0].clone()
+            m.collate(inputs['points'])
+            return m.extract_feat(m._sparse_input(1), sp, m._vb.inverse, [0, S])[0].clone()
     # training step with a fused optimizer, then eval: the eval forward must see the stepped weights
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=True)
     model.loss(inputs, copy.deepcopy(samples))['det_loss'].backward()
     opt.step()
     model.eval()
-    a = feats()
+    a = run(model)
     fresh = build_model(cfg).to(DEV).eval()
     fresh.load_state_dict(model.state_dict(), strict=True)
-    with torch.no_grad():
-        b = fresh.predict_raw(inputs, samples)['cls_preds'][0]
+    b = run(fresh)
     assert PA.rel(a, b) < 1e-5
+    assert PA.rel(a, run(model)) < 1e-6                  # unchanged weights, unchanged (data_ptr, _version): the packs are reused
     # .data write in eval mode
     w = model.unet.blocks[0].conv_branch[2].weight
     v = w._version
     w.data.mul_(1.5)
     assert w._version == v
     model.invalidate_weight_packs()
-    c = feats()
-    assert PA.rel(a, c) > 1e-3
+    c = run(model)
+    assert PA.rel(a, c) > 1e-3, PA.rel(a, c)
     fresh.load_state_dict(model.state_dict(), strict=True)
-    with torch.no_grad():
-        d = fresh.predict_raw(inputs, samples)['cls_preds'][0]
-    assert PA.rel(c, d) < 1e-5
+    assert PA.rel(c, run(fresh)) < 1e-5

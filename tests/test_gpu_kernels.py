@@ -205,6 +205,53 @@ def test_batchnorm_relu_fwd_bwd(C, relu):
         assert _rel(bn_g(x.to(_dev()), relu=relu), ye) < 1e-5
 
 
+@pytest.mark.parametrize('cin,cout,n_points,vs', [(32, 32, 30_000, 0.02), (16, 32, 12_000, 0.05), (64, 64, 30_000, 0.02), (96, 64, 9_000, 0.05),
+                                                   (128, 128, 60_000, 0.02), (32, 96, 3_000, 0.05)])
+def test_batchnorm_statistics_from_the_convolution_epilogue(cin, cout, n_points, vs):
+    """conv -> BN(+ReLU) with the statistics taken from the per-tile column sums the convolution kernel writes on its way out
+    (no pass over the conv output) == the same pair with the norm making its own statistics pass, and == torch in float64:
+    output, running statistics, every gradient.  Shapes cover 64- and 32-row tiles, several column slices, a residual addend,
+    ragged last tiles and launches with offset groups (where the kernel writes no statistics and the norm falls back)."""
+    from unidet3d_amd import ops, sparse
+    scenes = _scene_points(2, n_points, seed0=51)
+    vb = ops.voxelize([torch.from_numpy(s.points).to(_dev()) for s in scenes], vs, 128)
+    n = vb.coords.shape[0]
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, generator=g); w = torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1
+    add = torch.randn(n, cout, generator=g); go = torch.randn(n, cout, generator=g)
+    gamma = torch.rand(cout, generator=g) + 0.5; beta = torch.randn(cout, generator=g) * 0.1
+    res = {}
+    for mode in (True, False):
+        prev, sparse._EPILOGUE_STATS = sparse._EPILOGUE_STATS, mode
+        try:
+            bn = sparse.SparseBatchNorm(cout).to(_dev())
+            bn.weight.data.copy_(gamma); bn.bias.data.copy_(beta)
+            xd, wd, ad = x.clone().to(_dev()).requires_grad_(), w.clone().to(_dev()).requires_grad_(), add.clone().to(_dev()).requires_grad_()
+            st = {}
+            f = sparse.sparse_conv(xd, wd, rb, 'fwd', ad, st)
+            assert ('partial' in st) == (mode and sparse._plan(cin, cout, 27, n)[1] == 1)
+            y = bn(f, relu=True, stats=st if 'partial' in st else None)
+            y.backward(go.to(_dev()))
+            res[mode] = dict(f=f.detach(), y=y.detach(), dx=xd.grad, dw=wd.grad, da=ad.grad, dg=bn.weight.grad, db=bn.bias.grad,
+                             rm=bn.running_mean.clone(), rv=bn.running_var.clone(), nbt=int(bn.num_batches_tracked))
+        finally:
+            sparse._EPILOGUE_STATS = prev
+    pairs = so.build_subm_rulebook(vb.coords.cpu(), vb.spatial_shape)
+    xo, wo, ao = [t.clone().double().requires_grad_() for t in (x, w, add)]
+    bo = torch.nn.BatchNorm1d(cout, eps=1e-4, momentum=0.1).double()
+    bo.weight.data.copy_(gamma); bo.bias.data.copy_(beta)
+    fo = so.sparse_conv(xo, wo, pairs, n) + ao
+    yo = torch.relu(bo(fo)); yo.backward(go.double())
+    ref = dict(f=fo, y=yo, dx=xo.grad, dw=wo.grad, da=ao.grad, dg=bo.weight.grad, db=bo.bias.grad, rm=bo.running_mean, rv=bo.running_var)
+    for mode in (True, False):
+        for k, v in ref.items():
+            assert _rel(res[mode][k], v) < 1e-4, (mode, k, _rel(res[mode][k], v))
+        assert res[mode]['nbt'] == 1
+    for k in ('y', 'dx', 'rm', 'rv'):
+        assert _rel(res[True][k], res[False][k]) < 2e-6, k
+
+
 # ---------------------------------------------------------------------------- K11 / K12
 def test_superpoint_pool_and_centers():
     from unidet3d_amd import ops

@@ -31,11 +31,11 @@ import json
 d = json.load(open('$OUT/bench_r2lib.json'))
 print('fp32 r2 lib:', round(d['value'], 1), round(d['ms_per_step'], 2), {k: round(v['ms_per_step'], 2) for k, v in d['kernels'].items()}, d['config']['warmup_losses'])
 PY
-timeout 300 python bench.py --no-cpu-baseline --no-cfg3 --optimizer sgd --steps 3 > $OUT/bench_sgd.json 2> $OUT/bench_sgd.log; grep "warm-up" $OUT/bench_sgd.log | tail -3
+
 echo "t=$(( $(date +%s) - T0 ))s"
 # counters on the sparse weight gradient (level 1 and 2)
 timeout 400 bash tools/pmc_wgrad.sh 1 8 > $OUT/pmc_wgrad_l1.txt 2>&1; tail -8 $OUT/pmc_wgrad_l1.txt | cut -c1-400
-timeout 300 bash tools/pmc_wgrad.sh 2 8 > $OUT/pmc_wgrad_l2.txt 2>&1
+
 echo "t=$(( $(date +%s) - T0 ))s"
 # kernel stats of the fp32 bench step
 cd /tmp && export TMPDIR=/tmp

@@ -192,11 +192,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
         }
         qf[d].x *= scale * LOG2E; qf[d].y *= scale * LOG2E; qf[d].z *= scale * LOG2E; qf[d].w *= scale * LOG2E;
     }
-    // The MFMA accumulators of S^T and dP^T start at -lse and -delta of the lane's query (the C operand is free), so
-    // exp2(s - lse) and dp - delta cost no VALU instruction (VALU time adds to MFMA time on this chip).  Log2 units; rows past
-    // the end start at -inf, so that exp2(.) = 0 masks them without a select per element.
-    const float nlse_q = qok ? -lse[(int64_t)h * n_total + start + qrow] * LOG2E : -INFINITY;
-    const float ndel_q = qok ? -delta[(int64_t)h * n_total + start + qrow] : 0.f;
+    // log2 units; rows past the end get +inf so that exp2(s - lse) = 0 masks them without a select per element
+    const float lse_q = qok ? lse[(int64_t)h * n_total + start + qrow] * LOG2E : INFINITY;
+    const float del_q = qok ? delta[(int64_t)h * n_total + start + qrow] : 0.f;
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -207,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
         const bool last = kt == ntiles - 1 && (len & 63);          // wave-uniform
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            f32x4 s4 = {nlse_q, nlse_q, nlse_q, nlse_q}, dp4 = {ndel_q, ndel_q, ndel_q, ndel_q};
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 const float4 ak = *reinterpret_cast<const float4*>(Ks + (kb * 16 + i16) * ATT_LD + d * 16 + qd * 4);
@@ -220,9 +218,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
             float ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(s4[r]);
+                float p = __builtin_amdgcn_exp2f(s4[r] - lse_q);
                 if (last && kt * 64 + kb * 16 + qd * 4 + r >= len) p = 0.f;        // zero-padded keys of the last tile
-                ds[r] = p * dp4[r];
+                ds[r] = p * (dp4[r] - del_q);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -248,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
                                                       float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float Qs[64 * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Os[64 * ATT_LD];
-    __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
+    __shared__ float lse_s[64], del_s[64];
     const AttnWork wk_ = attn_decode(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
     if (b >= B) return;
@@ -277,14 +275,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
         stage_tile(dobase, D, qt * 64, len, 1.f, Os, tid);
         if (tid < 64) {
             const int q = qt * 64 + tid;
-            // negated: they initialise the MFMA accumulators of S and dP (see attn_bwd_dq_k); -inf masks a row past the end
-            lse_s[tid] = q < len ? -lse[(int64_t)h * n_total + start + q] * LOG2E : -INFINITY;
-            del_s[tid] = q < len ? -delta[(int64_t)h * n_total + start + q] : 0.f;
+            lse_s[tid] = q < len ? lse[(int64_t)h * n_total + start + q] * LOG2E : INFINITY;   // exp2(s - inf) = 0 masks the row
+            del_s[tid] = q < len ? delta[(int64_t)h * n_total + start + q] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
-            f32x4 s4 = *reinterpret_cast<const f32x4*>(lse_s + qb * 16 + qd * 4), dp4 = *reinterpret_cast<const f32x4*>(del_s + qb * 16 + qd * 4);
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 const float4 aq = *reinterpret_cast<const float4*>(Qs + (qb * 16 + i16) * ATT_LD + d * 16 + qd * 4);
@@ -297,8 +294,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
             float p[4], ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(s4[r]);
-                ds[r] = p[r] * dp4[r];
+                const int qq = qb * 16 + qd * 4 + r;
+                p[r] = __builtin_amdgcn_exp2f(s4[r] - lse_s[qq]);
+                ds[r] = p[r] * (dp4[r] - del_s[qq]);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {

@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_k(const float* __restric
     const bool qok = qrow < len;
     const bf16x8 qf = row_frag(qok ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * B_LOG2E);
     const bf16x8 dof = row_frag(qok ? dout + (int64_t)(start + qrow) * D + h * 32 + g * 8 : nullptr, 1.f);
-    // accumulators of S^T / dP^T start at -lse / -delta of the lane's query (attn.hip, attn_bwd_dq_k); -inf masks rows past the end
-    const float nlse_q = qok ? -lse[(int64_t)h * n_total + start + qrow] * B_LOG2E : -INFINITY;
-    const float ndel_q = qok ? -delta[(int64_t)h * n_total + start + qrow] : 0.f;
+    // log2 units; rows past the end get +inf so that exp2(s - lse) = 0 masks them without a select per element
+    const float lse_q = qok ? lse[(int64_t)h * n_total + start + qrow] * B_LOG2E : INFINITY;
+    const float del_q = qok ? delta[(int64_t)h * n_total + start + qrow] : 0.f;
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -205,13 +205,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_k(const float* __restric
         for (int kb = 0; kb < 4; ++kb) {
             const bf16x8 ak = *reinterpret_cast<const bf16x8*>(Ks + (kb * 16 + i16) * HLD + g * 8);
             const bf16x8 av = *reinterpret_cast<const bf16x8*>(Vs + (kb * 16 + i16) * HLD + g * 8);
-            const f32x4 s4 = U3D_MFMA_BF16(ak, qf, (f32x4{nlse_q, nlse_q, nlse_q, nlse_q}));
-            const f32x4 dp4 = U3D_MFMA_BF16(av, dof, (f32x4{ndel_q, ndel_q, ndel_q, ndel_q}));
+            const f32x4 s4 = U3D_MFMA_BF16(ak, qf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+            const f32x4 dp4 = U3D_MFMA_BF16(av, dof, (f32x4{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(s4[r]);
+                float p = __builtin_amdgcn_exp2f(s4[r] - lse_q);
                 if (last && kt * 64 + kb * 16 + g * 4 + r >= len) p = 0.f;        // zero-padded keys of the last tile
-                ds[kb][r] = p * dp4[r];
+                ds[kb][r] = p * (dp4[r] - del_q);
             }
         }
 #pragma unroll
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_k(const float* __restri
                                                            float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * HLD];
     __shared__ __attribute__((aligned(16))) __bf16 Os[64 * HLD];
-    __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
+    __shared__ float lse_s[64], del_s[64];
     const AttnWorkB wk_ = attn_decode_b(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
     if (b >= B) return;
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_k(const float* __restri
         stage_tile_bf16(dobase, D, qt * 64, len, 1.f, Os, tid);
         if (tid < 64) {
             const int q = qt * 64 + tid;
-            lse_s[tid] = q < len ? -lse[(int64_t)h * n_total + start + q] * B_LOG2E : -INFINITY;   // negated: accumulator seeds; -inf masks the row
-            del_s[tid] = q < len ? -delta[(int64_t)h * n_total + start + q] : 0.f;
+            lse_s[tid] = q < len ? lse[(int64_t)h * n_total + start + q] * B_LOG2E : INFINITY;   // exp2(s - inf) = 0 masks the row
+            del_s[tid] = q < len ? delta[(int64_t)h * n_total + start + q] : 0.f;
         }
         __syncthreads();
         float p[4][4], ds[4][4];
@@ -268,12 +268,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_k(const float* __restri
         for (int qb = 0; qb < 4; ++qb) {
             const bf16x8 aq = *reinterpret_cast<const bf16x8*>(Qs + (qb * 16 + i16) * HLD + g * 8);
             const bf16x8 ao = *reinterpret_cast<const bf16x8*>(Os + (qb * 16 + i16) * HLD + g * 8);
-            const f32x4 s4 = U3D_MFMA_BF16(aq, kf, *reinterpret_cast<const f32x4*>(lse_s + qb * 16 + g * 4));
-            const f32x4 dp4 = U3D_MFMA_BF16(ao, vf, *reinterpret_cast<const f32x4*>(del_s + qb * 16 + g * 4));
+            const f32x4 s4 = U3D_MFMA_BF16(aq, kf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+            const f32x4 dp4 = U3D_MFMA_BF16(ao, vf, (f32x4{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[qb][r] = __builtin_amdgcn_exp2f(s4[r]);
-                ds[qb][r] = p[qb][r] * dp4[r];
+                const int qq = qb * 16 + g * 4 + r;
+                p[qb][r] = __builtin_amdgcn_exp2f(s4[r] - lse_s[qq]);
+                ds[qb][r] = p[qb][r] * (dp4[r] - del_s[qq]);
             }
         }
 #pragma unroll

@@ -8,12 +8,73 @@
 
 namespace u3d {
 
+// What the LAST workgroup of a statistics kernel does after every workgroup has written its partial row (fp64 [2C]) to the
+// workspace: sum the rows of each column in a fixed order (deterministic), store sums[0..2C) (+ the row count) and, for the
+// forward pass, finalize the layer (mean / invstd / scale / shift, running statistics) -- the "sum partials" / "finalize"
+// launches of rounds 1-2 folded into the reduction (threadfence-reduction: release fence, ticket, acquire fence).
+struct BnFin {
+    double* sums;            // [2C+1]
+    double rows;             // row count of this rank
+    int set_rows;            // store rows into sums[2C]
+    const float* gamma;      // finalize when st != nullptr
+    const float* beta;
+    float eps, momentum;
+    float* running_mean;
+    float* running_var;
+    float* st;               // mean, invstd, scale, shift [4][C]
+    int64_t* nbt;
+};
+
+__device__ __forceinline__ void bn_finish(const double* partial, int nblk, int C, const BnFin& f, int* ticket) {
+    __shared__ int is_last;
+    __threadfence();                                   // release: this workgroup's partial row
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == nblk - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                                   // acquire: the other workgroups' rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int c = wave; c < C; c += nw) {               // one wave per channel: lanes over rows, fixed shuffle tree
+        double t1 = 0.0, t2 = 0.0;
+        for (int b = lane; b < nblk; b += 64) {
+            t1 += partial[(int64_t)b * 2 * C + c];
+            t2 += partial[(int64_t)b * 2 * C + C + c];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { t1 += __shfl_xor(t1, d, 64); t2 += __shfl_xor(t2, d, 64); }
+        if (lane) continue;
+        f.sums[c] = t1;
+        f.sums[C + c] = t2;
+        if (!f.st) continue;
+        const double m = t1 / f.rows;
+        double var = t2 / f.rows - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float mf = (float)m;
+        f.st[c] = mf;
+        f.st[C + c] = is;
+        const float sc = f.gamma[c] * is;
+        f.st[2 * C + c] = sc;
+        f.st[3 * C + c] = f.beta[c] - mf * sc;
+        if (f.running_mean) {
+            const double unbiased = f.rows > 1.0 ? var * f.rows / (f.rows - 1.0) : var;
+            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mf;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (f.set_rows) f.sums[2 * C] = f.rows;
+        if (f.nbt) *f.nbt += 1;
+        *ticket = 0;                                   // ready for the next launch on this stream
+    }
+}
+
 // mode 0: sums = [sum x, sum x^2]; mode 1: backward sums [sum dy', sum dy'*xhat]
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                   int64_t n, int C, double* sums /* partials [gridDim.x][2C] */) {
+                                                   int64_t n, int C, double* sums /* partials [gridDim.x][2C] */, BnFin fin, int* ticket) {
     __shared__ double sh[256 * 8];
     const int lpr = C >> 2;
     const int rpb = 256 / lpr;
@@ -82,61 +143,39 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
             out[C + tid * 4 + j] = tb[j];
         }
     }
+    bn_finish(sums, gridDim.x, C, fin, ticket);
 }
 
-// sums[c] = sum_b partial[b][c] in a fixed order (deterministic); optionally sums[2C] = rows.
-// One wave per column: lane l adds rows l, l+64, ... then a fixed shuffle tree.
-__global__ __launch_bounds__(256) void bn_sum_partials_k(const double* __restrict__ partial, int nblk, int C2, double rows,
-                                                         int set_rows, double* __restrict__ sums) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c < C2) {
-        double t = 0.0;
-        for (int b = lane; b < nblk; b += 64) t += partial[(int64_t)b * C2 + c];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
-        if (lane == 0) sums[c] = t;
+// Statistics of a convolution output from the per-tile partial sums its epilogue wrote (spconv_gmm_k: float [n_tiles][2][C] =
+// sum x | sum x^2 over the <= 64 rows of a tile): no pass over x at all.  Workgroup b adds the tiles b, b + G, b + 2G, ... in
+// fp64; the last workgroup finishes as above.
+__global__ __launch_bounds__(256) void bn_partials_k(const float* __restrict__ partial, int64_t n_tiles, int C, double* ws, BnFin fin, int* ticket) {
+    __shared__ double sh[256];
+    const int C2 = 2 * C, tid = threadIdx.x;
+    double* out = ws + (int64_t)blockIdx.x * C2;
+    for (int c0 = 0; c0 < C2; c0 += 256) {                 // column chunks of up to 256
+        const int w = min(256, C2 - c0), rpp = 256 / w;    // rows per pass
+        const int col = c0 + tid % w, slot = tid / w;
+        double a0 = 0.0, a1 = 0.0;
+        if (slot < rpp) {
+            const int64_t step = (int64_t)gridDim.x * rpp;
+            int64_t r = (int64_t)blockIdx.x * rpp + slot;
+            for (; r + step < n_tiles; r += 2 * step) {    // two independent loads in flight
+                a0 += (double)partial[r * C2 + col];
+                a1 += (double)partial[(r + step) * C2 + col];
+            }
+            if (r < n_tiles) a0 += (double)partial[r * C2 + col];
+        }
+        sh[tid] = a0 + a1;
+        __syncthreads();
+        if (tid < w) {
+            double t = 0.0;
+            for (int s_ = 0; s_ < rpp; ++s_) t += sh[s_ * w + tid];
+            out[c0 + tid] = t;
+        }
+        __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && set_rows) sums[C2] = rows;
-}
-
-// bn_sum_partials_k for the two statistics of channel c + bn_finalize_k of that channel in one launch (one wave per channel)
-__global__ __launch_bounds__(256) void bn_sum_finalize_k(const double* __restrict__ partial, int nblk, int C, double rows, double* __restrict__ sums,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-                                                         float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                                         float* shift, int64_t* num_batches_tracked) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sums[2 * C] = rows;
-        if (num_batches_tracked) *num_batches_tracked += 1;
-    }
-    if (c >= C) return;
-    double t1 = 0.0, t2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        t1 += partial[(int64_t)b * 2 * C + c];
-        t2 += partial[(int64_t)b * 2 * C + C + c];
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { t1 += __shfl_xor(t1, d, 64); t2 += __shfl_xor(t2, d, 64); }
-    if (lane) return;
-    sums[c] = t1;
-    sums[C + c] = t2;
-    const double m = t1 / rows;
-    double var = t2 / rows - m * m;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    const float mf = (float)m;
-    mean[c] = mf;
-    invstd[c] = is;
-    const float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - mf * sc;
-    if (running_mean) {
-        const double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
+    bn_finish(ws, gridDim.x, C, fin, ticket);
 }
 
 
@@ -241,18 +280,40 @@ static int bn_grid(int64_t n, int C) {
     int64_t g = ceil_div(n, (int64_t)rpb * 16);
     return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
 }
+static int bn_partials_grid(int64_t n_tiles, int C) {
+    const int rpp = 2 * C >= 256 ? 1 : 256 / (2 * C);
+    int64_t g = ceil_div(n_tiles, (int64_t)rpp * 16);         // ~16 tiles per thread
+    return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
+}
 
 int64_t u3d_bn_ws_bytes(int C) { return (int64_t)256 * 2 * C * sizeof(double) + 64; }
 
-int u3d_bn_stats(const float* x, int64_t n, int C, double* sums, void* ws, u3d_stream_t stream) {
-    if (!x || !sums || !ws || !bn_ok(n, C)) return U3D_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
-    const int g = bn_grid(n, C);
-    hipLaunchKernelGGL(bn_reduce_k<0>, dim3(g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws);
-    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 3) / 4), dim3(256), 0, s, (const double*)ws, g, 2 * C, (double)n, 1, sums);
+static BnFin bn_fin(double* sums, double rows, int set_rows) {
+    BnFin f;
+    f.sums = sums; f.rows = rows; f.set_rows = set_rows; f.gamma = nullptr; f.beta = nullptr; f.eps = 0.f; f.momentum = 0.f;
+    f.running_mean = nullptr; f.running_var = nullptr; f.st = nullptr; f.nbt = nullptr;
+    return f;
+}
+
+// statistics of x [n][C] (pass over x), or -- partial != NULL -- from the per-tile sums a convolution epilogue wrote
+static int bn_stats_launch(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const BnFin& f, void* ws, int32_t* ticket,
+                           hipStream_t s) {
+    if (partial) {
+        if (n_tiles <= 0) return U3D_EINVAL;
+        ProfScope prof(U3D_K_BN, s, (double)n_tiles * C * 8);
+        hipLaunchKernelGGL(bn_partials_k, dim3(bn_partials_grid(n_tiles, C)), dim3(256), 0, s, partial, n_tiles, C, (double*)ws, f, (int*)ticket);
+    } else {
+        ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
+        hipLaunchKernelGGL(bn_reduce_k<0>, dim3(bn_grid(n, C)), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws, f, (int*)ticket);
+    }
     return check_launch("bn_stats");
+}
+
+int u3d_bn_stats(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, double* sums, void* ws, int32_t* ticket,
+                 u3d_stream_t stream) {
+    if ((!x && !partial) || !sums || !ws || !ticket || !bn_ok(n, C)) return U3D_EINVAL;
+    return bn_stats_launch(x, n, C, partial, n_tiles, bn_fin(sums, (double)n, 1), ws, ticket, (hipStream_t)stream);
 }
 
 int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
@@ -275,13 +336,12 @@ int u3d_bn_apply(const float* x, const float* scale, const float* shift, int rel
 }
 
 int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
-                     const float* shift, int relu, int64_t n, int C, double* sums, void* ws, u3d_stream_t stream) {
-    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !ws || !bn_ok(n, C)) return U3D_EINVAL;
+                     const float* shift, int relu, int64_t n, int C, double* sums, void* ws, int32_t* ticket, u3d_stream_t stream) {
+    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !ws || !ticket || !bn_ok(n, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
-    const int g = bn_grid(n, C);
-    hipLaunchKernelGGL(bn_reduce_k<1>, dim3(g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws);
-    hipLaunchKernelGGL(bn_sum_partials_k, dim3((2 * C + 3) / 4), dim3(256), 0, s, (const double*)ws, g, 2 * C, 0.0, 0, sums);
+    hipLaunchKernelGGL(bn_reduce_k<1>, dim3(bn_grid(n, C)), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws,
+                       bn_fin(sums, 0.0, 0), (int*)ticket);
     return check_launch("bn_bwd_stats");
 }
 
@@ -297,30 +357,24 @@ int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const f
     return check_launch("bn_bwd_apply");
 }
 
-int u3d_bn_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum,
-                   float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st, double* sums,
-                   void* ws, u3d_stream_t stream) {
-    // statistics (per-block partials) -> one launch that sums the partials of a channel AND finalises it -> apply
-    if (!x || !sums || !ws || !gamma || !beta || !st || !y || !bn_ok(n, C)) return U3D_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    {
-        ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
-        const int g = bn_grid(n, C);
-        hipLaunchKernelGGL(bn_reduce_k<0>, dim3(g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws);
-        hipLaunchKernelGGL(bn_sum_finalize_k, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)ws, g, C, (double)n, sums, gamma, beta, eps,
-                           momentum, running_mean, running_var, st, st + C, st + 2 * C, st + 3 * C, num_batches_tracked);
-        int rc = check_launch("bn_forward");
-        if (rc) return rc;
-    }
+int u3d_bn_forward(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st,
+                   double* sums, void* ws, int32_t* ticket, u3d_stream_t stream) {
+    // ONE statistics launch (per-workgroup partials; the last workgroup sums them and finalizes the layer) -> apply
+    if (!x || !sums || !ws || !ticket || !gamma || !beta || !st || !y || !bn_ok(n, C)) return U3D_EINVAL;
+    BnFin f = bn_fin(sums, (double)n, 1);
+    f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum; f.running_mean = running_mean; f.running_var = running_var;
+    f.st = st; f.nbt = num_batches_tracked;
+    int rc = bn_stats_launch(x, n, C, partial, n_tiles, f, ws, ticket, (hipStream_t)stream);
+    if (rc) return rc;
     return u3d_bn_apply(x, st + 2 * C, st + 3 * C, relu, n, C, y, stream);
 }
 
 int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n, int C,
-                    float* dx, float* dgamma, float* dbeta, const float* addend, void* ws, u3d_stream_t stream) {
+                    float* dx, float* dgamma, float* dbeta, const float* addend, void* ws, int32_t* ticket, u3d_stream_t stream) {
     // sums[0..2C) are overwritten; sums[2C] (the row count) is taken from the forward pass's vector
     if (!fwd_sums) return U3D_EINVAL;
-    int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, stream);
+    int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, ticket, stream);
     if (rc) return rc;
     if (!dx) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;       // the row count is read from the forward pass's vector (no copy launch)

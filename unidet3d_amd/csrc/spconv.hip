@@ -34,6 +34,8 @@ struct GmmParams {
     const int32_t* ts;
     const float* addend;
     float* out;          // dst, or the partial buffer [G][n_dst][Cd] when G > 1
+    float* stats;        // nullable (G == 1 only): per-tile column sums of dst for the batch norm behind this convolution,
+                         // float [n_sub][2][Cd] = sum x | sum x^2 over the tile's rows
     int K;
     int64_t cap;
     int Cs, Cd;
@@ -45,7 +47,21 @@ struct GmmParams {
 };
 
 constexpr int GMM_CDS = 32;            // output columns per wave
-constexpr int GMM_ALD = 40;            // accumulator row stride (floats): 160 B keeps the 16-byte accesses of consecutive rows on distinct banks
+// Accumulator tile of a wave in LDS: R rows x 32 floats.  Default layout (round 3): 128-byte rows, the eight 16-byte quads of
+// row r stored at quad ^ (r & 7) -- the XOR spreads the random-row 16-byte accesses of the MFMA read-modify-write over the
+// banks like the padded 160-byte rows of rounds 1-2 did, without their 25 % padding, and the scratch row for lanes past the
+// end of a range aliases the head of the staging image (dead at that point of a unit) instead of being a 65th row:
+// 10 KB per wave instead of 12.4 -> FOUR workgroups (16 waves) per CU instead of three for the 64-row kernels.
+// -DU3D_GMM_ALD40 builds the old layout (A/B measurements).
+#ifdef U3D_GMM_ALD40
+constexpr bool GMM_SWZ = false;
+constexpr int GMM_ALD = 40;
+#else
+constexpr bool GMM_SWZ = true;
+constexpr int GMM_ALD = 32;
+#endif
+// float index of (row r, 16-byte quad c4) in the tile
+__device__ __forceinline__ int gmm_acc_idx(int r, int c4) { return GMM_SWZ ? r * 32 + ((c4 ^ (r & 7)) << 2) : r * GMM_ALD + (c4 << 2); }
 
 // ---- software-pipelined wave program ---------------------------------------------------------------------
 // A wave's work is a sequence of ITEMS (offset k, window of W = 16*NCH pairs of k's range in this row tile);
@@ -107,7 +123,7 @@ struct GmmWave {
     int lane, i16, slice, k_hi, cs4, K, row0;
     int64_t cap;
     int ts_s, ts_e;                               // lane k: pair range of offset k in this row tile
-    int lr, lp16, lane16, lw, lw4;                // per-lane constants
+    int lr, lp16, lane16, lw, lw4, q16;           // per-lane constants
     int wr_off, rd_off[JB];                       // float offsets into `stage` of this lane's write / fragment reads
 
     GmmItem it0, it1;                             // item being computed / item whose first unit is fetched next
@@ -123,7 +139,8 @@ struct GmmWave {
         rs_src = make_rsrc(p.src); rs_g = make_rsrc(p.gather); rs_s = make_rsrc(p.scatter); rs_w = make_rsrc(p.w);
         lane = lane_; i16 = lane & 15; slice = slice_; cs4 = p.Cs * 4; K = p.K; cap = p.cap; row0 = (int)row0_;
         const int q = lane >> 4;
-        accq = reinterpret_cast<char*>(acc) + q * 16;
+        accq = reinterpret_cast<char*>(acc) + (GMM_SWZ ? 0 : q * 16);
+        q16 = q << 4;
         stage = stage_;
         lr = lane / PPR; lp16 = (lane % PPR) * 16; lane16 = lane * 16; lw = lane & (W - 1); lw4 = lw * 4;
         wr_off = (lr * PPR + ((lane % PPR) ^ swz(lr))) * 4;             // swz(i*RPI + lr) == swz(lr) for PPR = 4, 8
@@ -208,10 +225,18 @@ struct GmmWave {
     // byte offsets of the accumulator rows of item `it` whose raw scatter rows are `raw_s` (lane l < W owns pair base + l)
     __device__ __forceinline__ void row_offsets(const GmmItem& it, int raw_s, int& o0, int& o1) const {
         const int mine = lw < it.e - it.base ? raw_s - row0 : TRASH;
-        const int mine_off = (int)__umul24(mine, GMM_ALD * 4);
-        o0 = __shfl(mine_off, i16, 64);
-        o1 = NCH == 2 ? __shfl(mine_off, 16 + i16, 64) : 0;
+        if constexpr (GMM_SWZ) {       // byte offset of quad 0 of the row, then this lane's quad q: (q ^ (row & 7)) << 4
+            const int mine_off = (mine << 7) | ((mine & 7) << 4);
+            o0 = __shfl(mine_off, i16, 64) ^ q16;
+            o1 = NCH == 2 ? __shfl(mine_off, 16 + i16, 64) ^ q16 : 0;
+        } else {
+            const int mine_off = (int)__umul24(mine, GMM_ALD * 4);
+            o0 = __shfl(mine_off, i16, 64);
+            o1 = NCH == 2 ? __shfl(mine_off, 16 + i16, 64) : 0;
+        }
     }
+    // byte offset of columns 16..31 (quad q + 4) of the row whose columns 0..15 sit at byte offset o
+    static __device__ __forceinline__ int hi_cols(int o) { return GMM_SWZ ? (o ^ 64) : (o + 64); }
 
     // One unit of the current item.  Chunk 1 (pairs 16..31 of the window) exists only when the window holds more than
     // 16 pairs (wave-uniform).  Order matters: a wave's critical path per item is LDS round trips + MFMAs, so ALL LDS
@@ -223,10 +248,10 @@ struct GmmWave {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
         if constexpr (U == 0) {         // accumulator rows of the item -> C operands
             d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
-            d01 = *reinterpret_cast<const f32x4*>(accq + soff0 + 64);
+            d01 = *reinterpret_cast<const f32x4*>(accq + hi_cols(soff0));
             if (two) {
                 d10 = *reinterpret_cast<const f32x4*>(accq + soff1);
-                d11 = *reinterpret_cast<const f32x4*>(accq + soff1 + 64);
+                d11 = *reinterpret_cast<const f32x4*>(accq + hi_cols(soff1));
             }
         }
         const Frag f0 = frags<0>(cur);
@@ -277,10 +302,10 @@ struct GmmWave {
         }
         if constexpr (U == NJB - 1) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
-            *reinterpret_cast<f32x4*>(accq + soff0 + 64) = d01;
+            *reinterpret_cast<f32x4*>(accq + hi_cols(soff0)) = d01;
             if (two) {
                 *reinterpret_cast<f32x4*>(accq + soff1) = d10;
-                *reinterpret_cast<f32x4*>(accq + soff1 + 64) = d11;
+                *reinterpret_cast<f32x4*>(accq + hi_cols(soff1)) = d11;
             }
             g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
             it0 = it1; it1 = it2;
@@ -318,14 +343,17 @@ struct GmmWave {
 // 16-channel groups per unit: 128-byte row pieces (JB = 2) for 64-row tiles, 256-byte pieces for 32-row tiles when
 // the channel count allows
 constexpr int gmm_jb(int cs16, int r) { return (cs16 % 4 == 0 && r == 32) ? 4 : (cs16 % 2 == 0 ? 2 : 1); }
-constexpr int gmm_wave_lds(int cs16, int r) { return (r + 1) * GMM_ALD + 16 * gmm_jb(cs16, r) * 16; }      // floats: accumulator + staging image
+// floats: accumulator rows (+ the scratch row of the padded layout; the swizzled layout's scratch row IS the first 128 bytes
+// of the staging image) + staging image
+constexpr int gmm_acc_rows(int r) { return GMM_SWZ ? r : r + 1; }
+constexpr int gmm_wave_lds(int cs16, int r) { return gmm_acc_rows(r) * GMM_ALD + 16 * gmm_jb(cs16, r) * 16; }
 
 template <int CS16, int R, bool BF = false>
 __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
-    float* acc = smem + wave * gmm_wave_lds(CS16, R);                // R rows + one scratch row, then the staging image
+    float* acc = smem + wave * gmm_wave_lds(CS16, R);                // R rows (+ scratch row), then the staging image
 
     const int64_t wid = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wave;     // neighbouring row tiles share an XCD / L2
     const int per_sub = p.n_slices * p.G;
@@ -343,12 +371,12 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         const int r = idx >> 3, c4 = idx & 7;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.addend && p.G == 1) v = *reinterpret_cast<const float4*>(p.addend + (row0 + r) * p.Cd + n0 + c4 * 4);
-        *reinterpret_cast<float4*>(acc + r * GMM_ALD + c4 * 4) = v;
+        *reinterpret_cast<float4*>(acc + gmm_acc_idx(r, c4)) = v;
     }
 
     static_assert(!BF || CS16 % 2 == 0, "bf16 operands pair 16-channel groups");
     GmmWave<CS16, R, gmm_jb(CS16, R), BF> w;
-    w.init(p, acc, acc + (R + 1) * GMM_ALD, lane, slice, row0);
+    w.init(p, acc, acc + gmm_acc_rows(R) * GMM_ALD, lane, slice, row0);
     const int k_lo = g * p.kper;
     w.k_hi = min(p.K, k_lo + p.kper);
     // all (start, end) ranges of this wave's offsets in one round trip: lane k holds offset k's range
@@ -360,9 +388,36 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     w.run(k_lo);
 
     float* out = p.out + (p.G > 1 ? (int64_t)g * p.n_dst * p.Cd : 0);
+    // dst rows leave the LDS tile here; the batch norm that follows (every convolution of the U-Net feeds one) needs sum x and
+    // sum x^2 per channel: accumulated on the way out (lane = column quad c4, rows lane/8 + 8 i), folded over the 8 row groups
+    // with three shuffles and stored as ONE partial row per tile -- bn_partials_k adds the tiles in fp64.  This replaces a
+    // pass over dst (bn_reduce_k<0>) per layer; ~60 VALU instructions per tile, outside the MFMA loop.
+    if (!p.stats) {                                    // wave-uniform (input-gradient launches, eval mode)
+        for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
+            const int r = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<float4*>(out + (row0 + r) * p.Cd + n0 + c4 * 4) = *reinterpret_cast<const float4*>(acc + gmm_acc_idx(r, c4));
+        }
+        return;
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     for (int idx = lane; idx < rows * (GMM_CDS / 4); idx += 64) {
         const int r = idx >> 3, c4 = idx & 7;
-        *reinterpret_cast<float4*>(out + (row0 + r) * p.Cd + n0 + c4 * 4) = *reinterpret_cast<const float4*>(acc + r * GMM_ALD + c4 * 4);
+        const float4 v = *reinterpret_cast<const float4*>(acc + gmm_acc_idx(r, c4));
+        *reinterpret_cast<float4*>(out + (row0 + r) * p.Cd + n0 + c4 * 4) = v;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    }
+    {
+#pragma unroll
+        for (int d = 8; d <= 32; d <<= 1) {
+            s1.x += __shfl_xor(s1.x, d, 64); s1.y += __shfl_xor(s1.y, d, 64); s1.z += __shfl_xor(s1.z, d, 64); s1.w += __shfl_xor(s1.w, d, 64);
+            s2.x += __shfl_xor(s2.x, d, 64); s2.y += __shfl_xor(s2.y, d, 64); s2.z += __shfl_xor(s2.z, d, 64); s2.w += __shfl_xor(s2.w, d, 64);
+        }
+        if (lane < 8) {
+            float* st = p.stats + sub * 2 * p.Cd + n0 + lane * 4;
+            *reinterpret_cast<float4*>(st) = s1;
+            *reinterpret_cast<float4*>(st + p.Cd) = s2;
+        }
     }
 }
 
@@ -794,7 +849,7 @@ int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k
 
 static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
                            const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
-                           int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream, bool bf) {
+                           int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream, bool bf) {
     if (bf && Cs % 32) { set_error("spconv_gmm_bf16: Cs=%d must be a multiple of 32", Cs); return U3D_EUNSUPPORTED; }
     if (!src || !w_rows || !gather || !scatter || !tile_starts || !dst || K <= 0 || K > 32 || n_dst <= 0 || n_src <= 0 || cap <= 0) return U3D_EINVAL;
     // the kernel addresses through 32-bit buffer offsets and multiplies row indices with v_mul_u32_u24
@@ -813,6 +868,8 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
     GmmParams p;
     p.src = src; p.w = w_rows; p.gather = gather; p.scatter = scatter; p.ts = tile_starts; p.addend = addend;
     p.out = G > 1 ? (float*)ws : dst;
+    if (bn_partial && G > 1) { set_error("spconv_gmm: per-tile statistics are only produced without offset groups (k_groups = %d)", G); return U3D_EUNSUPPORTED; }
+    p.stats = bn_partial;
     p.K = K; p.cap = cap; p.Cs = Cs; p.Cd = Cd; p.n_dst = n_dst; p.n_sub = ceil_div(n_dst, R);
     p.n_slices = Cd / GMM_CDS; p.G = G; p.kper = (int)ceil_div(K, G);
     const int cs16 = Cs / 16;
@@ -839,16 +896,16 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
 
 int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
-                   int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
+                   int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream) {
     return spconv_gmm_impl(src, n_src, w_rows, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups, addend, dst, ws,
-                           flops_hint, stream, false);
+                           bn_partial, flops_hint, stream, false);
 }
 
 int u3d_spconv_gmm_bf16(const float* src, int64_t n_src, const void* w_rows_bf16, const int32_t* gather, const int32_t* scatter,
                         const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
-                        int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
+                        int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream) {
     return spconv_gmm_impl(src, n_src, (const float*)w_rows_bf16, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups,
-                           addend, dst, ws, flops_hint, stream, true);
+                           addend, dst, ws, bn_partial, flops_hint, stream, true);
 }
 
 int u3d_weight_pack_bf16(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {

@@ -228,8 +228,11 @@ class WeightPacks:
         self.state = state
 
 
-def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=False):
+def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=False, stats_out=None):
     """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in).
+    ``stats_out`` (a dict, or None): asks the kernel's epilogue for the per-tile column sums of dst that the batch norm behind
+    this convolution needs (``partial`` float [n_tiles, 2, Cd], ``n_tiles``); left empty when the launch splits the kernel
+    offsets over groups (deep levels: a few thousand rows, the norm then makes its own pass).
     ``bf``: bf16 MFMA operands (precision.py); source channel counts that are not a multiple of 32 (the 6 -> 32 input
     convolution, padded to 16) stay on the fp32 kernel."""
     Cs, Cd = src.shape[1], (weight.shape[2] if transposed else weight.shape[0])
@@ -239,6 +242,11 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
         if _PROFILE_FLOPS:      # N(Cs+Cd)s + 2P*idx + K*Cs*Cd*s  (s = 4 B, idx = 4 B)
             account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None
+        partial = None
+        if stats_out is not None and G == 1 and _EPILOGUE_STATS:
+            n_tiles = (n_dst + R - 1) // R
+            partial = torch.empty(n_tiles, 2, Cd, dtype=torch.float32, device=src.device)
+            stats_out.update(partial=partial, n_tiles=n_tiles)
         bf = bf and Cs % 32 == 0
         hit = _PACKED.get((weight.data_ptr(), int(transposed), bf))
         if hit is not None and hit[2] == weight._version and hit[1].device == src.device:
@@ -247,7 +255,7 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
             wp = torch.empty(weight.numel() // (2 if bf else 1), dtype=torch.float32, device=src.device)       # MFMA-fragment order
             L.call('u3d_weight_pack_bf16' if bf else 'u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
         L.call('u3d_spconv_gmm_bf16' if bf else 'u3d_spconv_gmm', L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
-               rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
+               rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), L.ptr(partial), float(flops), L.stream())
     return dst
 
 
@@ -264,6 +272,9 @@ def _side_stream(device):
 
 
 _PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops
+# batch-norm statistics from the convolution epilogue (no pass over the conv output); U3D_EPILOGUE_STATS=0 restores the
+# separate statistics pass (A/B measurements)
+_EPILOGUE_STATS = os.environ.get('U3D_EPILOGUE_STATS', '1') != '0'
 
 
 def set_profile_flops(on: bool):
@@ -280,7 +291,7 @@ class _SparseConvFn(torch.autograd.Function):
     'inv' (roles swapped; SparseInverseConv3d)."""
 
     @staticmethod
-    def forward(ctx, src, weight, rb: Rulebook, mode: str, addend):
+    def forward(ctx, src, weight, rb: Rulebook, mode: str, addend, stats_out=None):
         cout, cin = weight.shape[0], weight.shape[-1]
         w = weight.reshape(cout, rb.K, cin)
         src = src.contiguous()
@@ -290,7 +301,8 @@ class _SparseConvFn(torch.autograd.Function):
             g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
         ctx.bf = P.bf16()
-        dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops, ctx.bf)
+        dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops, ctx.bf,
+                   stats_out)
         ctx.save_for_backward(src, weight)
         ctx.rb, ctx.mode, ctx.has_addend = rb, mode, addend is not None
         return dst
@@ -337,11 +349,11 @@ class _SparseConvFn(torch.autograd.Function):
             dsrc = _gmm(dout, weight.reshape(cout, rb.K, cin).contiguous(), True, rb, g, s, role, n_dst, None, flops, ctx.bf)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-        return dsrc, dw, None, None, (dout if ctx.has_addend else None)
+        return dsrc, dw, None, None, (dout if ctx.has_addend else None), None
 
 
-def sparse_conv(src, weight, rb, mode='fwd', addend=None):
-    return _SparseConvFn.apply(src, weight, rb, mode, addend)
+def sparse_conv(src, weight, rb, mode='fwd', addend=None, stats_out=None):
+    return _SparseConvFn.apply(src, weight, rb, mode, addend, stats_out)
 
 
 # ----------------------------------------------------------------------------------------
@@ -360,20 +372,23 @@ def allreduce_bn_sums(sums: torch.Tensor, group=None):
 
 class _BNReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync, nbt=None, want_skip=False):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync, nbt=None, want_skip=False,
+                stats=None):
+        """``stats``: dict(partial, n_tiles) from the epilogue of the convolution that produced x (sparse._gmm), or None."""
         x = x.contiguous()
         n, C = x.shape
         dev = x.device
         st = torch.empty(4, C, dtype=torch.float32, device=dev)     # mean, invstd, scale, shift
         y = torch.empty_like(x)
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
+        part, n_tiles = (stats['partial'], stats['n_tiles']) if stats else (None, 0)
         sums = None
         sync_on = sync and _dist_on()
         if training and (n or sync_on):           # a rank without rows still joins the exchange (zero sums, zero count), like nn.SyncBatchNorm
             sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)   # [sum x, sum x^2, rows]
             if sync_on:
                 if n:
-                    L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(sums), L.ptr(ws), L.stream())
+                    L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(part), n_tiles, L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
                 else:
                     sums.zero_()
                 allreduce_bn_sums(sums)          # rows ride along: no host read-back on the critical path
@@ -383,8 +398,8 @@ class _BNReLUFn(torch.autograd.Function):
                 if n:
                     L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
             else:                                # one call: stats -> finalize -> apply
-                L.call('u3d_bn_forward', L.ptr(x), n, C, L.ptr(gamma), L.ptr(beta), eps, momentum, L.ptr(running_mean),
-                       L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
+                L.call('u3d_bn_forward', L.ptr(x), n, C, L.ptr(part), n_tiles, L.ptr(gamma), L.ptr(beta), eps, momentum, L.ptr(running_mean),
+                       L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
         else:
             st[0] = running_mean
             st[1] = torch.rsqrt(running_var + eps)
@@ -406,7 +421,7 @@ class _BNReLUFn(torch.autograd.Function):
     def backward(ctx, dy, dskip=None):
         x, st, fsums = ctx.saved_tensors
         if dy is None:                                 # only the identity branch carried a gradient
-            return (dskip,) + (None,) * 11
+            return (dskip,) + (None,) * 12
         dy = dy.contiguous()
         dskip = None if dskip is None else dskip.contiguous()
         n, C = x.shape
@@ -417,14 +432,14 @@ class _BNReLUFn(torch.autograd.Function):
         if not n:
             if ctx.training and fsums is not None and ctx.sync and _dist_on():     # keep the collective sequence of the other ranks
                 dist.all_reduce(torch.zeros(2 * C, dtype=torch.float64, device=dev), op=dist.ReduceOp.SUM)
-            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None, None
+            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None, None, None
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
         if ctx.training and fsums is not None:
             if ctx.sync and _dist_on():
                 sums[2 * C:] = fsums[2 * C:]         # global row count of the forward pass
                 L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                       int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
+                       int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
                 dgb[1] = sums[:C].to(torch.float32)
                 dgb[0] = sums[C:2 * C].to(torch.float32)
                 dist.all_reduce(sums[:2 * C], op=dist.ReduceOp.SUM)
@@ -432,17 +447,17 @@ class _BNReLUFn(torch.autograd.Function):
                        int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.ptr(dskip), L.stream())
             else:                                    # one call: bwd_stats -> bwd_apply (+ dgamma / dbeta)
                 L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(fsums), L.ptr(sums), n, C, L.ptr(dx),
-                       L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(dskip), L.ptr(ws), L.stream())
+                       L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(dskip), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
         else:                                        # eval: statistics are constants -> dx = scale * dy'
             L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                   int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
+                   int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
             dgb[1] = sums[:C].to(torch.float32)
             dgb[0] = sums[C:2 * C].to(torch.float32)
             sums.zero_()
             sums[2 * C] = 1.0
             L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
                    int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.ptr(dskip), L.stream())
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
 
 
 class SparseBatchNorm(nn.Module):
@@ -460,13 +475,16 @@ class SparseBatchNorm(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x: torch.Tensor, relu: bool = False, skip: bool = False):
+    def forward(self, x: torch.Tensor, relu: bool = False, skip: bool = False, stats=None):
         """``skip=True`` -> (y, x_id): ``x_id`` is x for a second consumer (the identity branch next to this norm); the gradient that
-        consumer sends back is added to dx inside this layer's backward kernel."""
+        consumer sends back is added to dx inside this layer's backward kernel.
+        ``stats``: the per-tile column sums the producing convolution's epilogue wrote for exactly this ``x``
+        (``SparseConvTensor.stats_for``): the statistics then cost no pass over x."""
         # num_batches_tracked is incremented by the statistics kernel (one launch less per layer)
         return _BNReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                self.momentum, relu, self.training, self.sync,
-                               self.num_batches_tracked if self.training and (x.shape[0] or (self.sync and _dist_on())) else None, skip)
+                               self.num_batches_tracked if self.training and (x.shape[0] or (self.sync and _dist_on())) else None, skip,
+                               stats if self.training else None)
 
 
 # ----------------------------------------------------------------------------------------
@@ -480,10 +498,18 @@ class SparseConvTensor:
         self.batch_size = int(batch_size)
         self.indice_dict = {} if indice_dict is None else indice_dict
         self._index = index
+        self.stats = None           # set by the convolution that produced ``features`` (training): dict(partial, n_tiles, owner)
 
-    def replace_feature(self, new_features):
-        return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size,
-                                self.indice_dict, self._index)
+    def replace_feature(self, new_features, stats=None):
+        t = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size,
+                             self.indice_dict, self._index)
+        if stats:
+            t.stats = dict(stats, owner=new_features)
+        return t
+
+    def stats_for(self, features):
+        """The convolution-epilogue statistics, if they were produced for exactly this feature tensor."""
+        return self.stats if self.stats is not None and self.stats.get('owner') is features and 'partial' in self.stats else None
 
     @property
     def index(self) -> OccupancyIndex:
@@ -527,7 +553,7 @@ class SparseSequential(SparseModule):
                 x = m(x)
             elif isinstance(m, SparseBatchNorm):
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = x.replace_feature(m(x.features, relu=fuse))
+                x = x.replace_feature(m(x.features, relu=fuse, stats=x.stats_for(x.features)))
                 i += 1 if fuse else 0
             elif isinstance(m, nn.Identity):
                 pass
@@ -580,7 +606,8 @@ class SubMConv3d(_ConvBase):
             # library picked a 0.6 ms kernel for the level-1 weight gradient, a [64 x 356k] x [356k x 32] product)
             y = dense.linear(x.features, self.weight.view(self.out_channels, self.in_channels))
             return x.replace_feature(y if addend is None else y + addend)
-        return x.replace_feature(sparse_conv(_pad16(x.features), self._w16(), self.geometry(x), 'fwd', addend))
+        st = {} if self.training else None
+        return x.replace_feature(sparse_conv(_pad16(x.features), self._w16(), self.geometry(x), 'fwd', addend, st), st)
 
     def geometry(self, x: SparseConvTensor) -> Rulebook:
         key = self.indice_key if self.indice_key is not None else ('__subm__', id(self))
@@ -598,8 +625,12 @@ class SparseConv3d(_ConvBase):
 
     def forward(self, x: SparseConvTensor) -> SparseConvTensor:
         oc, oshape, ix2, rb = self.geometry(x)
-        f = sparse_conv(_pad16(x.features), self._w16(), rb, 'fwd')
-        return SparseConvTensor(f, oc, oshape, x.batch_size, x.indice_dict, ix2)
+        st = {} if self.training else None
+        f = sparse_conv(_pad16(x.features), self._w16(), rb, 'fwd', None, st)
+        out = SparseConvTensor(f, oc, oshape, x.batch_size, x.indice_dict, ix2)
+        if st:
+            out.stats = dict(st, owner=f)
+        return out
 
     def geometry(self, x: SparseConvTensor):
         """Coarser level + rulebook for this conv; cached in ``indice_dict`` (the inverse conv reads the
@@ -620,5 +651,9 @@ class SparseInverseConv3d(_ConvBase):
         if self.indice_key not in x.indice_dict:
             raise L.U3DError(f'SparseInverseConv3d: no rulebook saved under {self.indice_key!r}')
         rb, idx, shape, index = x.indice_dict[self.indice_key]
-        f = sparse_conv(_pad16(x.features), self._w16(), rb, 'inv')
-        return SparseConvTensor(f, idx, shape, x.batch_size, x.indice_dict, index)
+        st = {} if self.training else None
+        f = sparse_conv(_pad16(x.features), self._w16(), rb, 'inv', None, st)
+        out = SparseConvTensor(f, idx, shape, x.batch_size, x.indice_dict, index)
+        if st:
+            out.stats = dict(st, owner=f)
+        return out

@@ -55,11 +55,12 @@ class ResidualBlock(SparseModule):
         mods = list(self.conv_branch._modules.values())
         # the block input feeds the first norm AND the skip branch: the norm hands the input back as a second output so that
         # both gradients meet inside its backward kernel (no accumulation kernel)
-        y, x_id = mods[0](input.features, relu=True, skip=True)
+        # (statistics of both norms come from the epilogue of the convolution that produced their input, when there was one)
+        y, x_id = mods[0](input.features, relu=True, skip=True, stats=input.stats_for(input.features))
         skip = self.i_branch(input.replace_feature(x_id)).features
         x = input.replace_feature(y)
         x = mods[2](x)
-        x = x.replace_feature(mods[3](x.features, relu=True))
+        x = x.replace_feature(mods[3](x.features, relu=True, stats=x.stats_for(x.features)))
         return mods[5](x, addend=skip)          # conv + residual in one kernel
 
 
@@ -119,7 +120,7 @@ class SpConvUNet(nn.Module):
         if len(self.num_planes) > 1:
             cm = list(self.conv._modules.values())
             if isinstance(cm[0], SparseBatchNorm) and len(cm) == 3:       # normalize_before: the skip connection leaves next to a norm
-                y, x_id = cm[0](output.features, relu=True, skip=True)
+                y, x_id = cm[0](output.features, relu=True, skip=True, stats=output.stats_for(output.features))
                 identity = output.replace_feature(x_id)
                 dec = cm[2](output.replace_feature(y))
             else:

@@ -345,18 +345,27 @@ int u3d_trim_boxes(const float* points, int64_t pt_ld, const int32_t* sp_list, c
                    const float* boxes, int nb, int box_dim, float low_thr, float up_thr, float* minmax, u3d_stream_t stream);
 
 /* =====================================================================================
- * R12  matcher + losses of a single-dataset batch on the device: forward value AND gradients in five launches
- *      (unidet3d/criterion.py:44-178, :200-320; unidet3d/axis_aligned_iou_loss.py:14-53; yaw-free boxes).
- *  cls [L][n_tot][C1], box [L][n_tot][6] (centre, size): outputs of the L decoder heads, scenes packed; cu int32 [B+1] first
- *  query of a scene; gt_off int32 [B+1] first GT of a scene; gt_labels int64 [G]; gt_boxes [G][6]; qmask uint8: scene b's
- *  [g_b][n_b] query mask at qm_off[b] (int64 [B+1] = prefix sums of n_b g_b, P = qm_off[B]); max_gt = max g_b (<= 64);
- *  min_queries_with_gt = min n_b over scenes with g_b > 0 (must be >= topk + 1, as torch.topk requires in the reference).
- *  loss [1] = sum over layers of lw_cls * mean_b(ds_w * CE_b) + lw_box * mean over scenes with matches (ds_w * DIoU_b);
- *  dcls / dbox receive d loss / d cls, d loss / d box.  ws: u3d_criterion_ws_bytes. */
+ * R12  matcher + losses of a batch on the device: forward value AND gradients in five launches
+ *      (unidet3d/criterion.py:44-178, :200-320; unidet3d/axis_aligned_iou_loss.py:14-53; unidet3d/rotated_iou_loss.py:14-82).
+ *      Single-dataset AND mixed batches of the joint config: every scene has its own dataset (class columns, top-k, weight)
+ *      and box parametrisation (6-dof axis-aligned, or 7-dof with a heading -> rotated DIoU in the matcher cost and the loss).
+ *  cls [L][n_tot][CU]: logits of the L decoder heads, scenes packed, CU columns per row; box [L][n_tot][BD], BD = 6 (centre, size)
+ *  or 7 (+ heading; a yaw-free scene of a 7-column batch ignores its heading column and receives a zero gradient there);
+ *  cu int32 [B+1] first query of a scene; gt_off int32 [B+1] first GT of a scene; gt_labels int64 [G] (index into the scene's class
+ *  list); gt_boxes [G][BD]; qmask uint8: scene b's [g_b][n_b] query mask at qm_off[b] (int64 [B+1] = prefix sums of n_b g_b,
+ *  P = qm_off[B]); scene_meta int32 [B][4] = {classes + 1 of the scene's dataset (the last one is "no object"), top-k,
+ *  1 if the scene's boxes carry a heading, offset of the scene's class-column list in cidx}; scene_w float [B] dataset weight;
+ *  cidx int32 (nullable): concatenated class-column lists (logit of class c of scene b = cls[..][cidx[off_b + c]]); NULL = the
+ *  scene's classes are columns 0 .. C1-1.  max_gt = max g_b (<= 64); min_query_slack = min over scenes with g_b > 0 of
+ *  n_b - (topk_b + 1) (must be >= 0, as torch.topk requires in the reference).
+ *  loss [1] = sum over layers of lw_cls * mean_b(w_b CE_b) + lw_box * mean over scenes with matches (w_b DIoU_b);
+ *  dcls [L][n_tot][CU] / dbox [L][n_tot][BD] receive d loss / d cls (zero in columns outside the scene's class list), d loss / d box.
+ *  ws: u3d_criterion_ws_bytes. */
 int u3d_criterion_packed(const float* cls, const float* box, const int32_t* cu, const int32_t* gt_off, const int64_t* gt_labels,
-                         const float* gt_boxes, const uint8_t* qmask, const int64_t* qm_off, int L, int B, int64_t n_tot, int C1, int64_t G,
-                         int64_t P, int max_gt, int min_queries_with_gt, int topk, float w_cls, float w_box, float non_obj_w, float ds_w,
-                         float lw_cls, float lw_box, float* loss, float* dcls, float* dbox, void* ws, u3d_stream_t stream);
+                         const float* gt_boxes, const uint8_t* qmask, const int64_t* qm_off, const int32_t* scene_meta,
+                         const float* scene_w, const int32_t* cidx, int L, int B, int64_t n_tot, int CU, int BD, int64_t G, int64_t P,
+                         int max_gt, int min_query_slack, float w_cls, float w_box, float non_obj_w, float lw_cls, float lw_box,
+                         float* loss, float* dcls, float* dbox, void* ws, u3d_stream_t stream);
 int64_t u3d_criterion_ws_bytes(int L, int B, int64_t n_tot, int64_t G, int64_t P);
 /* box decode of a yaw-free head in one pass each way: PredBBox's exp of the six face distances + _bbox_pred_to_bbox
  * (unidet3d/encoder.py:99-111, :241-271): raw [M][8] (Linear output), centers [M][3] -> box [M][6] (centre, size);

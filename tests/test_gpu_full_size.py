@@ -211,7 +211,16 @@ def test_cfg4_joint_config_mixed_batch_vs_oracle():
     O = PA.oracle_forward(orac, scenes, names, **kw)
     run = lambda m: PA.oracle_forward(m, scenes, names, **kw)  # noqa: E731
     g64 = PA.oracle_fp64_grads(orac, run)
-    P = PA.product_forward(prod, inputs, samples, relu_masks=True)
+    import collections
+    from unidet3d_amd import _lib as L
+    calls, orig_call = collections.Counter(), L.call
+    L.call = lambda name, *a: (calls.update([name]), orig_call(name, *a))[1]
+    try:
+        P = PA.product_forward(prod, inputs, samples, relu_masks=True)
+    finally:
+        L.call = orig_call
+    # the criterion of the mixed batch (six datasets, rotated ARKitScenes boxes) is ONE call of the fused kernel set (5 launches)
+    assert calls['u3d_criterion_packed'] == 1, calls
     g64m, _ = PA.oracle_fp64_grads_same_activation_pattern(orac, run, P['relu_masks'])
     assert P['out']['bboxes'][1].shape[1] == 7 and P['out']['bboxes'][0].shape[1] == 6            # ARKitScenes head is 7-dof
     for i, ds in enumerate(samples):                                           # target assignment is integer work: exact

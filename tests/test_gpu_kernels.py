@@ -205,8 +205,8 @@ def test_batchnorm_relu_fwd_bwd(C, relu):
         assert _rel(bn_g(x.to(_dev()), relu=relu), ye) < 1e-5
 
 
-@pytest.mark.parametrize('cin,cout,n_points,vs', [(32, 32, 30_000, 0.02), (16, 32, 12_000, 0.05), (64, 64, 30_000, 0.02), (96, 64, 9_000, 0.05),
-                                                   (128, 128, 60_000, 0.02), (32, 96, 3_000, 0.05)])
+@pytest.mark.parametrize('cin,cout,n_points,vs', [(32, 32, 30_000, 0.02), (16, 32, 12_000, 0.05), (64, 64, 30_000, 0.02), (128, 64, 9_000, 0.05),
+                                                   (128, 128, 60_000, 0.02), (96, 96, 3_000, 0.05)])
 def test_batchnorm_statistics_from_the_convolution_epilogue(cin, cout, n_points, vs):
     """conv -> BN(+ReLU) with the statistics taken from the per-tile column sums the convolution kernel writes on its way out
     (no pass over the conv output) == the same pair with the norm making its own statistics pass, and == torch in float64:
@@ -227,7 +227,8 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(cin, cout, n_points,
         try:
             bn = sparse.SparseBatchNorm(cout).to(_dev())
             bn.weight.data.copy_(gamma); bn.bias.data.copy_(beta)
-            xd, wd, ad = x.clone().to(_dev()).requires_grad_(), w.clone().to(_dev()).requires_grad_(), add.clone().to(_dev()).requires_grad_()
+            # (the 16-channel case is the network's zero-padded 6-channel input: no input gradient exists for it)
+            xd, wd, ad = x.clone().to(_dev()).requires_grad_(cin % 32 == 0), w.clone().to(_dev()).requires_grad_(), add.clone().to(_dev()).requires_grad_()
             st = {}
             f = sparse.sparse_conv(xd, wd, rb, 'fwd', ad, st)
             assert ('partial' in st) == (mode and sparse._plan(cin, cout, 27, n)[1] == 1)
@@ -246,9 +247,10 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(cin, cout, n_points,
     ref = dict(f=fo, y=yo, dx=xo.grad, dw=wo.grad, da=ao.grad, dg=bo.weight.grad, db=bo.bias.grad, rm=bo.running_mean, rv=bo.running_var)
     for mode in (True, False):
         for k, v in ref.items():
-            assert _rel(res[mode][k], v) < 1e-4, (mode, k, _rel(res[mode][k], v))
+            if res[mode][k] is not None:
+                assert _rel(res[mode][k], v) < 1e-4, (mode, k, _rel(res[mode][k], v))
         assert res[mode]['nbt'] == 1
-    for k in ('y', 'dx', 'rm', 'rv'):
+    for k in ('y', 'dw', 'rm', 'rv'):
         assert _rel(res[True][k], res[False][k]) < 2e-6, k
 
 

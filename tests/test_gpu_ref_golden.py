@@ -15,10 +15,12 @@ DEV = 'cuda:0'
 C, D, T = R.C, R.D, R.T
 
 
-@pytest.mark.parametrize('tag,packed,fused', [('C1', False, False), ('C1', True, False), ('C1', True, True), ('C2', False, False), ('C3', False, False),
-                                              ('C3', True, False), ('C3', True, True)])
+@pytest.mark.parametrize('tag,packed,fused', [('C1', False, False), ('C1', True, False), ('C1', True, True), ('C2', False, False), ('C2', True, True),
+                                              ('C3', False, False), ('C3', True, False), ('C3', True, True)])
 def test_criterion_on_device_matches_reference(tag, packed, fused):
-    """per-scene loop, batched tensor ops and the fused kernel (csrc/criterion.hip) against the reference's values"""
+    """per-scene loop, batched tensor ops and the fused kernel (csrc/criterion.hip) against the reference's values; C2 = a mixed
+    batch of the joint config (three datasets, per-dataset top-k / weights, 7-dof ARKitScenes boxes -> rotated DIoU in matcher and
+    loss): ('C2', True, True) runs it through the kernel's mixed-batch form"""
     worst = R.check_product_criterion(tag, DEV, packed, fused)
     import _parity as PA
     PA.log_errors(f'criterion_golden_{tag}_{"fused" if fused else ("packed" if packed else "loop")}', dict(grad_rel=worst))
@@ -66,6 +68,66 @@ def test_fused_criterion_matches_tensor_op_path_at_bench_sizes(B, n_lo, n_hi, g_
     assert abs(float(res[True][0]) - float(res[False][0])) < 2e-6 * abs(float(res[False][0])), (res[True][0], res[False][0])
     for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
         assert R.rel(a, b) < 2e-5
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_fused_criterion_mixed_batch_with_rotated_boxes_matches_the_per_scene_path(seed):
+    """csrc/criterion.hip on a random MIXED batch (three datasets with different class counts, top-k and weights; one of them with
+    7-dof boxes: rotated DIoU through dual numbers) vs the per-scene tensor-op path (criterion.get_layer_loss, pinned by the
+    reference goldens C2 / F.rot): loss and every gradient, incl. the zero gradients in the columns of other datasets."""
+    import _parity as PA
+    from unidet3d_amd.structures import DepthInstance3DBoxes, InstanceData_
+    from unidet3d_amd.registry import MODELS
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(100 + seed)
+    crit_cfg = dict(R.JOINT_CRIT)
+    names = ['scannet', 'arkitscenes', 's3dis', 'arkitscenes', 'scannet', 's3dis'][:5 + seed]
+    n_cls = dict(scannet=18, s3dis=5, arkitscenes=17)
+    L, B = 3, len(names)
+    sizes = [int(torch.randint(40, 400, (1,), generator=g)) for _ in names]
+    gts = [int(torch.randint(1, 9, (1,), generator=g)) for _ in names]
+    gts[2] = 0                                                               # a scene without ground truth
+    insts, cls, box = [], [[] for _ in range(L)], [[] for _ in range(L)]
+    for name, n, k in zip(names, sizes, gts):
+        yaw = name == 'arkitscenes'
+        gtb = torch.cat((torch.rand(k, 3, generator=g) * 3, torch.rand(k, 3, generator=g) + 0.3), 1)
+        if yaw:
+            gtb = torch.cat((gtb, (torch.rand(k, 1, generator=g) - 0.5) * 2.4), 1)
+        qm = torch.rand(k, n, generator=g) < 0.4
+        insts.append(InstanceData_(labels_3d=torch.randint(0, n_cls[name], (k,), generator=g).to(DEV), query_masks=qm.to(DEV),
+                                   bboxes_3d=DepthInstance3DBoxes(gtb, with_yaw=yaw, box_dim=7 if yaw else 6, origin=(0.5, 0.5, 0.5)).to(DEV)))
+        for l in range(L):
+            cls[l].append(torch.randn(n, n_cls[name] + 1, generator=g) * 1.5)
+            b = torch.cat((torch.rand(n, 3, generator=g) * 3, torch.rand(n, 3, generator=g) + 0.3), 1)
+            if yaw:
+                b = torch.cat((b, (torch.rand(n, 1, generator=g) - 0.5) * 2.4), 1)
+            if k:
+                near = gtb[torch.randint(0, k, (n,), generator=g)] + torch.randn(n, gtb.shape[1], generator=g) * 0.08
+                near[:, 3:6] = near[:, 3:6].abs() + 0.05
+                b = torch.where((torch.rand(n, generator=g) < 0.5)[:, None], near, b)
+            box[l].append(b)
+    res = {}
+    for fused in (True, False):
+        lc = [[t.clone().to(DEV).requires_grad_() for t in c] for c in cls]
+        lb = [[t.clone().to(DEV).requires_grad_() for t in b] for b in box]
+        pred = dict(cls_preds=lc[0], bboxes=lb[0], aux_outputs=[dict(cls_preds=lc[l], bboxes=lb[l]) for l in range(1, L)])
+        if fused:
+            CU = max(n_cls.values()) + 1
+            pred['_packed'] = dict(cls=[torch.cat([F.pad(t, (0, CU - t.shape[1])) for t in c]) for c in lc],
+                                   box=[torch.cat([F.pad(t, (0, 7 - t.shape[1])) for t in b]) for b in lb], sizes=sizes,
+                                   cidx=[list(range(n_cls[nm] + 1)) for nm in names], yaw=[nm == 'arkitscenes' for nm in names])
+        crit = MODELS.build(crit_cfg)
+        crit.fused = fused
+        assert crit._can_fuse(pred, insts, names) == fused
+        loss = crit(pred, insts, names)['det_loss']
+        (loss * 1.3).backward()
+        res[fused] = (float(loss.detach()), [t.grad for c in lc for t in c], [t.grad if t.grad is not None else torch.zeros_like(t) for b in lb for t in b])
+    e_loss = abs(res[True][0] - res[False][0]) / abs(res[False][0])
+    e_cls = max(R.rel(a, b) for a, b in zip(res[True][1], res[False][1]))
+    e_box = max(R.rel(a, b) for a, b in zip(res[True][2], res[False][2]) if float(b.abs().max()) > 0)
+    PA.log_errors(f'criterion_fused_mixed_rotated_seed{seed}', dict(loss_rel=e_loss, dcls=e_cls, dbox=e_box, loss=res[False][0]))
+    print('fused mixed/rotated criterion vs per-scene path:', e_loss, e_cls, e_box)
+    assert e_loss < 1e-5 and e_cls < 1e-4 and e_box < 1e-3
 
 
 def test_rotated_diou_values_and_gradients_on_device():

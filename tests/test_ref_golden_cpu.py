@@ -61,9 +61,16 @@ def load_case(tag, device='cpu', packed=False):
         insts.append(InstanceData_(labels_3d=T(C[f'{tag}.s{i}.labels']).to(device), query_masks=T(C[f'{tag}.s{i}.qm']).to(device),
                                    bboxes_3d=DepthInstance3DBoxes(gtb.reshape(-1, dof), with_yaw=dof == 7, box_dim=dof, origin=(0.5, 0.5, 0.5))))
     pred = dict(cls_preds=cls[0], bboxes=box[0], aux_outputs=[dict(cls_preds=cls[l], bboxes=box[l]) for l in range(1, L)])
-    if packed:       # what UniDet3DEncoder adds for a single-dataset batch: [sum n_i, .] matrices, final layer first
+    if packed and len(set(names)) == 1:       # what UniDet3DEncoder adds for a single-dataset batch: [sum n_i, .] matrices, final layer first
         pc_, pb_ = [torch.cat(c) for c in cls], [torch.cat(b) for b in box]
         pred['_packed'] = dict(cls=pc_, box=pb_, sizes=[int(t.shape[0]) for t in cls[0]])
+    elif packed:     # ... and for a mixed batch: logits in a common width (a scene's classes first), boxes in 7 columns, plus which is which
+        F = torch.nn.functional
+        CU = max(int(t.shape[1]) for t in cls[0])
+        pc_ = [torch.cat([F.pad(t, (0, CU - t.shape[1])) for t in c]) for c in cls]
+        pb_ = [torch.cat([F.pad(t, (0, 7 - t.shape[1])) for t in b]) for b in box]
+        pred['_packed'] = dict(cls=pc_, box=pb_, sizes=[int(t.shape[0]) for t in cls[0]], cidx=[list(range(int(t.shape[1]))) for t in cls[0]],
+                               yaw=[int(t.shape[1]) == 7 for t in box[0]])
     return cfg, pred, insts, names, cls, box
 
 
@@ -125,7 +132,7 @@ def check_product_criterion(tag, device, packed, fused=True):
     crit = MODELS.build(cfg)
     crit.fused = fused          # on a GPU the packed single-dataset path runs csrc/criterion.hip unless told otherwise
     if packed:
-        assert crit._can_pack(pred, insts, names)
+        assert crit._can_pack(pred, insts, names) or (fused and crit._can_fuse(pred, insts, names))
     loss = crit(pred, insts, names)['det_loss']
     want = float(C[f'{tag}.loss'])
     assert abs(float(loss) - want) < 2e-6 * abs(want), (float(loss), want)

@@ -69,7 +69,7 @@ PROTOTYPES = {
     'u3d_segment_gather_sum': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     'u3d_segment_mean_xyz': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     'u3d_segment_minmax_xyz': (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
-    'u3d_criterion_packed': (_i32, [_vp] * 8 + [_i32, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_criterion_packed': (_i32, [_vp] * 11 + [_i32, _i32, _i64, _i32, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_box_decode_fwd': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'u3d_box_decode_bwd': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'u3d_criterion_ws_bytes': (_i64, [_i32, _i32, _i64, _i64, _i64]),

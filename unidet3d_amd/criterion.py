@@ -221,14 +221,15 @@ class _FusedCriterionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cls, box, g, consts):
         cls, box = cls.contiguous(), box.contiguous()
-        Ln, n_tot, C1 = cls.shape
+        Ln, n_tot, CU = cls.shape
+        BD = box.shape[-1]
         dev = cls.device
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         dcls, dbox = torch.empty_like(cls), torch.empty_like(box)
         ws = L.scratch(L.lib().u3d_criterion_ws_bytes(Ln, g['B'], n_tot, g['G'], g['P']), dev)
         L.call('u3d_criterion_packed', L.ptr(cls), L.ptr(box), L.ptr(g['cu']), L.ptr(g['gt_off']), L.ptr(g['labels']), L.ptr(g['boxes']),
-               L.ptr(g['qmask']), L.ptr(g['qm_off']), Ln, g['B'], n_tot, C1, g['G'], g['P'], g['max_gt'], g['min_q'], *consts,
-               L.ptr(loss), L.ptr(dcls), L.ptr(dbox), L.ptr(ws), L.stream())
+               L.ptr(g['qmask']), L.ptr(g['qm_off']), L.ptr(g['meta']), L.ptr(g['scene_w']), L.ptr(g['cidx']), Ln, g['B'], n_tot, CU, BD,
+               g['G'], g['P'], g['max_gt'], g['slack'], *consts, L.ptr(loss), L.ptr(dcls), L.ptr(dbox), L.ptr(ws), L.stream())
         ctx.save_for_backward(dcls, dbox)
         return loss[0]
 
@@ -297,14 +298,29 @@ class UniDet3DCriterion:
     # Same arithmetic as get_layer_loss, but every scene of the batch goes through ONE set of
     # [B, n_max, g_max] tensor ops instead of a Python loop of ~70 small kernels per (layer, scene):
     # the reference's loop (criterion.py:79-134) costs thousands of launches per step on a GPU.
-    def _can_pack(self, pred, insts, datasets_names):
-        if '_packed' not in pred or len(set(datasets_names)) != 1 or not self.iter_matcher:
-            return False
-        if not (isinstance(self.matcher, UniMatcher) and len(self.matcher.costs) == 2 and
+    def _matcher_ok(self):
+        return (isinstance(self.matcher, UniMatcher) and len(self.matcher.costs) == 2 and
                 isinstance(self.matcher.costs[0], QueryClassificationCost) and
-                isinstance(self.matcher.costs[1], BboxCostJointTraining)):
+                isinstance(self.matcher.costs[1], BboxCostJointTraining))
+
+    def _can_pack(self, pred, insts, datasets_names):
+        """single-dataset yaw-free batch with the decoder's packed head outputs: the batched tensor-op formulation applies"""
+        if '_packed' not in pred or len(set(datasets_names)) != 1 or not self.iter_matcher or not self._matcher_ok():
             return False
-        return all((not i.bboxes_3d.with_yaw) for i in insts) and pred['_packed']['box'][0].shape[-1] == 6
+        pk = pred['_packed']
+        return pk.get('cidx') is None and all((not i.bboxes_3d.with_yaw) for i in insts) and pk['box'][0].shape[-1] == 6
+
+    def _can_fuse(self, pred, insts, datasets_names):
+        """what csrc/criterion.hip takes: the decoder's packed head outputs of ANY batch -- one dataset or several, 6-dof boxes
+        or boxes with a heading -- under the reference configs' matcher and DIoU losses"""
+        if '_packed' not in pred or not self.iter_matcher or not self.fused or not self._fusable():
+            return False
+        pk = pred['_packed']
+        if not (pk['cls_stacked'] if 'cls_stacked' in pk else pk['cls'][0]).is_cuda:
+            return False
+        bd = (pk['box_stacked'] if 'box_stacked' in pk else pk['box'][0]).shape[-1]
+        yaw = pk.get('yaw') or [bd == 7] * len(insts)
+        return all(bool(i.bboxes_3d.with_yaw) == bool(y) or len(i) == 0 for i, y in zip(insts, yaw))
 
     def _pack_gt(self, insts, sizes, device):
         B, g_max, n_max = len(insts), max(max(len(i) for i in insts), 1), max(sizes)
@@ -380,21 +396,35 @@ class UniDet3DCriterion:
         return (self.loss_weight[0] * cls_loss + self.loss_weight[1] * bbox_loss).sum()
 
     # ---- fused device path (csrc/criterion.hip) ---------------------------------------------------
-    def _flat_gt(self, insts, sizes, device, topk):
-        """Ragged GT of the batch as flat device arrays for u3d_criterion_packed; None when the kernel's limits do not hold
-        (> 64 GTs in a scene, or a scene with GT but fewer than topk + 1 queries -- left to the tensor-op path)."""
+    def _flat_gt(self, insts, sizes, device, topks, weights, c1s, yaw, cidx, bd):
+        """Ragged GT and per-scene dataset constants of the batch as flat device arrays for u3d_criterion_packed; None when the
+        kernel's limits do not hold (> 64 GTs in a scene, or a scene with GT but fewer than topk + 1 queries -- left to the
+        per-scene path, which raises like the reference)."""
         gs = [len(i) for i in insts]
-        if max(gs, default=0) > 64 or any(g and n < topk + 1 for g, n in zip(gs, sizes)):
+        if max(gs, default=0) > 64 or any(g and n < k + 1 for g, n, k in zip(gs, sizes, topks)):
             return None
         cu, go, qo = [0], [0], [0]
         for n, g in zip(sizes, gs):
             cu.append(cu[-1] + n); go.append(go[-1] + g); qo.append(qo[-1] + n * g)
         with_gt = [i for i in insts if len(i)]
         labels = torch.cat([i.labels_3d for i in with_gt]) if with_gt else None
-        boxes = torch.cat([_gt_boxes(i.bboxes_3d) for i in with_gt]).float().contiguous() if with_gt else None
+        boxes = None
+        if with_gt:
+            rows = [_gt_boxes(i.bboxes_3d).float() for i in with_gt]
+            rows = [r if r.shape[1] == bd else torch.nn.functional.pad(r, (0, bd - r.shape[1])) for r in rows]
+            boxes = torch.cat(rows).contiguous()
         qmask = torch.cat([i.query_masks.reshape(-1) for i in with_gt]).contiguous().view(torch.uint8) if with_gt else None
-        return dict(B=len(insts), G=go[-1], P=qo[-1], max_gt=max(gs, default=0), min_q=min([n for g, n in zip(gs, sizes) if g], default=0),
+        meta, coff, cflat = [], 0, []
+        for b in range(len(insts)):
+            meta.append([int(c1s[b]), int(topks[b]), int(bool(yaw[b])), coff])
+            if cidx is not None:
+                cflat.extend(int(c) for c in cidx[b])
+                coff += len(cidx[b])
+        return dict(B=len(insts), G=go[-1], P=qo[-1], max_gt=max(gs, default=0),
+                    slack=min([n - (k + 1) for g, n, k in zip(gs, sizes, topks) if g], default=0),
                     cu=_h2d(cu, torch.int32, device), gt_off=_h2d(go, torch.int32, device), qm_off=_h2d(qo, torch.int64, device),
+                    meta=_h2d(meta, torch.int32, device), scene_w=_h2d([float(w) for w in weights], torch.float32, device),
+                    cidx=_h2d(cflat, torch.int32, device) if cidx is not None else None,
                     labels=labels, boxes=boxes, qmask=qmask)
 
     @staticmethod
@@ -404,14 +434,22 @@ class UniDet3DCriterion:
             return pk['cls_stacked'], pk['box_stacked']
         return torch.stack(pk['cls']), torch.stack(pk['box'])
 
-    def _loss_fused(self, pk, insts, name):
-        idx = self.datasets.index(name)
+    def _loss_fused(self, pk, insts, names):
+        """``names``: the dataset of every scene.  ``pk`` (UniDet3DEncoder): stacked logits [L, sum n_i, CU] and boxes [L, sum n_i, 6 | 7]
+        plus, for a mixed batch, ``cidx`` (per scene: the columns of its dataset's classes, "no object" last) and ``yaw`` (per scene:
+        its boxes carry a heading)."""
         cls, box = self._stacked(pk)
-        g = self._flat_gt(insts, pk['sizes'], cls.device, self.topk[idx])
+        B, bd = len(insts), box.shape[-1]
+        idxs = [self.datasets.index(n) for n in names]
+        cidx = pk.get('cidx')
+        c1s = [len(c) for c in cidx] if cidx is not None else [cls.shape[-1]] * B
+        yaw = pk.get('yaw') or [bd == 7] * B
+        g = self._flat_gt(insts, pk['sizes'], cls.device, [self.topk[i] for i in idxs], [self.datasets_weights[i] for i in idxs], c1s, yaw,
+                          cidx, bd)
         if g is None:
             return None
-        consts = (int(self.topk[idx]), float(self.matcher.costs[0].weight), float(self.matcher.costs[1].weight),
-                  float(self.non_object_weight), float(self.datasets_weights[idx]), float(self.loss_weight[0]), float(self.loss_weight[1]))
+        consts = (float(self.matcher.costs[0].weight), float(self.matcher.costs[1].weight), float(self.non_object_weight),
+                  float(self.loss_weight[0]), float(self.loss_weight[1]))
         return _FusedCriterionFn.apply(cls, box, g, consts)
 
     def _fusable(self):
@@ -423,19 +461,21 @@ class UniDet3DCriterion:
         c = costs[1]
         if getattr(c.loss_simple, 'reduction', None) != 'none':
             return False
-        return (isinstance(c.loss_simple, UniDet3DAxisAlignedIoULoss) and c.loss_simple.mode == 'diou' and c.loss_simple.loss_weight == 1.0 and
+        rot_ok = all(isinstance(r, UniDet3DRotatedIoU3DLoss) and r.mode == 'diou' and r.loss_weight == 1.0 and r.reduction == 'none'
+                     for r in (c.loss_rotated, self.bbox_loss_rotated))
+        return (rot_ok and isinstance(c.loss_simple, UniDet3DAxisAlignedIoULoss) and c.loss_simple.mode == 'diou' and c.loss_simple.loss_weight == 1.0 and
                 isinstance(self.bbox_loss_simple, UniDet3DAxisAlignedIoULoss) and self.bbox_loss_simple.mode == 'diou' and
                 self.bbox_loss_simple.loss_weight == 1.0 and self.bbox_loss_simple.reduction == 'none')
 
-    fused = True        # device kernel for single-dataset yaw-free batches; False forces the tensor-op formulation (tests)
+    fused = True        # device kernel (csrc/criterion.hip) for packed head outputs; False forces the tensor-op formulations (tests)
 
     def __call__(self, pred, insts, datasets_names):
+        if self._can_fuse(pred, insts, datasets_names):
+            loss = self._loss_fused(pred['_packed'], insts, datasets_names)
+            if loss is not None:
+                return {'det_loss': loss}
         if self._can_pack(pred, insts, datasets_names):
             pk = pred['_packed']
-            if self.fused and pk['cls'][0].is_cuda and self._fusable():
-                loss = self._loss_fused(pk, insts, datasets_names[0])
-                if loss is not None:
-                    return {'det_loss': loss}
             gt = self._pack_gt(insts, pk['sizes'], pk['cls'][0].device)
             # final layer + the aux layers, each re-matched (iter_matcher), in one batched pass
             return {'det_loss': self._loss_packed(*self._stacked(pk), gt, datasets_names[0])}

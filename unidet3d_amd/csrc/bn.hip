@@ -4,6 +4,8 @@
 // sums can be all-reduced across data-parallel ranks (SyncBatchNorm) between stats and apply.
 // Replaces nn.SyncBatchNorm / nn.BatchNorm1d(eps=1e-4, momentum=0.1) + nn.ReLU at
 // unidet3d/spconv_unet.py:42,49,119-124,147,177 and unidet3d/unidet3d.py:104-111.
+#include <stdlib.h>
+
 #include "u3d_common.h"
 
 namespace u3d {
@@ -25,16 +27,10 @@ struct BnFin {
     int64_t* nbt;
 };
 
-__device__ __forceinline__ void bn_finish(const double* partial, int nblk, int C, const BnFin& f, int* ticket) {
-    __shared__ int is_last;
-    __threadfence();                                   // release: this workgroup's partial row
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == nblk - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();                                   // acquire: the other workgroups' rows
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int c = wave; c < C; c += nw) {               // one wave per channel: lanes over rows, fixed shuffle tree
+// channels c = wave0, wave0 + nw, ...: one wave per channel, lanes over the partial rows, fixed shuffle tree
+__device__ __forceinline__ void bn_finish_body(const double* partial, int nblk, int C, const BnFin& f, int wave0, int nw, bool first) {
+    const int lane = threadIdx.x & 63;
+    for (int c = wave0; c < C; c += nw) {
         double t1 = 0.0, t2 = 0.0;
         for (int b = lane; b < nblk; b += 64) {
             t1 += partial[(int64_t)b * 2 * C + c];
@@ -62,11 +58,32 @@ __device__ __forceinline__ void bn_finish(const double* partial, int nblk, int C
             f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
         }
     }
-    if (threadIdx.x == 0) {
+    if (first && threadIdx.x == 0) {
         if (f.set_rows) f.sums[2 * C] = f.rows;
         if (f.nbt) *f.nbt += 1;
-        *ticket = 0;                                   // ready for the next launch on this stream
     }
+}
+
+// ticket != nullptr: threadfence reduction -- the last workgroup to arrive runs bn_finish_body (one launch instead of two).
+// Measured on MI355X (round 3, visit B): with a full fence in every workgroup the statistics kernels became 3-6x SLOWER (an
+// agent-scope acquire invalidates the XCD's L2 under the workgroups still streaming x), hence release-only on the way in,
+// acquire only in the last workgroup, and the two-launch form (ticket == nullptr + bn_sum_k) as the default until measured again.
+__device__ __forceinline__ void bn_finish(const double* partial, int nblk, int C, const BnFin& f, int* ticket) {
+    if (!ticket) return;                               // kernel-uniform
+    __shared__ int is_last;
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the wave that wrote this workgroup's partial row
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == nblk - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bn_finish_body(partial, nblk, C, f, threadIdx.x >> 6, blockDim.x >> 6, true);
+    if (threadIdx.x == 0) *ticket = 0;                 // ready for the next launch on this stream
+}
+
+// second launch of the two-launch form: 4 channels per workgroup
+__global__ __launch_bounds__(256) void bn_sum_k(const double* __restrict__ partial, int nblk, int C, BnFin f) {
+    bn_finish_body(partial, nblk, C, f, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, blockIdx.x == 0);
 }
 
 // mode 0: sums = [sum x, sum x^2]; mode 1: backward sums [sum dy', sum dy'*xhat]
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(256) void bn_partials_k(const float* __restrict__ p
         }
         __syncthreads();
     }
+    if (ticket) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // up to 256 threads wrote the row
     bn_finish(ws, gridDim.x, C, fin, ticket);
 }
 
@@ -288,6 +306,17 @@ static int bn_partials_grid(int64_t n_tiles, int C) {
 
 int64_t u3d_bn_ws_bytes(int C) { return (int64_t)256 * 2 * C * sizeof(double) + 64; }
 
+// U3D_BN_FINISH=ticket: one launch (threadfence reduction); default: statistics kernel + bn_sum_k
+static bool bn_ticket_mode() {
+    static const bool on = [] { const char* e = getenv("U3D_BN_FINISH"); return e && e[0] == 't'; }();
+    return on;
+}
+static int bn_finish_launch(const void* ws, int nblk, int C, const BnFin& f, hipStream_t s) {
+    if (bn_ticket_mode()) return U3D_OK;
+    hipLaunchKernelGGL(bn_sum_k, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)ws, nblk, C, f);
+    return check_launch("bn_sum");
+}
+
 static BnFin bn_fin(double* sums, double rows, int set_rows) {
     BnFin f;
     f.sums = sums; f.rows = rows; f.set_rows = set_rows; f.gamma = nullptr; f.beta = nullptr; f.eps = 0.f; f.momentum = 0.f;
@@ -301,13 +330,15 @@ static int bn_stats_launch(const float* x, int64_t n, int C, const float* partia
     if (partial) {
         if (n_tiles <= 0) return U3D_EINVAL;
         ProfScope prof(U3D_K_BN, s, (double)n_tiles * C * 8);
-        hipLaunchKernelGGL(bn_partials_k, dim3(bn_partials_grid(n_tiles, C)), dim3(256), 0, s, partial, n_tiles, C, (double*)ws, f, (int*)ticket);
-    } else {
-        ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
-        hipLaunchKernelGGL(bn_reduce_k<0>, dim3(bn_grid(n, C)), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws, f, (int*)ticket);
+        const int g = bn_partials_grid(n_tiles, C);
+        hipLaunchKernelGGL(bn_partials_k, dim3(g), dim3(256), 0, s, partial, n_tiles, C, (double*)ws, f, bn_ticket_mode() ? (int*)ticket : (int*)nullptr);
+        return bn_finish_launch(ws, g, C, f, s);
     }
-    return check_launch("bn_stats");
+    ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
+    const int g = bn_grid(n, C);
+    hipLaunchKernelGGL(bn_reduce_k<0>, dim3(g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws, f, bn_ticket_mode() ? (int*)ticket : (int*)nullptr);
+    return bn_finish_launch(ws, g, C, f, s);
 }
 
 int u3d_bn_stats(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, double* sums, void* ws, int32_t* ticket,
@@ -340,9 +371,11 @@ int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const f
     if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !ws || !ticket || !bn_ok(n, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
-    hipLaunchKernelGGL(bn_reduce_k<1>, dim3(bn_grid(n, C)), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws,
-                       bn_fin(sums, 0.0, 0), (int*)ticket);
-    return check_launch("bn_bwd_stats");
+    const int g = bn_grid(n, C);
+    const BnFin f = bn_fin(sums, 0.0, 0);
+    hipLaunchKernelGGL(bn_reduce_k<1>, dim3(g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws,
+                       f, bn_ticket_mode() ? (int*)ticket : (int*)nullptr);
+    return bn_finish_launch(ws, g, C, f, s);
 }
 
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,

@@ -1,11 +1,14 @@
-// R12 on the device in five launches: matcher + classification / box losses of all decoder layers and scenes of a
-// single-dataset batch, forward AND gradients (the reference: unidet3d/criterion.py:44-178 UniDet3DCriterion.get_layer_loss /
-// __call__, :200-320 the cost classes and UniMatcher, unidet3d/axis_aligned_iou_loss.py:14-53 axis_aligned_diou_loss; yaw-free
-// boxes).  The torch-op formulation of the same arithmetic (unidet3d_amd/criterion.py::_loss_packed) costs ~380 launches of
-// [layers, scenes, n, g] tensor ops per step; here
-//   crit_cost_k   one thread per (layer, query): log-sum-exp of the logits, cost[q][j] of every GT of the query's scene
-//                 (-softmax[label_j] w_cls + (1 - IoU + centre term of GT 0 -- the reference's `[:, 0]` quirk) w_box, 1e8 where the
-//                 GT's query mask forbids the query);
+// R12 on the device in five launches: matcher + classification / box losses of all decoder layers and scenes of a batch,
+// forward AND gradients (the reference: unidet3d/criterion.py:44-178 UniDet3DCriterion.get_layer_loss / __call__, :200-320 the
+// cost classes and UniMatcher, unidet3d/axis_aligned_iou_loss.py:14-53 axis_aligned_diou_loss, unidet3d/rotated_iou_loss.py:14-82
+// diff_diou_rotated_3d / rotated_diou_3d_loss over mmcv's rectangle intersection).  Round 3: MIXED batches of the joint config --
+// every scene carries its own class-column list (dataset), top-k, dataset weight and box parametrisation (6-dof axis-aligned or
+// 7-dof with a heading: the rotated DIoU for both the matcher cost and the loss, with analytic gradients).
+// The torch-op formulation of the same arithmetic costs ~380 launches of [layers, scenes, n, g] tensor ops per step for one
+// dataset and a Python loop of ~70 launches per (layer, scene) for a mixed batch; here
+//   crit_cost_k   one thread per (layer, query): log-sum-exp of the scene's class columns, cost[q][j] of every GT of the query's
+//                 scene (-softmax[label_j] w_cls + box cost w_box, 1e8 where the GT's query mask forbids the query); box cost =
+//                 1 - IoU + centre term of GT 0 (the reference's `[:, 0]` quirk of the axis-aligned form) or 1 - rotated DIoU;
 //   crit_kth_k    one wave per (layer, scene, GT): the (topk+1)-th smallest cost of the column by k rounds of lexicographic
 //                 (value, index) minimum extraction -- the threshold of `cost < values` (:316-319);
 //   crit_stats_k  one workgroup per (layer, scene): matched set (a 64-bit GT mask per query), class target = label of the LAST
@@ -13,8 +16,11 @@
 //                 fixed order (no atomics);
 //   crit_final_k  one thread: the scalar loss (means over scenes / scenes with matches, sum over layers) and the per-layer scale
 //                 factors of the gradients;
-//   crit_grad_k   one thread per (layer, query): d loss / d logits (softmax - one-hot, weighted) and d loss / d box (analytic DIoU
-//                 derivative through _bbox_to_loss, sub-gradients of min / max / clamp as torch takes them).
+//   crit_grad_k   one thread per (layer, query): d loss / d logits (softmax - one-hot, weighted; zero in the columns of other
+//                 datasets) and d loss / d box: the analytic DIoU derivative through _bbox_to_loss for axis-aligned boxes (sub-
+//                 gradients of min / max / clamp as torch takes them); for rotated boxes the SAME routine that computes the value
+//                 is run on dual numbers (value + 7 tangents), i.e. forward-mode differentiation of exactly the branch taken --
+//                 what autograd does to the reference's tensor program.
 #include <math.h>
 
 #include "u3d_common.h"
@@ -22,24 +28,27 @@
 namespace u3d {
 
 struct CritParams {
-    const float* cls;          // [L][n_tot][C1]
-    const float* box;          // [L][n_tot][6]  (centre, size)
+    const float* cls;          // [L][n_tot][CU]
+    const float* box;          // [L][n_tot][BD]  (centre, size[, heading]); BD = 6 or 7
     const int32_t* cu;         // [B+1] first query of every scene
     const int32_t* gt_off;     // [B+1] first GT of every scene
-    const int64_t* gt_labels;  // [G]
-    const float* gt_boxes;     // [G][6]
+    const int64_t* gt_labels;  // [G]   (index into the scene's class list)
+    const float* gt_boxes;     // [G][BD]
     const uint8_t* qmask;      // scene b: [g_b][n_b] at qm_off[b]
     const int64_t* qm_off;     // [B+1]; also the offset of scene b's [n_b][g_b] block in `cost`
-    int L, B, C1, topk;
+    const int32_t* meta;       // [B][4]: classes + 1 of the scene's dataset, top-k, 1 = boxes carry a heading, offset into cidx
+    const float* scene_w;      // [B] dataset weight
+    const int32_t* cidx;       // class columns of every scene in the CU-wide logit rows (concatenated); nullptr = columns 0..C1-1
+    int L, B, CU, BD;
     int64_t n_tot, G, P;       // P = sum n_b g_b
-    float w_cls, w_box, non_obj_w, ds_w, lw_cls, lw_box;
+    float w_cls, w_box, non_obj_w, lw_cls, lw_box;
     // workspace
     float* cost;               // [L][P]
     float* logz;               // [L][n_tot]
     float* kth;                // [L][G]
     unsigned long long* mm;    // [L][n_tot] matched-GT bit mask
     float* stats;              // [L][B][4]: sum w, sum w nll, matched pairs, sum diou
-    float* scale;              // [L][2]: (unused, box scale) -- written by crit_final_k
+    float* scale;              // [L][2]: (unused, number of scenes with matches) -- written by crit_final_k
     float* loss;               // [1]
     float* dcls;
     float* dbox;
@@ -53,6 +62,7 @@ __device__ __forceinline__ int scene_of(const int32_t* cu, int B, int q) {
     }
     return lo;
 }
+__device__ __forceinline__ int col_of(const CritParams& p, int b, int c) { return p.cidx ? p.cidx[p.meta[b * 4 + 3] + c] : c; }
 
 struct Box6 { float p1[3], p2[3]; };
 __device__ __forceinline__ Box6 corners(const float* b) {      // _bbox_to_loss (criterion.py:180-198)
@@ -83,30 +93,210 @@ __device__ __forceinline__ float centre_term(const Box6& p, const Box6& t) {    
     return r2 / c2;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Rotated DIoU (unidet3d/rotated_iou_loss.py:14-60 over mmcv.ops.diff_iou_rotated: box2corners, box_intersection,
+// box1_in_box2, build_vertices, sort_indices, calculate_area), one (prediction, target) pair, on a scalar type S that is either
+// float (values: the matcher's cost matrix) or Dual (value + tangents w.r.t. the 7 parameters of the predicted box: the loss
+// gradient).  Same stages and constants as the tensor-op formulation in unidet3d_amd/criterion.py, which is pinned by the
+// reference's golden vectors (tests/golden/ref_criterion.npz F.rot, C2): corners, 16 edge-edge intersections with the strict
+// 0 < t, u < 1 test (point = a + t2 (b - a), t2 = den_t / (num + 1e-8)), corners of one rectangle inside the other (1e-6 slack),
+// candidates ordered by angle around their mean (no gradient through the order), shoelace area, |.|, zero below 3 vertices.
+struct Dual {
+    float v, d[7];
+    __device__ __forceinline__ Dual() {}
+    __device__ __forceinline__ Dual(float x) : v(x) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) d[i] = 0.f;
+    }
+};
+__device__ __forceinline__ Dual dual_var(float x, int i) { Dual r(x); r.d[i] = 1.f; return r; }
+__device__ __forceinline__ float val(float x) { return x; }
+__device__ __forceinline__ float val(const Dual& x) { return x.v; }
+__device__ __forceinline__ Dual operator+(const Dual& a, const Dual& b) { Dual r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ Dual operator-(const Dual& a, const Dual& b) { Dual r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ Dual operator-(const Dual& a) { Dual r; r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ Dual operator*(const Dual& a, const Dual& b) { Dual r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ Dual operator/(const Dual& a, const Dual& b) { Dual r; const float inv = 1.f / b.v; r.v = a.v * inv;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv; return r; }
+__device__ __forceinline__ Dual operator*(float a, const Dual& b) { Dual r; r.v = a * b.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.d[i] = a * b.d[i]; return r; }
+__device__ __forceinline__ Dual operator+(const Dual& a, float b) { Dual r = a; r.v += b; return r; }
+__device__ __forceinline__ Dual scaled(const Dual& a, float k) { return k * a; }
+__device__ __forceinline__ float scaled(float a, float k) { return k * a; }
+__device__ __forceinline__ void sincos_of(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
+__device__ __forceinline__ void sincos_of(const Dual& a, Dual& s, Dual& c) {
+    const float sv = sinf(a.v), cv = cosf(a.v);
+    s.v = sv; c.v = cv;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { s.d[i] = cv * a.d[i]; c.d[i] = -sv * a.d[i]; }
+}
+// torch.maximum / torch.minimum: the gradient of a tie is split evenly; clamp(min=0) passes the gradient for x >= 0; |x| has sign(x)
+template <typename S> __device__ __forceinline__ S max2(const S& a, const S& b) { return val(a) > val(b) ? a : (val(a) < val(b) ? b : scaled(a + b, 0.5f)); }
+template <typename S> __device__ __forceinline__ S min2(const S& a, const S& b) { return val(a) < val(b) ? a : (val(a) > val(b) ? b : scaled(a + b, 0.5f)); }
+template <typename S> __device__ __forceinline__ S relu0(const S& a) { return val(a) >= 0.f ? a : S(0.f); }
+template <typename S> __device__ __forceinline__ S abs_of(const S& a) { return val(a) > 0.f ? a : (val(a) < 0.f ? S(0.f) - a : S(0.f)); }
+// x.max(-1)[0] / x.min(-1)[0] over the 4 corners: the gradient goes to the FIRST extremal entry
+template <typename S> __device__ __forceinline__ S max4(const S (&x)[4]) { int k = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (val(x[i]) > val(x[k])) k = i; return x[k]; }
+template <typename S> __device__ __forceinline__ S min4(const S (&x)[4]) { int k = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (val(x[i]) < val(x[k])) k = i; return x[k]; }
+
+template <typename S>
+__device__ __forceinline__ void box2corners(const S& x, const S& y, const S& w, const S& h, const S& a, S (&cx)[4], S (&cy)[4]) {
+    S s, c;
+    sincos_of(a, s, c);
+    const float sx[4] = {0.5f, -0.5f, -0.5f, 0.5f}, sy[4] = {0.5f, 0.5f, -0.5f, -0.5f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const S x4 = scaled(w, sx[i]), y4 = scaled(h, sy[i]);
+        cx[i] = x4 * c - y4 * s + x;
+        cy[i] = x4 * s + y4 * c + y;
+    }
+}
+
+// corners of rectangle 1 inside rectangle 2 (mmcv box1_in_box2): values only
+template <typename S>
+__device__ __forceinline__ void corners_inside(const S (&x1)[4], const S (&y1)[4], const S (&x2)[4], const S (&y2)[4], bool (&in)[4]) {
+    const float ax = val(x2[0]), ay = val(y2[0]);
+    const float abx = val(x2[1]) - ax, aby = val(y2[1]) - ay, adx = val(x2[3]) - ax, ady = val(y2[3]) - ay;
+    const float nab = abx * abx + aby * aby, nad = adx * adx + ady * ady;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float amx = val(x1[i]) - ax, amy = val(y1[i]) - ay;
+        const float pab = (abx * amx + aby * amy) / nab, pad = (adx * amx + ady * amy) / nad;
+        in[i] = pab > -1e-6f && pab < 1.f + 1e-6f && pad > -1e-6f && pad < 1.f + 1e-6f;
+    }
+}
+
+// 1 - DIoU of a predicted box p and a target t, both (x, y, z, w, h, l, alpha)
+template <typename S>
+__device__ S rotated_diou_loss(const S (&p)[7], const float (&tf)[7]) {
+    S t[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t[i] = S(tf[i]);
+    S x1[4], y1[4], x2[4], y2[4];
+    box2corners(p[0], p[1], p[3], p[4], p[6], x1, y1);
+    box2corners(t[0], t[1], t[3], t[4], t[6], x2, y2);
+    // ---- candidate vertices: 4 + 4 corners, 16 edge intersections ----
+    S vx[24], vy[24];
+    bool ok[24];
+    {
+        bool in1[4], in2[4];
+        corners_inside(x1, y1, x2, y2, in1);
+        corners_inside(x2, y2, x1, y1, in2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { vx[i] = x1[i]; vy[i] = y1[i]; ok[i] = in1[i]; vx[4 + i] = x2[i]; vy[4 + i] = y2[i]; ok[4 + i] = in2[i]; }
+    }
+    for (int i = 0; i < 4; ++i) {
+        const S &ax = x1[i], &ay = y1[i], &bx = x1[(i + 1) & 3], &by = y1[(i + 1) & 3];
+        for (int j = 0; j < 4; ++j) {
+            const S &cx = x2[j], &cy = y2[j], &dx = x2[(j + 1) & 3], &dy = y2[(j + 1) & 3];
+            const S num = (ax - bx) * (cy - dy) - (ay - by) * (cx - dx);
+            const S den_t = (ax - cx) * (cy - dy) - (ay - cy) * (cx - dx);
+            const S den_u = (ax - bx) * (ay - cy) - (ay - by) * (ax - cx);
+            const float nv = val(num);
+            bool m = false;
+            if (nv != 0.f) {
+                const float tt = val(den_t) / nv, uu = -val(den_u) / nv;
+                m = tt > 0.f && tt < 1.f && uu > 0.f && uu < 1.f;
+            }
+            const int k = 8 + i * 4 + j;
+            ok[k] = m;
+            if (m) {
+                const S t2 = den_t / (num + 1e-8f);
+                vx[k] = ax + t2 * (bx - ax);
+                vy[k] = ay + t2 * (by - ay);
+            } else {
+                vx[k] = S(0.f); vy[k] = S(0.f);
+            }
+        }
+    }
+    // ---- order the valid candidates by angle around their mean (values only), shoelace area ----
+    int nvert = 0;
+    float mx = 0.f, my = 0.f;
+    for (int k = 0; k < 24; ++k)
+        if (ok[k]) { ++nvert; mx += val(vx[k]); my += val(vy[k]); }
+    S inter(0.f);
+    if (nvert >= 3) {
+        mx /= nvert; my /= nvert;
+        int ord[24];
+        float ang[24];
+        int n = 0;
+        for (int k = 0; k < 24; ++k)
+            if (ok[k]) {                      // stable insertion by (angle, index)
+                const float a = atan2f(val(vy[k]) - my, val(vx[k]) - mx);
+                int pos = n;
+                while (pos > 0 && ang[pos - 1] > a) { ang[pos] = ang[pos - 1]; ord[pos] = ord[pos - 1]; --pos; }
+                ang[pos] = a; ord[pos] = k; ++n;
+            }
+        S area(0.f);
+        for (int a = 0; a < n; ++a) {
+            const int k0 = ord[a], k1 = ord[a + 1 == n ? 0 : a + 1];
+            area = area + (vx[k0] * vy[k1] - vy[k0] * vx[k1]);
+        }
+        inter = scaled(abs_of(area), 0.5f);
+    }
+    // ---- third dimension, union, enclosing box, centre term (rotated_iou_loss.py:27-60) ----
+    const S zmax1 = p[2] + scaled(p[5], 0.5f), zmin1 = p[2] - scaled(p[5], 0.5f);
+    const S zmax2 = t[2] + scaled(t[5], 0.5f), zmin2 = t[2] - scaled(t[5], 0.5f);
+    const S inter3 = inter * relu0(min2(zmax1, zmax2) - max2(zmin1, zmin2));
+    const S uni = p[3] * p[4] * p[5] + t[3] * t[4] * t[5] - inter3;
+    const S ex = min2(min4(x1), min4(x2)) - max2(max4(x1), max4(x2));
+    const S ey = min2(min4(y1), min4(y2)) - max2(max4(y1), max4(y2));
+    const S ez = min2(zmin1, zmin2) - max2(zmax1, zmax2);
+    // the reference's centre term runs over the first three entries of the BEV vectors (x, y, w) -- not (x, y, z) (:58)
+    const S d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[3] - t[3];
+    const S r2 = d0 * d0 + d1 * d1 + d2 * d2;
+    const S c2 = ex * ex + ey * ey + ez * ez;
+    return S(1.f) - (inter3 / uni - r2 / c2);
+}
+
+__device__ __forceinline__ float rot_cost(const float* pb, const float* gb) {
+    float p[7], t[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { p[i] = pb[i]; t[i] = gb[i]; }
+    return rotated_diou_loss<float>(p, t);
+}
+
 __global__ __launch_bounds__(256) void crit_cost_k(CritParams p) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)p.L * p.n_tot) return;
     const int l = (int)(idx / p.n_tot), q = (int)(idx % p.n_tot);
-    const float* x = p.cls + idx * p.C1;
-    float mx = -INFINITY;
-    for (int c = 0; c < p.C1; ++c) mx = fmaxf(mx, x[c]);
-    float se = 0.f;
-    for (int c = 0; c < p.C1; ++c) se += expf(x[c] - mx);
-    p.logz[idx] = mx + logf(se);
     const int b = scene_of(p.cu, p.B, q);
+    const int C1 = p.meta[b * 4], yaw = p.meta[b * 4 + 2];
+    const float* x = p.cls + idx * p.CU;
+    float mx = -INFINITY;
+    for (int c = 0; c < C1; ++c) mx = fmaxf(mx, x[col_of(p, b, c)]);
+    float se = 0.f;
+    for (int c = 0; c < C1; ++c) se += expf(x[col_of(p, b, c)] - mx);
+    p.logz[idx] = mx + logf(se);
     const int g0 = p.gt_off[b], g = p.gt_off[b + 1] - g0;
     if (g == 0) return;
     const int ql = q - p.cu[b], n = p.cu[b + 1] - p.cu[b];
-    const Box6 pb = corners(p.box + idx * 6);
-    const float rc0 = centre_term(pb, corners(p.gt_boxes + (int64_t)g0 * 6));       // the `[:, 0]` term: GT 0 of the scene for every GT
+    const float* pbox = p.box + idx * p.BD;
+    const Box6 pb = corners(pbox);
+    const float rc0 = yaw ? 0.f : centre_term(pb, corners(p.gt_boxes + (int64_t)g0 * p.BD));       // the `[:, 0]` term: GT 0 of the scene for every GT
     float* crow = p.cost + (int64_t)l * p.P + p.qm_off[b] + (int64_t)ql * g;
     const uint8_t* qm = p.qmask + p.qm_off[b];
     for (int j = 0; j < g; ++j) {
         float c = 1e8f;
         if (qm[(int64_t)j * n + ql]) {
-            const float prob = expf(x[p.gt_labels[g0 + j]] - mx) / se;
-            const float iou_loss = 1.f - iou3(pb, corners(p.gt_boxes + (int64_t)(g0 + j) * 6));
-            c = -prob * p.w_cls + (iou_loss + rc0) * p.w_box;
+            const float prob = expf(x[col_of(p, b, (int)p.gt_labels[g0 + j])] - mx) / se;
+            const float* gb = p.gt_boxes + (int64_t)(g0 + j) * p.BD;
+            const float box_cost = yaw ? rot_cost(pbox, gb) : (1.f - iou3(pb, corners(gb))) + rc0;
+            c = -prob * p.w_cls + box_cost * p.w_box;
         }
         crow[j] = c;
     }
@@ -121,11 +311,12 @@ __global__ __launch_bounds__(64) void crit_kth_k(CritParams p) {
     while (b + 1 < p.B && p.gt_off[b + 1] <= gj) ++b;
     const int g0 = p.gt_off[b], g = p.gt_off[b + 1] - g0, j = gj - g0;
     const int n = p.cu[b + 1] - p.cu[b];
+    const int topk = p.meta[b * 4 + 1];
     const float* col = p.cost + (int64_t)l * p.P + p.qm_off[b] + j;
     const int lane = threadIdx.x;
     float pv = -INFINITY;
     int pi = -1;
-    for (int r = 0; r <= p.topk; ++r) {            // r-th smallest in (value, index) order, duplicates counted
+    for (int r = 0; r <= topk; ++r) {              // r-th smallest in (value, index) order, duplicates counted
         float bv = INFINITY;
         int bi = 0x7fffffff;
         for (int q = lane; q < n; q += 64) {
@@ -148,7 +339,7 @@ __global__ __launch_bounds__(256) void crit_stats_k(CritParams p) {
     const int l = blockIdx.x / p.B, b = blockIdx.x % p.B;
     const int q0 = p.cu[b], n = p.cu[b + 1] - q0;
     const int g0 = p.gt_off[b], g = p.gt_off[b + 1] - g0;
-    const int n_cls = p.C1 - 1;
+    const int n_cls = p.meta[b * 4] - 1, yaw = p.meta[b * 4 + 2];
     float sw = 0.f, swn = 0.f, cnt = 0.f, sd = 0.f;
     for (int ql = threadIdx.x; ql < n; ql += 256) {
         const int64_t idx = (int64_t)l * p.n_tot + q0 + ql;
@@ -157,13 +348,19 @@ __global__ __launch_bounds__(256) void crit_stats_k(CritParams p) {
         if (g) {
             const float* crow = p.cost + (int64_t)l * p.P + p.qm_off[b] + (int64_t)ql * g;
             const float* kth = p.kth + (int64_t)l * p.G + g0;
-            const Box6 pb = corners(p.box + idx * 6);
+            const float* pbox = p.box + idx * p.BD;
+            const Box6 pb = corners(pbox);
             for (int j = 0; j < g; ++j)
                 if (crow[j] < kth[j]) {
                     m |= 1ull << j;
                     last = j;
-                    const Box6 tb = corners(p.gt_boxes + (int64_t)(g0 + j) * 6);
-                    sd += (1.f - iou3(pb, tb)) + centre_term(pb, tb);
+                    const float* gb = p.gt_boxes + (int64_t)(g0 + j) * p.BD;
+                    if (yaw) {
+                        sd += rot_cost(pbox, gb);
+                    } else {
+                        const Box6 tb = corners(gb);
+                        sd += (1.f - iou3(pb, tb)) + centre_term(pb, tb);
+                    }
                     cnt += 1.f;
                 }
         }
@@ -171,7 +368,7 @@ __global__ __launch_bounds__(256) void crit_stats_k(CritParams p) {
         const int target = last >= 0 ? (int)p.gt_labels[g0 + last] : n_cls;
         const float w = target == n_cls ? p.non_obj_w : 1.f;
         sw += w;
-        swn += w * (p.logz[idx] - p.cls[idx * p.C1 + target]);
+        swn += w * (p.logz[idx] - p.cls[idx * p.CU + col_of(p, b, target)]);
     }
     // fixed-order block reduction
     __shared__ float red[4][256];
@@ -193,8 +390,8 @@ __global__ void crit_final_k(CritParams p) {
         float cls_sum = 0.f, box_sum = 0.f, n_has = 0.f;
         for (int b = 0; b < p.B; ++b) {
             const float* s = p.stats + ((int64_t)l * p.B + b) * 4;
-            cls_sum += p.ds_w * (s[1] / s[0]);
-            if (s[2] > 0.f) { box_sum += p.ds_w * (s[3] / s[2]); n_has += 1.f; }
+            cls_sum += p.scene_w[b] * (s[1] / s[0]);
+            if (s[2] > 0.f) { box_sum += p.scene_w[b] * (s[3] / s[2]); n_has += 1.f; }
         }
         total += p.lw_cls * (cls_sum / p.B) + p.lw_box * (box_sum / fmaxf(n_has, 1.f));
         p.scale[l * 2 + 1] = n_has;
@@ -211,26 +408,56 @@ __global__ __launch_bounds__(256) void crit_grad_k(CritParams p) {
     const int l = (int)(idx / p.n_tot), q = (int)(idx % p.n_tot);
     const int b = scene_of(p.cu, p.B, q);
     const int g0 = p.gt_off[b];
-    const int n_cls = p.C1 - 1;
+    const int C1 = p.meta[b * 4], n_cls = C1 - 1, yaw = p.meta[b * 4 + 2];
+    const float ds_w = p.scene_w[b];
     const float* st = p.stats + ((int64_t)l * p.B + b) * 4;
     const unsigned long long m = p.mm[idx];
-    // ---- classification: lw_cls * ds_w / B * w_q / sum_w * (softmax - onehot(target)) ----
+    // ---- classification: lw_cls * ds_w / B * w_q / sum_w * (softmax - onehot(target)); zero in the other datasets' columns ----
     const int last = m ? 63 - __clzll(m) : -1;
     const int target = last >= 0 ? (int)p.gt_labels[g0 + last] : n_cls;
     const float w = target == n_cls ? p.non_obj_w : 1.f;
-    const float kc = p.lw_cls * p.ds_w / p.B * w / st[0];
-    const float* x = p.cls + idx * p.C1;
-    float* dx = p.dcls + idx * p.C1;
+    const float kc = p.lw_cls * ds_w / p.B * w / st[0];
+    const float* x = p.cls + idx * p.CU;
+    float* dx = p.dcls + idx * p.CU;
     const float lz = p.logz[idx];
-    for (int c = 0; c < p.C1; ++c) dx[c] = kc * (expf(x[c] - lz) - (c == target ? 1.f : 0.f));
+    if (p.cidx)
+        for (int c = 0; c < p.CU; ++c) dx[c] = 0.f;
+    for (int c = 0; c < C1; ++c) {
+        const int col = col_of(p, b, c);
+        dx[col] = kc * (expf(x[col] - lz) - (c == target ? 1.f : 0.f));
+    }
     // ---- boxes: lw_box * ds_w / (n_has * cnt) * sum over matched GTs of d diou / d box ----
+    float* db = p.dbox + idx * p.BD;
+    if (yaw) {
+        float gacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (m) {
+            const float kb = p.lw_box * ds_w / (fmaxf(p.scale[l * 2 + 1], 1.f) * st[2]);
+            Dual pd[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) pd[i] = dual_var(p.box[idx * 7 + i], i);
+            for (unsigned long long mmask = m; mmask; mmask &= mmask - 1) {
+                const int j = __ffsll((long long)mmask) - 1;
+                float t[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) t[i] = p.gt_boxes[(int64_t)(g0 + j) * 7 + i];
+                const Dual r = rotated_diou_loss<Dual>(pd, t);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) gacc[i] += r.d[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) gacc[i] *= kb;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) db[i] = gacc[i];
+        return;
+    }
     float gc[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f};
     if (m) {
-        const float kb = p.lw_box * p.ds_w / (fmaxf(p.scale[l * 2 + 1], 1.f) * st[2]);
-        const Box6 pb = corners(p.box + idx * 6);
+        const float kb = p.lw_box * ds_w / (fmaxf(p.scale[l * 2 + 1], 1.f) * st[2]);
+        const Box6 pb = corners(p.box + idx * p.BD);
         for (unsigned long long mmask = m; mmask; mmask &= mmask - 1) {
             const int j = __ffsll((long long)mmask) - 1;
-            const Box6 tb = corners(p.gt_boxes + (int64_t)(g0 + j) * 6);
+            const Box6 tb = corners(p.gt_boxes + (int64_t)(g0 + j) * p.BD);
             float wh[3], dd[3], lo[3], hi[3];
             float inter = 1.f, vp = 1.f, vt = 1.f, r2 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -268,9 +495,9 @@ __global__ __launch_bounds__(256) void crit_grad_k(CritParams p) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { gc[a] *= kb; gs[a] *= kb; }
     }
-    float* db = p.dbox + idx * 6;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { db[a] = gc[a]; db[3 + a] = gs[a]; }
+    if (p.BD == 7) db[6] = 0.f;                        // a yaw-free scene of a mixed batch: the heading column is not used
 }
 
 // ---- box decode of a yaw-free head: PredBBox's exp + _bbox_pred_to_bbox (unidet3d/encoder.py:99-111, :241-271) in one pass ----
@@ -332,22 +559,25 @@ int64_t u3d_criterion_ws_bytes(int L, int B, int64_t n_tot, int64_t G, int64_t P
 }
 
 int u3d_criterion_packed(const float* cls, const float* box, const int32_t* cu, const int32_t* gt_off, const int64_t* gt_labels,
-                         const float* gt_boxes, const uint8_t* qmask, const int64_t* qm_off, int L, int B, int64_t n_tot, int C1, int64_t G,
-                         int64_t P, int max_gt, int min_queries_with_gt, int topk, float w_cls, float w_box, float non_obj_w, float ds_w,
-                         float lw_cls, float lw_box, float* loss, float* dcls, float* dbox, void* ws, u3d_stream_t stream) {
-    if (!cls || !box || !cu || !gt_off || !qm_off || !loss || !dcls || !dbox || !ws || L <= 0 || B <= 0 || n_tot <= 0 || C1 < 2 || G < 0 || P < 0)
+                         const float* gt_boxes, const uint8_t* qmask, const int64_t* qm_off, const int32_t* scene_meta,
+                         const float* scene_w, const int32_t* cidx, int L, int B, int64_t n_tot, int CU, int BD, int64_t G, int64_t P,
+                         int max_gt, int min_query_slack, float w_cls, float w_box, float non_obj_w, float lw_cls, float lw_box,
+                         float* loss, float* dcls, float* dbox, void* ws, u3d_stream_t stream) {
+    if (!cls || !box || !cu || !gt_off || !qm_off || !scene_meta || !scene_w || !loss || !dcls || !dbox || !ws || L <= 0 || B <= 0 ||
+        n_tot <= 0 || CU < 2 || (BD != 6 && BD != 7) || G < 0 || P < 0)
         return U3D_EINVAL;
     if (G > 0 && (!gt_labels || !gt_boxes || !qmask)) return U3D_EINVAL;
     if (max_gt > 64) { set_error("criterion: %d ground-truth boxes in one scene exceed the 64-bit match mask", max_gt); return U3D_EUNSUPPORTED; }
-    if (G > 0 && min_queries_with_gt < topk + 1) {        // torch.topk(cost, topk + 1, dim=0) of the reference raises here as well
-        set_error("criterion: a scene with ground truth has %d queries, fewer than topk + 1 = %d", min_queries_with_gt, topk + 1);
+    if (G > 0 && min_query_slack < 0) {        // torch.topk(cost, topk + 1, dim=0) of the reference raises here as well
+        set_error("criterion: a scene with ground truth has fewer queries than its topk + 1 (slack %d)", min_query_slack);
         return U3D_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
     CritParams p;
     p.cls = cls; p.box = box; p.cu = cu; p.gt_off = gt_off; p.gt_labels = gt_labels; p.gt_boxes = gt_boxes; p.qmask = qmask; p.qm_off = qm_off;
-    p.L = L; p.B = B; p.C1 = C1; p.topk = topk; p.n_tot = n_tot; p.G = G; p.P = P;
-    p.w_cls = w_cls; p.w_box = w_box; p.non_obj_w = non_obj_w; p.ds_w = ds_w; p.lw_cls = lw_cls; p.lw_box = lw_box;
+    p.meta = scene_meta; p.scene_w = scene_w; p.cidx = cidx;
+    p.L = L; p.B = B; p.CU = CU; p.BD = BD; p.n_tot = n_tot; p.G = G; p.P = P;
+    p.w_cls = w_cls; p.w_box = w_box; p.non_obj_w = non_obj_w; p.lw_cls = lw_cls; p.lw_box = lw_box;
     char* w = (char*)ws;
     p.cost = (float*)w; w += al64((int64_t)L * P * 4);
     p.logz = (float*)w; w += al64((int64_t)L * n_tot * 4);

@@ -212,15 +212,24 @@ class UniDet3DEncoder(nn.Module):
             cls_p = mlp(nq, w1, b1, w2[cidx], b2[cidx], 'relu')
             box_p = _BoxDecodeFn.apply(box_raw, centers_packed) if yaw_free else _bbox_pred_to_bbox(centers_packed, box_all)
             return list(cls_p.split(sizes)), list(box_p.split(sizes)), (cls_p, box_p)
+        # mixed batch (joint config): full-width logits once; both box parametrisations once on the packed matrix -- the per-scene
+        # outputs of the reference's dict contract are row slices of them (the reference decodes scene by scene, :186-199)
         cls_all = mlp(nq, w1, b1, w2, b2, 'relu')
+        b6 = _bbox_pred_to_bbox(centers_packed, box_all[:, :6])
+        idxs = [self.datasets.index(name) for name in datasets_names]
+        any_yaw = any(self.angles[i] for i in idxs)
+        b7 = _bbox_pred_to_bbox(centers_packed, box_all) if any_yaw else None
         cls_preds, boxes = [], []
-        for i, (c, pb, name) in enumerate(zip(cls_all.split(sizes), box_all.split(sizes), datasets_names)):
-            idx = self.datasets.index(name)
+        for c, p6, p7, idx in zip(cls_all.split(sizes), b6.split(sizes), b7.split(sizes) if any_yaw else [None] * len(sizes), idxs):
             cls_preds.append(c[:, self._cidx(idx, feats.device)])
-            if not self.angles[idx]:
-                pb = pb[:, :6]
-            boxes.append(_bbox_pred_to_bbox(sp_centers[i], pb))
-        return cls_preds, boxes, None
+            boxes.append(p7 if self.angles[idx] else p6)
+        if any_yaw:      # [M, 7] for the criterion kernel: heading rows from b7, the others from b6 with a zero heading column
+            flags = L.h2d([bool(self.angles[i]) for i in idxs], torch.bool, feats.device)
+            yaw_rows = torch.repeat_interleave(flags, L.h2d(list(sizes), torch.int64, feats.device), output_size=int(sum(sizes)))[:, None]
+            box_p = torch.where(yaw_rows, b7, torch.nn.functional.pad(b6, (0, 1)))
+        else:
+            box_p = b6
+        return cls_preds, boxes, (cls_all, box_p)
 
     def forward(self, x: List[torch.Tensor], sp_centers: List[torch.Tensor], datasets_names: List[str]):
         sizes = [int(t.shape[0]) for t in x]
@@ -254,4 +263,9 @@ class UniDet3DEncoder(nn.Module):
             cls_p, box_p = packed
             res['_packed'] = dict(cls=[cls_p[j * n:(j + 1) * n] for j in range(NL)], box=[box_p[j * n:(j + 1) * n] for j in range(NL)],
                                   sizes=sizes, cls_stacked=cls_p.view(NL, n, cls_p.shape[-1]), box_stacked=box_p.view(NL, n, box_p.shape[-1]))
+            if len(set(datasets_names)) > 1:        # mixed batch: which columns / box form belong to which scene
+                CU = cls_p.shape[-1]
+                idxs = [self.datasets.index(name) for name in datasets_names]
+                res['_packed'].update(cidx=[[c if c >= 0 else CU + c for c in self.datasets_cls_idxs[i]] for i in idxs],
+                                      yaw=[bool(self.angles[i]) for i in idxs])
         return res

@@ -513,9 +513,14 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
                                                                       // SGPRs (as a VGPR each index load became a waterfall loop)
     const int sub = wave % SPLIT, wa = sub % SG, wb = sub / SG;
     const int range = ((j / p.K) * 8 + xcd) * RPW + wave / SPLIT;
-    if (range >= p.n_tiles) return;                      // wave-uniform; the kernel has no barrier
-    const int lo = p.ts[(int64_t)k * (p.n_tiles + 1) + range];
-    const int hi = p.ts[(int64_t)k * (p.n_tiles + 1) + range + 1];
+    // SPLIT == 1: the four waves of a workgroup walk four consecutive ranges of the same offset and add their accumulators
+    // through LDS at the end (one partial block per workgroup: a quarter of the partial traffic and of the fixed-order
+    // reduce's reads) -- such a wave stays for the two barriers even without a range of its own.
+    constexpr bool LDSR = SPLIT == 1;
+    const bool active = range < p.n_tiles;               // wave-uniform
+    if (!LDSR && !active) return;
+    const int lo = active ? p.ts[(int64_t)k * (p.n_tiles + 1) + range] : 0;
+    const int hi = active ? p.ts[(int64_t)k * (p.n_tiles + 1) + range + 1] : 0;
     // VALU instructions do not overlap with fp32 MFMAs on a SIMD (tools/coissue.hip), so the loop is written for VALU
     // count: raw buffer loads (one v_mad_u32_u24 per gathered row instead of a 64-bit address chain), the pair list
     // read from a scalar offset with constant per-lane offsets (lane group q takes pairs 4q..4q+3 of the trip;
@@ -656,6 +661,37 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
     }
     // partial block of this range in register order [sub][(a*NXW + b)*4 + r][lane]: 256-byte coalesced stores,
     // no atomics; wgrad_reduce_k maps it back to dW[co][k][ci] and sums the ranges in a fixed order.
+    if constexpr (LDSR) {
+        // ((w0 + w2) + (w1 + w3)): fixed order -> deterministic.  Accumulator element (a, b, r) of lane l sits at [(a NXW + b) 4 + r][l].
+        constexpr int EW = NGW * NXW * 256;
+        __shared__ float red[2][EW];
+        float* mine = red[wave & 1] + lane;
+        if (wave < 2) {
+#pragma unroll
+            for (int a = 0; a < NGW; ++a)
+#pragma unroll
+                for (int b = 0; b < NXW; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[((a * NXW + b) * 4 + r) * 64] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (wave >= 2) {
+#pragma unroll
+            for (int a = 0; a < NGW; ++a)
+#pragma unroll
+                for (int b = 0; b < NXW; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[((a * NXW + b) * 4 + r) * 64] += acc[a][b][r];
+        }
+        __syncthreads();
+        const int group = range >> 2;                    // = the workgroup's range group; at least its first range exists
+        if ((range & ~3) >= p.n_tiles) return;
+        float* out = p.partial + ((int64_t)k * ceil_div(p.n_tiles, 4) + group) * (CD * CS);
+        for (int e = threadIdx.x; e < EW; e += 256) out[e] = red[0][e] + red[1][e];
+        return;
+    }
+    // partial block of this range in register order [sub][(a*NXW + b)*4 + r][lane]: 256-byte coalesced stores,
+    // no atomics; wgrad_reduce_k maps it back to dW[co][k][ci] and sums the ranges in a fixed order.
     float* out = p.partial + ((int64_t)k * p.n_tiles + range) * (CD * CS) + (int64_t)sub * (NGW * NXW * 256) + lane;
 #pragma unroll
     for (int a = 0; a < NGW; ++a)
@@ -718,7 +754,8 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     const bool pipe = pipe_env >= 0 ? pipe_env != 0 : (NG / SG) * (NX / SX) <= 16;
     if (pipe) hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, BF, true>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, BF, false>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, p.n_tiles, p.K, NG, NX, SG, SX, dW);
+    const int n_blocks = SPLIT == 1 ? (int)ceil_div(p.n_tiles, 4) : p.n_tiles;       // partial blocks per offset (see the LDS reduction in the kernel)
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, n_blocks, p.K, NG, NX, SG, SX, dW);
     return check_launch("spconv_wgrad");
 }
 

@@ -94,4 +94,5 @@ def test_train_predict_evaluate_on_device():
         assert set(dev) == set(orc)
         for k in dev:
             assert (np.isnan(dev[k]) and np.isnan(orc[k])) or abs(dev[k] - orc[k]) < 1e-6, (k, dev[k], orc[k])
-    assert after_dev['mAP_0.25'] >= before_dev['mAP_0.25'] and after_dev['mAR_0.25'] >= before_dev['mAR_0.25'], rec
+    # measured: mAP@0.25 0.0 -> 1.0, mAP@0.5 1.0, loss 9.6 -> 0.94 (profiles/round3_parity_errors.jsonl)
+    assert after_dev['mAP_0.25'] > 0.5 and after_dev['mAR_0.25'] > 0.5 and before_dev['mAP_0.25'] < 0.2, rec

@@ -100,8 +100,13 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * GT;
-    const int n0 = blockIdx.y * TN;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8 (own 4 MB L2); XCD x takes a contiguous chunk of tile ids with the
+    // column tiles of one row tile next to each other, so the A row tile (GT x K, read by every column tile: PMC showed 196 MB
+    // fetched per launch for 76 MB of operands with the 2-D grid) comes from HBM once and from that XCD's L2 afterwards
+    const int nt_ = (N + TN - 1) / TN;
+    const int64_t wid_ = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t m0 = (wid_ / nt_) * GT;
+    const int n0 = (int)(wid_ % nt_) * TN;
     const int rows_a = (int)min((int64_t)GT, M - m0), rows_b = min(TN, N - n0);
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + m0 * K, (int64_t)rows_a * K * 4);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(W + (int64_t)n0 * K, (int64_t)rows_b * K * 4);
@@ -179,8 +184,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * GT;
-    const int n0 = blockIdx.y * TN;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8 (own 4 MB L2); XCD x takes a contiguous chunk of tile ids with the
+    // column tiles of one row tile next to each other, so the A row tile (GT x K, read by every column tile: PMC showed 196 MB
+    // fetched per launch for 76 MB of operands with the 2-D grid) comes from HBM once and from that XCD's L2 afterwards
+    const int nt_ = (N + TN - 1) / TN;
+    const int64_t wid_ = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t m0 = (wid_ / nt_) * GT;
+    const int n0 = (int)(wid_ % nt_) * TN;
     const int rows_a = (int)min((int64_t)GT, M - m0), rows_b = min(TN, N - n0);
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + m0 * K, (int64_t)rows_a * K * 4);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(W + (int64_t)n0 * K, (int64_t)rows_b * K * 4);
@@ -536,7 +546,7 @@ static void launch_nt(const float* A, const float* W, const float* bias, float* 
     // workgroups costs more than the narrow tile's extra LDS reads (measured on the step: threshold 512 -> 2200: 7.07 -> 6.76 ms of GEMMs)
     static const int64_t narrow_below = [] { const char* e = getenv("U3D_NT_NARROW_BELOW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)2200; }();
     const bool narrow = ceil_div(M, GT) * ceil_div(N, GT) < narrow_below;
-    const dim3 grid((unsigned)ceil_div(M, GT), (unsigned)ceil_div(N, narrow ? 64 : GT));
+    const dim3 grid((unsigned)(ceil_div(M, GT) * ceil_div(N, narrow ? 64 : GT)));       // (row tile, column tile) decoded in the kernel
     if (bf16_operands) {
         if (narrow) hipLaunchKernelGGL((gemm_nt_bf16_k<64, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
         else hipLaunchKernelGGL((gemm_nt_bf16_k<128, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);

@@ -12,16 +12,6 @@ namespace u3d {
 
 constexpr int RB_T = 256;
 
-// nbr[k*n + o] = input row of output o at offset k, or -1.  grid (ceil(n/256), 27)
-__global__ __launch_bounds__(RB_T) void subm_nbr_k(const int32_t* __restrict__ coords, int64_t n, Index ix, int32_t* nbr) {
-    const int64_t o = (int64_t)blockIdx.x * RB_T + threadIdx.x;
-    if (o >= n) return;
-    const int k = blockIdx.y;
-    const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
-    const int4 c = *reinterpret_cast<const int4*>(coords + o * 4);
-    nbr[(int64_t)k * n + o] = index_lookup(ix, c.x, c.y + dx, c.z + dy, c.w + dz);
-}
-
 // val[k*n + i] = parent row if offset(i) == k (and the parent is inside the halved grid) else -1
 __global__ __launch_bounds__(RB_T) void down_nbr_k(const int32_t* __restrict__ coords, int64_t n, Index ix2, int32_t* val) {
     const int64_t i = (int64_t)blockIdx.x * RB_T + threadIdx.x;
@@ -105,6 +95,46 @@ __global__ __launch_bounds__(RB_T) void rb_write_k(const int32_t* __restrict__ v
     }
 }
 
+// ---- SubM rulebook without the dense neighbour matrix -------------------------------------------------------------------
+// Rounds 1-2 stored nbr[27][n] (subm_nbr_k) and read it back in the count and the write pass: 3 x 27 n 4 B = 115 MB of traffic at
+// level 1 of cfg2 for 34 MB of pairs.  The lookup is a bitmap word + a rank word (L2-resident), so both passes now redo it.
+__device__ __forceinline__ int subm_lookup(const int32_t* __restrict__ coords, int64_t o, int k, const Index& ix) {
+    const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+    const int4 c = *reinterpret_cast<const int4*>(coords + o * 4);
+    return index_lookup(ix, c.x, c.y + dx, c.z + dy, c.w + dz);
+}
+
+// grid (nblk, 27)
+__global__ __launch_bounds__(RB_T) void subm_count_k(const int32_t* __restrict__ coords, int64_t n, Index ix, int nblk, int32_t* block_cnt) {
+    const int64_t r = (int64_t)blockIdx.x * RB_T + threadIdx.x;
+    const int k = blockIdx.y;
+    const bool ok = r < n && subm_lookup(coords, r, k, ix) >= 0;
+    const int c = __syncthreads_count(ok);
+    if (threadIdx.x == 0) block_cnt[(int64_t)k * nblk + blockIdx.x] = c;
+}
+
+// stable compaction, as rb_write_k: list_row[k][pos] = output row, list_val[k][pos] = its neighbour's row    grid (nblk, 27)
+__global__ __launch_bounds__(RB_T) void subm_write_k(const int32_t* __restrict__ coords, int64_t n, Index ix, int nblk,
+                                                     const int32_t* __restrict__ block_base, int64_t cap, int32_t* list_row, int32_t* list_val) {
+    __shared__ int s_w[RB_T / 64];
+    const int64_t r = (int64_t)blockIdx.x * RB_T + threadIdx.x;
+    const int k = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = r < n ? subm_lookup(coords, r, k, ix) : -1;
+    const bool ok = v >= 0;
+    const unsigned long long m = __ballot(ok);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < RB_T / 64; ++w) if (w < wave) woff += s_w[w];
+    if (ok) {
+        const int64_t pos = (int64_t)k * cap + block_base[(int64_t)k * nblk + blockIdx.x] + woff + rank;
+        list_row[pos] = (int)r;
+        list_val[pos] = v;
+    }
+}
+
 // tile_starts[k][t] = lower_bound(rows[k][0..counts[k]), t*T)
 __global__ __launch_bounds__(256) void tile_starts_k(const int32_t* __restrict__ rows, const int32_t* __restrict__ counts, int64_t cap,
                                                      int T, int64_t n_tiles, int32_t* out) {
@@ -141,7 +171,7 @@ using namespace u3d;
 
 extern "C" {
 
-int64_t u3d_subm_rulebook_ws_bytes(int64_t n) { return rb_ws_bytes(n, 27); }
+int64_t u3d_subm_rulebook_ws_bytes(int64_t n) { return (2 * 27 * ceil_div(n, RB_T) + 64) * 4; }      // block counts + bases only
 int64_t u3d_down_rulebook_ws_bytes(int64_t n) { return rb_ws_bytes(n, 8); }
 
 int u3d_subm_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int B,
@@ -152,12 +182,13 @@ int u3d_subm_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap, 
     ProfScope prof(U3D_K_RULEBOOK, s, 0.0);
     Index ix{bitmap, word_rank, B, X, Y, Z, (Z + 63) / 64};
     const int nblk = (int)ceil_div(n, RB_T);
-    int32_t* nbr = (int32_t*)ws;
-    int32_t* bc = nbr + 27 * n;
+    int32_t* bc = (int32_t*)ws;
     int32_t* bb = bc + (int64_t)27 * nblk;
-    hipLaunchKernelGGL(subm_nbr_k, dim3(nblk, 27), dim3(RB_T), 0, s, coords, n, ix, nbr);
-    // rows = output voxel, value = input (neighbour) row
-    return compact(nbr, n, 27, n, pair_out, pair_in, counts, bc, bb, s);
+    // rows = output voxel, value = input (neighbour) row; count -> per-offset scan of the block counts -> stable write
+    hipLaunchKernelGGL(subm_count_k, dim3(nblk, 27), dim3(RB_T), 0, s, coords, n, ix, nblk, bc);
+    hipLaunchKernelGGL(rb_scan_k, dim3(27), dim3(RB_T), 0, s, (const int32_t*)bc, nblk, bb, counts);
+    hipLaunchKernelGGL(subm_write_k, dim3(nblk, 27), dim3(RB_T), 0, s, coords, n, ix, nblk, (const int32_t*)bb, n, pair_out, pair_in);
+    return check_launch("subm rulebook");
 }
 
 int u3d_index_mark(const int32_t* coords, int64_t n, int shift, int X2, int Y2, int Z2, uint64_t* bitmap2, u3d_stream_t stream) {

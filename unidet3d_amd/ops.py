@@ -159,6 +159,9 @@ def instance_boxes(vb: VoxelBatch, instance_ids: torch.Tensor, n_inst_total: int
 # ----------------------------------------------------------------------------------------
 # inference post-processing
 # ----------------------------------------------------------------------------------------
+NMS_MAX, NMS_ROT_MAX = 4400, 3600          # csrc/postproc.hip: boxes one workgroup keeps in LDS
+
+
 def nms_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, iou_thr: float, score_thr: float,
                    fast_nms: bool = True):
     """``UniDet3D._single_scene_multiclass_nms`` (unidet3d/unidet3d.py:595-650): class by class
@@ -179,13 +182,26 @@ def nms_multiclass(bboxes: torch.Tensor, scores: torch.Tensor, labels: torch.Ten
     lab = labels[order].to(torch.int32).contiguous()
     keep = torch.empty(n, dtype=torch.uint8, device=b.device)
     if b.shape[1] == 7:                                           # with_yaw: mmcv nms3d on the rotated BEV rectangles (:625-626)
-        L.call('u3d_nms_rotated', L.ptr(b), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+        fn, arg, limit = 'u3d_nms_rotated', b, NMS_ROT_MAX
     elif fast_nms:
-        L.call('u3d_nms_bev', L.ptr(b), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+        fn, arg, limit = 'u3d_nms_bev', b, NMS_MAX
     else:
         half = b[:, 3:] / 2                                      # _bbox_to_loss (criterion.py:180-198)
-        corners = torch.cat((b[:, :3] - half, b[:, :3] + half), dim=1).contiguous()
-        L.call('u3d_nms_aligned3d', L.ptr(corners), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+        fn, arg, limit = 'u3d_nms_aligned3d', torch.cat((b[:, :3] - half, b[:, :3] + half), dim=1).contiguous(), NMS_MAX
+    # One workgroup holds a launch's boxes in LDS (4400 / 3600 boxes).  Suppression never crosses a class boundary, so a larger
+    # set (test_cfg.topk_insts above the limit -- the reference accepts any) is cut at class boundaries into several launches;
+    # only a SINGLE class with more boxes than the limit is refused.
+    if n <= limit:
+        L.call(fn, L.ptr(arg), L.ptr(lab), n, float(iou_thr), L.ptr(keep), L.stream())
+    else:
+        starts = torch.cat((lab.new_zeros(1), (lab[1:] != lab[:-1]).nonzero()[:, 0].to(torch.int32) + 1, lab.new_full((1,), n))).tolist()
+        lo = 0
+        while lo < n:
+            hi = max([e for e in starts if lo < e <= lo + limit], default=None)
+            if hi is None:
+                raise L.U3DError(f'nms: one class holds more than {limit} boxes above the score threshold')
+            L.call(fn, L.ptr(arg[lo:hi]), L.ptr(lab[lo:hi]), hi - lo, float(iou_thr), L.ptr(keep[lo:hi]), L.stream())
+            lo = hi
     k = order[keep.bool()]
     out = bboxes[k]
     if fast_nms and out.shape[1] == 6:        # the reference appends a zero heading for nms3d_normal and returns those 7-column boxes (:629-638)

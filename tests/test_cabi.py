@@ -48,7 +48,8 @@ def test_pure_size_queries_run_without_gpu():
     assert l.u3d_spconv_plan(32, 32, 27, 400000, ctypes.byref(R), ctypes.byref(G)) == 0 and (R.value, G.value) == (64, 1)
     assert l.u3d_spconv_plan(160, 160, 27, 1400, ctypes.byref(R), ctypes.byref(G)) == 0 and R.value == 32 and G.value > 1
     assert l.u3d_spconv_plan(24, 32, 27, 1000, ctypes.byref(R), ctypes.byref(G)) < 0     # unsupported channel count is refused
-    assert l.u3d_subm_rulebook_ws_bytes(1000) >= 27 * 1000 * 4
+    assert l.u3d_subm_rulebook_ws_bytes(1000) >= 2 * 27 * 4 * 4      # block counts + bases of 4 blocks (no dense neighbour matrix since round 3)
+    assert l.u3d_down_rulebook_ws_bytes(1000) >= 8 * 1000 * 4
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only check')

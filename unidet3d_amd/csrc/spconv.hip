@@ -60,6 +60,14 @@ constexpr int GMM_ALD = 40;
 constexpr bool GMM_SWZ = true;
 constexpr int GMM_ALD = 32;
 #endif
+// Timing ablations (tools/build_variant.sh ... -DU3D_GMM_ABL=n; results are WRONG by construction, never shipped):
+//   1 = no MFMAs (operands kept alive), 2 = no accumulator read-modify-write in LDS, 3 = every gather hits rows 0..63
+#ifndef U3D_GMM_ABL
+#define U3D_GMM_ABL 0
+#endif
+#ifndef U3D_WG_ABL
+#define U3D_WG_ABL 0
+#endif
 // float index of (row r, 16-byte quad c4) in the tile
 __device__ __forceinline__ int gmm_acc_idx(int r, int c4) { return GMM_SWZ ? r * 32 + ((c4 ^ (r & 7)) << 2) : r * GMM_ALD + (c4 << 2); }
 
@@ -181,7 +189,8 @@ struct GmmWave {
     __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u) const {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int g = __shfl(raw_g, i * RPI + lr, 64);
+            int g = __shfl(raw_g, i * RPI + lr, 64);
+            if (U3D_GMM_ABL == 3) g &= 63;
             buf.a[i] = bload128(rs_src, (int)__umul24(g, cs4) + lp16, u * (JB * 64));
         }
         if constexpr (BF) {      // 32-channel groups: (jl, nb) blocks of 1 KB (8 bf16 per lane)
@@ -246,7 +255,9 @@ struct GmmWave {
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
-        if constexpr (U == 0) {         // accumulator rows of the item -> C operands
+        if constexpr (U == 0 && U3D_GMM_ABL == 2) {
+            d00 = f32x4{0.f, 0.f, 0.f, 0.f}; d01 = d00; d10 = d00; d11 = d00;
+        } else if constexpr (U == 0) {         // accumulator rows of the item -> C operands
             d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
             d01 = *reinterpret_cast<const f32x4*>(accq + hi_cols(soff0));
             if (two) {
@@ -282,6 +293,9 @@ struct GmmWave {
                     d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j][1]), x1, d11, 0, 0, 0);
                 }
             }
+        } else if constexpr (U3D_GMM_ABL == 1) {
+#pragma unroll
+            for (int j = 0; j < JB; ++j) asm volatile("" :: "v"(cur.b[j][0]), "v"(cur.b[j][1]), "v"(f0.v[j]), "v"(f1.v[j]));
         } else {
 #pragma unroll
         for (int j = 0; j < JB; ++j)
@@ -300,7 +314,11 @@ struct GmmWave {
                 }
         }
         }
-        if constexpr (U == NJB - 1) {
+        if constexpr (U == NJB - 1 && U3D_GMM_ABL == 2) {
+            asm volatile("" :: "v"(d00), "v"(d01), "v"(d10), "v"(d11));
+            g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
+            it0 = it1; it1 = it2;
+        } else if constexpr (U == NJB - 1) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
             *reinterpret_cast<f32x4*>(accq + hi_cols(soff0)) = d01;
             if (two) {
@@ -612,12 +630,22 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
         };
         auto load_rows = [&](float (&gv)[4][NGW], float (&xv)[4][NXW], const int (&io)[4], const int (&ix)[4]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                load_row_part<NGW>(gv[u], rs_g, (int)__umul24(io[u], CD * 4) + gvo);
-                load_row_part<NXW>(xv[u], rs_x, (int)__umul24(ix[u], CS * 4) + xvo);
+            for (int u = 0; u < 4; ++u) {       // (U3D_WG_ABL == 3: timing ablation, every gather hits rows 0..63)
+                load_row_part<NGW>(gv[u], rs_g, (int)__umul24(U3D_WG_ABL == 3 ? (io[u] & 63) : io[u], CD * 4) + gvo);
+                load_row_part<NXW>(xv[u], rs_x, (int)__umul24(U3D_WG_ABL == 3 ? (ix[u] & 63) : ix[u], CS * 4) + xvo);
             }
         };
         auto mfmas = [&](const float (&gv)[4][NGW], const float (&xv)[4][NXW]) {
+            if constexpr (U3D_WG_ABL == 1) {    // timing ablation: operands kept alive, no MFMA
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int a = 0; a < NGW; ++a) asm volatile("" :: "v"(gv[u][a]));
+#pragma unroll
+                    for (int b = 0; b < NXW; ++b) asm volatile("" :: "v"(xv[u][b]));
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll

@@ -61,7 +61,8 @@ constexpr bool GMM_SWZ = true;
 constexpr int GMM_ALD = 32;
 #endif
 // Timing ablations (tools/build_variant.sh ... -DU3D_GMM_ABL=n; results are WRONG by construction, never shipped):
-//   1 = no MFMAs (operands kept alive), 2 = no accumulator read-modify-write in LDS, 3 = every gather hits rows 0..63
+//   bit 0 (1) = no MFMAs (operands kept alive), bit 1 (2) = no accumulator read-modify-write in LDS, 4 = every gather hits rows 0..63,
+//   bit 3 (8) = no LDS staging transposition, bit 4 (16) = no index shuffles, bit 5 (32) = weights loaded once
 #ifndef U3D_GMM_ABL
 #define U3D_GMM_ABL 0
 #endif
@@ -190,7 +191,8 @@ struct GmmWave {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             int g = __shfl(raw_g, i * RPI + lr, 64);
-            if (U3D_GMM_ABL == 3) g &= 63;
+            if (U3D_GMM_ABL & 4) g &= 63;
+            if (U3D_GMM_ABL & 16) g = raw_g;
             buf.a[i] = bload128(rs_src, (int)__umul24(g, cs4) + lp16, u * (JB * 64));
         }
         if constexpr (BF) {      // 32-channel groups: (jl, nb) blocks of 1 KB (8 bf16 per lane)
@@ -200,6 +202,9 @@ struct GmmWave {
                 buf.b[j][0] = bload128(rs_w, lane16, wso + j * 2048);
                 buf.b[j][1] = bload128(rs_w, lane16 + 1024, wso + j * 2048);
             }
+        } else if constexpr ((U3D_GMM_ABL & 32) != 0) {
+#pragma unroll
+            for (int j = 0; j < JB; ++j) { asm volatile("" : "+v"(buf.b[j][0]), "+v"(buf.b[j][1])); }
         } else {
             const int wso = ((slice * K + k) * CS16 + u * JB) * 2048;       // bytes: (j, nb) blocks of 1 KB
 #pragma unroll
@@ -216,6 +221,12 @@ struct GmmWave {
     // rows of one 16-pair chunk: registers -> swizzled LDS image -> fragments
     template <int C>
     __device__ __forceinline__ Frag frags(const Buf& buf) const {
+        if constexpr ((U3D_GMM_ABL & 8) != 0) {
+            Frag f;
+#pragma unroll
+            for (int j = 0; j < JB; ++j) f.v[j] = buf.a[(C * IPC + j) % NI];
+            return f;
+        }
 #pragma unroll
         for (int i = 0; i < IPC; ++i) {
             int off = wr_off + i * (RPI * PPR * 4);
@@ -236,6 +247,7 @@ struct GmmWave {
         const int mine = lw < it.e - it.base ? raw_s - row0 : TRASH;
         if constexpr (GMM_SWZ) {       // byte offset of quad 0 of the row, then this lane's quad q: (q ^ (row & 7)) << 4
             const int mine_off = (mine << 7) | ((mine & 7) << 4);
+            if constexpr ((U3D_GMM_ABL & 16) != 0) { o0 = (mine_off & 0x1f80) ^ q16; o1 = o0; return; }
             o0 = __shfl(mine_off, i16, 64) ^ q16;
             o1 = NCH == 2 ? __shfl(mine_off, 16 + i16, 64) ^ q16 : 0;
         } else {
@@ -255,7 +267,7 @@ struct GmmWave {
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
-        if constexpr (U == 0 && U3D_GMM_ABL == 2) {
+        if constexpr (U == 0 && (U3D_GMM_ABL & 2) != 0) {
             d00 = f32x4{0.f, 0.f, 0.f, 0.f}; d01 = d00; d10 = d00; d11 = d00;
         } else if constexpr (U == 0) {         // accumulator rows of the item -> C operands
             d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
@@ -293,7 +305,7 @@ struct GmmWave {
                     d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j][1]), x1, d11, 0, 0, 0);
                 }
             }
-        } else if constexpr (U3D_GMM_ABL == 1) {
+        } else if constexpr ((U3D_GMM_ABL & 1) != 0) {
 #pragma unroll
             for (int j = 0; j < JB; ++j) asm volatile("" :: "v"(cur.b[j][0]), "v"(cur.b[j][1]), "v"(f0.v[j]), "v"(f1.v[j]));
         } else {
@@ -314,7 +326,7 @@ struct GmmWave {
                 }
         }
         }
-        if constexpr (U == NJB - 1 && U3D_GMM_ABL == 2) {
+        if constexpr (U == NJB - 1 && (U3D_GMM_ABL & 2) != 0) {
             asm volatile("" :: "v"(d00), "v"(d01), "v"(d10), "v"(d11));
             g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
             it0 = it1; it1 = it2;

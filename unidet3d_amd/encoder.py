@@ -220,9 +220,13 @@ class UniDet3DEncoder(nn.Module):
         any_yaw = any(self.angles[i] for i in idxs)
         b7 = _bbox_pred_to_bbox(centers_packed, box_all) if any_yaw else None
         cls_preds, boxes = [], []
-        for c, p6, p7, idx in zip(cls_all.split(sizes), b6.split(sizes), b7.split(sizes) if any_yaw else [None] * len(sizes), idxs):
+        for c, p6, p7, raw, idx in zip(cls_all.split(sizes), b6.split(sizes), b7.split(sizes) if any_yaw else [None] * len(sizes),
+                                       box_all.split(sizes), idxs):
             cls_preds.append(c[:, self._cidx(idx, feats.device)])
-            boxes.append(p7 if self.angles[idx] else p6)
+            if raw.shape[0] == 0:       # the reference returns an EMPTY scene's 8 (or 6) raw columns undecoded (encoder.py:253-254)
+                boxes.append(raw if self.angles[idx] else raw[:, :6])
+            else:
+                boxes.append(p7 if self.angles[idx] else p6)
         if any_yaw:      # [M, 7] for the criterion kernel: heading rows from b7, the others from b6 with a zero heading column
             flags = L.h2d([bool(self.angles[i]) for i in idxs], torch.bool, feats.device)
             yaw_rows = torch.repeat_interleave(flags, L.h2d(list(sizes), torch.int64, feats.device), output_size=int(sum(sizes)))[:, None]

@@ -40,6 +40,7 @@ struct GmmParams {
     int64_t cap;
     int Cs, Cd;
     int64_t n_dst;
+    int64_t n_src;
     int64_t n_sub;
     int n_slices;
     int G;
@@ -133,11 +134,14 @@ struct GmmWave {
     int64_t cap;
     int ts_s, ts_e;                               // lane k: pair range of offset k in this row tile
     int lr, lp16, lane16, lw, lw4, q16;           // per-lane constants
+    int cg[1], cs_[1];                            // byte offsets of this lane's first entries in an item's index window (see load_idx)
     int wr_off, rd_off[JB];                       // float offsets into `stage` of this lane's write / fragment reads
 
     GmmItem it0, it1;                             // item being computed / item whose first unit is fetched next
-    int g_cur;                                    // it0: gather row of pair (base + lane), lanes < W
-    int ix1_g, ix1_s;                             // it1: raw indices, lanes < W
+    // Pair indices per lane, loaded straight into the lanes that use them (round 3; rounds 1-2 loaded one coalesced window and
+    // redistributed it with NI + NCH ds_bpermute per item and per unit -- 10 us of a 145 us level-1 launch by ablation):
+    int g_cur[NI];                                // it0: gather rows of the pairs this lane loads (pair i*RPI + lane/PPR of the window)
+    int ix1_g[NI], ix1_s[NCH];                    // it1: gather rows; scatter rows of pair c*16 + lane%16 (this lane's MFMA column)
     int soff0, soff1;                             // it0: byte offset of this lane's accumulator row, chunk 0 / 1
     f32x4 d00, d01, d10, d11;                     // accumulators [chunk][column block]; named scalars: arrays get merged into
                                                   // runtime-indexed scratch by the TWO / single-chunk tail merge
@@ -145,13 +149,18 @@ struct GmmWave {
     static __device__ __forceinline__ int swz(int row) { return PPR == 4 ? ((row >> 1) & 3) : (row & (PPR - 1)); }
 
     __device__ __forceinline__ void init(const GmmParams& p, float* acc, float* stage_, int lane_, int slice_, int64_t row0_) {
-        rs_src = make_rsrc(p.src); rs_g = make_rsrc(p.gather); rs_s = make_rsrc(p.scatter); rs_w = make_rsrc(p.w);
+        // exact extents: an index window may run past the end of its range (entries of the next tile, uninitialised memory past
+        // the offset's count, or -- past the list -- zeros) -- such lanes compute into the scratch row, and whatever row index
+        // they read, the buffer bounds keep the gather inside `src` (out-of-range loads return 0)
+        rs_src = make_rsrc(p.src, p.n_src * p.Cs * 4); rs_g = make_rsrc(p.gather, p.cap * 4);
+        rs_s = make_rsrc(p.scatter, p.cap * 4); rs_w = make_rsrc(p.w);
         lane = lane_; i16 = lane & 15; slice = slice_; cs4 = p.Cs * 4; K = p.K; cap = p.cap; row0 = (int)row0_;
         const int q = lane >> 4;
         accq = reinterpret_cast<char*>(acc) + (GMM_SWZ ? 0 : q * 16);
         q16 = q << 4;
         stage = stage_;
         lr = lane / PPR; lp16 = (lane % PPR) * 16; lane16 = lane * 16; lw = lane & (W - 1); lw4 = lw * 4;
+        cg[0] = lr * 4; cs_[0] = i16 * 4;
         wr_off = (lr * PPR + ((lane % PPR) ^ swz(lr))) * 4;             // swz(i*RPI + lr) == swz(lr) for PPR = 4, 8
 #pragma unroll
         for (int j = 0; j < JB; ++j) rd_off[j] = (i16 * PPR + ((j * 4 + q) ^ swz(i16))) * 4;
@@ -180,21 +189,21 @@ struct GmmWave {
         n.valid = false;
         return n;
     }
-    // two coalesced loads per item (lanes < W = the item's pairs, clamped into the range -> unconditional)
-    __device__ __forceinline__ void load_idx(const GmmItem& it, int& g, int& s_) const {
-        const int voff = min(it.base * 4 + lw4, (it.e - 1) * 4);
+    // NI + NCH dword loads per item: every lane fetches exactly the entries it will use -- its gather rows (the rows its load
+    // instructions fetch) and its scatter rows (its MFMA column).  Two VALU adds per item: the window start goes into the VGPR
+    // offset (the buffer range check looks at VGPR + immediate offset only), the offset's list start k * cap is the scalar
+    // offset, and the descriptors span ONE list (cap entries): an entry past the end of the list reads as row 0.
+    __device__ __forceinline__ void load_idx(const GmmItem& it, int (&g)[NI], int (&s_)[NCH]) const {
         const int soff_k = (int)(it.k * cap) * 4;
-        g = bload32(rs_g, voff, soff_k);
-        s_ = bload32(rs_s, voff, soff_k);
-    }
-    __device__ __forceinline__ void issue(Buf& buf, int raw_g, int k, int u) const {
+        const int vg = cg[0] + it.base * 4, vs = cs_[0] + it.base * 4;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            int g = __shfl(raw_g, i * RPI + lr, 64);
-            if (U3D_GMM_ABL & 4) g &= 63;
-            if (U3D_GMM_ABL & 16) g = raw_g;
-            buf.a[i] = bload128(rs_src, (int)__umul24(g, cs4) + lp16, u * (JB * 64));
-        }
+        for (int i = 0; i < NI; ++i) g[i] = bload32(rs_g, vg + i * (RPI * 4), soff_k);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s_[c] = bload32(rs_s, vs + c * 64, soff_k);
+    }
+    __device__ __forceinline__ void issue(Buf& buf, const int (&g)[NI], int k, int u) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) buf.a[i] = bload128(rs_src, (int)__umul24(g[i], cs4) + lp16, u * (JB * 64));
         if constexpr (BF) {      // 32-channel groups: (jl, nb) blocks of 1 KB (8 bf16 per lane)
             const int wso = ((slice * K + k) * (CS16 / 2) + u * (JB / 2)) * 2048;
 #pragma unroll
@@ -242,18 +251,17 @@ struct GmmWave {
         return f;
     }
 
-    // byte offsets of the accumulator rows of item `it` whose raw scatter rows are `raw_s` (lane l < W owns pair base + l)
-    __device__ __forceinline__ void row_offsets(const GmmItem& it, int raw_s, int& o0, int& o1) const {
-        const int mine = lw < it.e - it.base ? raw_s - row0 : TRASH;
+    // byte offsets of this lane's accumulator rows (chunk 0 / 1) of item `it` from the scatter rows it loaded
+    __device__ __forceinline__ void row_offsets(const GmmItem& it, const int (&s_)[NCH], int& o0, int& o1) const {
+        const int left = it.e - it.base;                   // pairs of the window that exist
+        const int r0 = i16 < left ? s_[0] - row0 : TRASH;
+        const int r1 = NCH == 2 ? (16 + i16 < left ? s_[NCH - 1] - row0 : TRASH) : 0;
         if constexpr (GMM_SWZ) {       // byte offset of quad 0 of the row, then this lane's quad q: (q ^ (row & 7)) << 4
-            const int mine_off = (mine << 7) | ((mine & 7) << 4);
-            if constexpr ((U3D_GMM_ABL & 16) != 0) { o0 = (mine_off & 0x1f80) ^ q16; o1 = o0; return; }
-            o0 = __shfl(mine_off, i16, 64) ^ q16;
-            o1 = NCH == 2 ? __shfl(mine_off, 16 + i16, 64) ^ q16 : 0;
+            o0 = ((r0 << 7) | ((r0 & 7) << 4)) ^ q16;
+            o1 = NCH == 2 ? ((r1 << 7) | ((r1 & 7) << 4)) ^ q16 : 0;
         } else {
-            const int mine_off = (int)__umul24(mine, GMM_ALD * 4);
-            o0 = __shfl(mine_off, i16, 64);
-            o1 = NCH == 2 ? __shfl(mine_off, 16 + i16, 64) : 0;
+            o0 = (int)__umul24(r0, GMM_ALD * 4);
+            o1 = NCH == 2 ? (int)__umul24(r1, GMM_ALD * 4) : 0;
         }
     }
     // byte offset of columns 16..31 (quad q + 4) of the row whose columns 0..15 sit at byte offset o
@@ -281,7 +289,7 @@ struct GmmWave {
         Frag f1 = f0;
         if (two) f1 = frags<NCH - 1>(cur);
         GmmItem it2;
-        int g2 = 0, s2 = 0, n0 = 0, n1 = 0;
+        int g2[NI], s2[NCH], n0 = 0, n1 = 0;
         if constexpr (U == NJB - 1) {
             row_offsets(it1, ix1_s, n0, n1);
             it2 = next_of(it1);
@@ -328,7 +336,7 @@ struct GmmWave {
         }
         if constexpr (U == NJB - 1 && (U3D_GMM_ABL & 2) != 0) {
             asm volatile("" :: "v"(d00), "v"(d01), "v"(d10), "v"(d11));
-            g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
+            rotate(g2, s2); soff0 = n0; soff1 = n1;
             it0 = it1; it1 = it2;
         } else if constexpr (U == NJB - 1) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
@@ -337,9 +345,16 @@ struct GmmWave {
                 *reinterpret_cast<f32x4*>(accq + soff1) = d10;
                 *reinterpret_cast<f32x4*>(accq + hi_cols(soff1)) = d11;
             }
-            g_cur = ix1_g; ix1_g = g2; ix1_s = s2; soff0 = n0; soff1 = n1;
+            rotate(g2, s2); soff0 = n0; soff1 = n1;
             it0 = it1; it1 = it2;
         }
+    }
+
+    __device__ __forceinline__ void rotate(const int (&g2)[NI], const int (&s2)[NCH]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { g_cur[i] = ix1_g[i]; ix1_g[i] = g2[i]; }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) ix1_s[c] = s2[c];
     }
 
     // units U .. NJB-1 of the current item, buffers alternating
@@ -352,7 +367,7 @@ struct GmmWave {
     __device__ __forceinline__ void run(int k_lo) {
         it0 = first_item(k_lo);
         if (!it0.valid) return;
-        int s_first;
+        int s_first[NCH];
         load_idx(it0, g_cur, s_first);
         it1 = next_of(it0);
         load_idx(it1, ix1_g, ix1_s);
@@ -947,7 +962,7 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
     p.out = G > 1 ? (float*)ws : dst;
     if (bn_partial && G > 1) { set_error("spconv_gmm: per-tile statistics are only produced without offset groups (k_groups = %d)", G); return U3D_EUNSUPPORTED; }
     p.stats = bn_partial;
-    p.K = K; p.cap = cap; p.Cs = Cs; p.Cd = Cd; p.n_dst = n_dst; p.n_sub = ceil_div(n_dst, R);
+    p.K = K; p.cap = cap; p.Cs = Cs; p.Cd = Cd; p.n_dst = n_dst; p.n_src = n_src; p.n_sub = ceil_div(n_dst, R);
     p.n_slices = Cd / GMM_CDS; p.G = G; p.kper = (int)ceil_div(K, G);
     const int cs16 = Cs / 16;
     int rc = U3D_EUNSUPPORTED;

@@ -55,11 +55,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x
 
 // Shared epilogue of the NT kernels.  D layout of 32x32 MFMAs (dtype independent): col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-template <int TN, int EPI>
-__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[2][TN / 64], float* __restrict__ C, const float* __restrict__ bias,
+template <int TN, int EPI, int TM = GT>
+__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[TM / 64][TN / 64], float* __restrict__ C, const float* __restrict__ bias,
                                             const float* __restrict__ aux, float* __restrict__ pre, int64_t m0, int n0, int rows_a, int N,
                                             int wr, int wc, int i32, int kh) {
-    constexpr int NB = TN / 64;
+    constexpr int NB = TN / 64, TA = TM / 64;
     const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(C + m0 * N, (int64_t)rows_a * N * 4);
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((EPI == 2 ? (const float*)pre : aux) + (EPI >= 2 ? m0 * N : 0), (int64_t)rows_a * N * 4);
 #pragma unroll
@@ -68,10 +68,10 @@ __device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[2][TN / 64], flo
         const float bv = (bias && n < N) ? bias[n] : 0.f;
         const int vc = n < N ? (4 * kh * N + n) * 4 : 0x7fffffff;        // columns past N: dropped by the bounds check
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2);
+                const int row = wr * (TM / 2) + a * 32 + (r & 3) + 8 * (r >> 2);
                 float v = acc[a][b][r] + bv;
                 if constexpr (EPI == 1) v = fmaxf(v, 0.f);
                 if constexpr (EPI == 2) {
@@ -90,12 +90,13 @@ __device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[2][TN / 64], flo
     }
 }
 
-template <int TN, int EPI>
+// TM x TN macro tile (TM = 128 or 64 rows: wave (wr, wc) owns TM/2 x TN/2), K-step GK
+template <int TN, int EPI, int TM = GT>
 __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                                  float* __restrict__ C, int64_t M, int N, int K, const float* __restrict__ aux,
                                                  float* __restrict__ pre) {
-    constexpr int NB = TN / 64;                 // 32-column MFMA tiles per wave
-    __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
+    constexpr int NB = TN / 64, TA = TM / 64;    // 32-column / 32-row MFMA tiles per wave
+    __shared__ __attribute__((aligned(16))) float As[2][TM * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][TN * GLD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,30 +106,30 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
     // fetched per launch for 76 MB of operands with the 2-D grid) comes from HBM once and from that XCD's L2 afterwards
     const int nt_ = (N + TN - 1) / TN;
     const int64_t wid_ = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int64_t m0 = (wid_ / nt_) * GT;
+    const int64_t m0 = (wid_ / nt_) * TM;
     const int n0 = (int)(wid_ % nt_) * TN;
-    const int rows_a = (int)min((int64_t)GT, M - m0), rows_b = min(TN, N - n0);
+    const int rows_a = (int)min((int64_t)TM, M - m0), rows_b = min(TN, N - n0);
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + m0 * K, (int64_t)rows_a * K * 4);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(W + (int64_t)n0 * K, (int64_t)rows_b * K * 4);
     // staging map: thread -> (row = tid>>2 (+64), float4 column = tid&3)
     const int srow = tid >> 2, sc4 = tid & 3;
     const int vo = (srow * K + sc4 * 4) * 4, vstep = 64 * K * 4;
-    f32x4 ra[2], rb[NB];
+    f32x4 ra[TA], rb[NB];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ra[j] = bload128(rs_a, vo + j * vstep, kt * (GK * 4));
+        for (int j = 0; j < TA; ++j) ra[j] = bload128(rs_a, vo + j * vstep, kt * (GK * 4));
 #pragma unroll
         for (int j = 0; j < NB; ++j) rb[j] = bload128(rs_b, vo + j * vstep, kt * (GK * 4));
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&As[buf][(srow + 64 * j) * GLD + sc4 * 4]) = ra[j];
+        for (int j = 0; j < TA; ++j) *reinterpret_cast<f32x4*>(&As[buf][(srow + 64 * j) * GLD + sc4 * 4]) = ra[j];
 #pragma unroll
         for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 64 * j) * GLD + sc4 * 4]) = rb[j];
     };
-    f32x16 acc[2][NB];
+    f32x16 acc[TA][NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        f32x4 af[2][2], bf[NB][2];
+        f32x4 af[TA][2], bf[NB][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float* ap = &As[buf][(wr * 64 + t * 32 + i32) * GLD + kh * 8];
+        for (int t = 0; t < TA; ++t) {
+            const float* ap = &As[buf][(wr * (TM / 2) + t * 32 + i32) * GLD + kh * 8];
             af[t][0] = *reinterpret_cast<const f32x4*>(ap);
             af[t][1] = *reinterpret_cast<const f32x4*>(ap + 4);
         }
@@ -158,13 +159,13 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < TA; ++a)
 #pragma unroll
                     for (int b = 0; b < NB; ++b) acc[a][b] = U3D_MFMA32(af[a][h][c], bf[b][h][c], acc[a][b]);
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
-    nt_epilogue<TN, EPI>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
+    nt_epilogue<TN, EPI, TM>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
 }
 
 // bf16-operand form of gemm_nt_k (BASELINE configs[2]; the reference's `--amp` Linear layers): A and W are fp32 in HBM, rounded
@@ -174,12 +175,12 @@ __global__ __launch_bounds__(256) void gemm_nt_k(const float* __restrict__ A, co
 constexpr int GKH = 32;        // K-step of the bf16 kernel
 constexpr int GLH = GKH + 8;   // padded LDS row (halves)
 
-template <int TN, int EPI>
+template <int TN, int EPI, int TM = GT>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                                       float* __restrict__ C, int64_t M, int N, int K, const float* __restrict__ aux,
                                                       float* __restrict__ pre) {
-    constexpr int NB = TN / 64;
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][GT * GLH];
+    constexpr int NB = TN / 64, TA = TM / 64;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][TM * GLH];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TN * GLH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,18 +190,18 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
     // fetched per launch for 76 MB of operands with the 2-D grid) comes from HBM once and from that XCD's L2 afterwards
     const int nt_ = (N + TN - 1) / TN;
     const int64_t wid_ = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int64_t m0 = (wid_ / nt_) * GT;
+    const int64_t m0 = (wid_ / nt_) * TM;
     const int n0 = (int)(wid_ % nt_) * TN;
-    const int rows_a = (int)min((int64_t)GT, M - m0), rows_b = min(TN, N - n0);
+    const int rows_a = (int)min((int64_t)TM, M - m0), rows_b = min(TN, N - n0);
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + m0 * K, (int64_t)rows_a * K * 4);
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(W + (int64_t)n0 * K, (int64_t)rows_b * K * 4);
     // staging map: thread -> (row = tid>>2 (+64), 8 floats at column 8 * (tid&3))
     const int srow = tid >> 2, sc8 = tid & 3;
     const int vo = (srow * K + sc8 * 8) * 4, vstep = 64 * K * 4;
-    f32x4 ra[2][2], rb[NB][2];
+    f32x4 ra[TA][2], rb[NB][2];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TA; ++j) {
             ra[j][0] = bload128(rs_a, vo + j * vstep, kt * (GKH * 4));
             ra[j][1] = bload128(rs_a, vo + j * vstep + 16, kt * (GKH * 4));
         }
@@ -215,13 +216,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x8*>(&As[buf][(srow + 64 * j) * GLH + sc8 * 8]) = cvt8(ra[j][0], ra[j][1]);
+        for (int j = 0; j < TA; ++j) *reinterpret_cast<bf16x8*>(&As[buf][(srow + 64 * j) * GLH + sc8 * 8]) = cvt8(ra[j][0], ra[j][1]);
 #pragma unroll
         for (int j = 0; j < NB; ++j) *reinterpret_cast<bf16x8*>(&Bs[buf][(srow + 64 * j) * GLH + sc8 * 8]) = cvt8(rb[j][0], rb[j][1]);
     };
-    f32x16 acc[2][NB];
+    f32x16 acc[TA][NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -235,20 +236,20 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            bf16x8 af[2], bf[NB];
+            bf16x8 af[TA], bf[NB];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const bf16x8*>(&As[buf][(wr * 64 + t * 32 + i32) * GLH + h * 16 + kh * 8]);
+            for (int t = 0; t < TA; ++t) af[t] = *reinterpret_cast<const bf16x8*>(&As[buf][(wr * (TM / 2) + t * 32 + i32) * GLH + h * 16 + kh * 8]);
 #pragma unroll
             for (int t = 0; t < NB; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wc * (TN / 2) + t * 32 + i32) * GLH + h * 16 + kh * 8]);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < TA; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
-    nt_epilogue<TN, EPI>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
+    nt_epilogue<TN, EPI, TM>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
 }
 
 // partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k].  T = 128 or 64 output rows AND columns per workgroup:
@@ -539,21 +540,32 @@ static int tn_splits(int64_t M, int N, int K, int T, bool bf) {
     return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
 }
 
+// Tile choice by a small cost model.  All workgroups of these launches are resident at once (<= 5 per CU by LDS), so a launch
+// lasts as long as its most loaded CU: ceil(workgroups / 256) workgroup-times -- round 2's 128x64 tiles gave the decoder's
+// [16.8k x 256] products 525 workgroups = 2.05 per CU, i.e. three on some CUs and a third of the machine idle behind them
+// (0.51 of the MFMA peak).  Candidates 128x128, 128x64, 64x64: time ~ ceil(wgs / 256) * tile area * (1 + overhead of the tile:
+// LDS fragment reads and staging per MFMA grow as the tile shrinks: 0 / 8 % / 20 %, from the instruction mix).
 template <int EPI>
 static void launch_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, const float* aux, float* pre,
                       bool bf16_operands, hipStream_t s) {
-    // 128x64 tiles unless 128x128 ones still give every CU ~9 workgroups: with 3-4 big tiles per CU the last, partly filled round of
-    // workgroups costs more than the narrow tile's extra LDS reads (measured on the step: threshold 512 -> 2200: 7.07 -> 6.76 ms of GEMMs)
-    static const int64_t narrow_below = [] { const char* e = getenv("U3D_NT_NARROW_BELOW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)2200; }();
-    const bool narrow = ceil_div(M, GT) * ceil_div(N, GT) < narrow_below;
-    const dim3 grid((unsigned)(ceil_div(M, GT) * ceil_div(N, narrow ? 64 : GT)));       // (row tile, column tile) decoded in the kernel
-    if (bf16_operands) {
-        if (narrow) hipLaunchKernelGGL((gemm_nt_bf16_k<64, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
-        else hipLaunchKernelGGL((gemm_nt_bf16_k<128, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
-    } else {
-        if (narrow) hipLaunchKernelGGL((gemm_nt_k<64, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
-        else hipLaunchKernelGGL((gemm_nt_k<128, EPI>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    static const int force = [] { const char* e = getenv("U3D_NT_TILE"); return e ? atoi(e) : 0; }();       // 1 / 2 / 3 = 128x128 / 128x64 / 64x64
+    const int tm[3] = {128, 128, 64}, tn[3] = {128, 64, 64};
+    const double over[3] = {1.0, 1.08, 1.2};
+    int best = 0;
+    double best_t = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const int64_t wgs = ceil_div(M, tm[c]) * ceil_div(N, tn[c]);
+        const double t = (double)ceil_div(wgs, 256) * tm[c] * tn[c] * over[c];
+        if (c == 0 || t < best_t) { best = c; best_t = t; }
     }
+    if (force >= 1 && force <= 3) best = force - 1;
+    const dim3 grid((unsigned)(ceil_div(M, tm[best]) * ceil_div(N, tn[best])));       // (row tile, column tile) decoded in the kernel
+#define U3D_NT_LAUNCH(KERNEL)                                                                                                          \
+    if (best == 0) hipLaunchKernelGGL((KERNEL<128, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);                \
+    else if (best == 1) hipLaunchKernelGGL((KERNEL<64, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);            \
+    else hipLaunchKernelGGL((KERNEL<64, EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    if (bf16_operands) { U3D_NT_LAUNCH(gemm_nt_bf16_k) } else { U3D_NT_LAUNCH(gemm_nt_k) }
+#undef U3D_NT_LAUNCH
 }
 
 // epi: 0..4 (see nt_epilogue); + 8: bf16 MFMA operands (fp32 data in HBM, fp32 accumulation)

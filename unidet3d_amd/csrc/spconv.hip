@@ -152,8 +152,8 @@ struct GmmWave {
         // exact extents: an index window may run past the end of its range (entries of the next tile, uninitialised memory past
         // the offset's count, or -- past the list -- zeros) -- such lanes compute into the scratch row, and whatever row index
         // they read, the buffer bounds keep the gather inside `src` (out-of-range loads return 0)
-        rs_src = make_rsrc(p.src, p.n_src * p.Cs * 4); rs_g = make_rsrc(p.gather, p.cap * 4);
-        rs_s = make_rsrc(p.scatter, p.cap * 4); rs_w = make_rsrc(p.w);
+        rs_src = make_rsrc(p.src, p.n_src * p.Cs * 4); rs_g = make_rsrc(p.gather, (int64_t)p.K * p.cap * 4);
+        rs_s = make_rsrc(p.scatter, (int64_t)p.K * p.cap * 4); rs_w = make_rsrc(p.w);
         lane = lane_; i16 = lane & 15; slice = slice_; cs4 = p.Cs * 4; K = p.K; cap = p.cap; row0 = (int)row0_;
         const int q = lane >> 4;
         accq = reinterpret_cast<char*>(acc) + (GMM_SWZ ? 0 : q * 16);
@@ -190,9 +190,11 @@ struct GmmWave {
         return n;
     }
     // NI + NCH dword loads per item: every lane fetches exactly the entries it will use -- its gather rows (the rows its load
-    // instructions fetch) and its scatter rows (its MFMA column).  Two VALU adds per item: the window start goes into the VGPR
-    // offset (the buffer range check looks at VGPR + immediate offset only), the offset's list start k * cap is the scalar
-    // offset, and the descriptors span ONE list (cap entries): an entry past the end of the list reads as row 0.
+    // instructions fetch) and its scatter rows (its MFMA column).  Two VALU adds per item (window start + lane part in the VGPR
+    // offset, the lists' start k * cap in the scalar offset, the per-instruction part as immediate).  The descriptors span the
+    // whole [K][cap] index array (the hardware's range check covers scalar + vector + immediate offset -- measured: a
+    // descriptor of one list with the list start in the scalar offset reads zeros for every k >= 1): a window that runs past
+    // its list reads entries of the next offset's list (valid rows), past the array it reads 0.
     __device__ __forceinline__ void load_idx(const GmmItem& it, int (&g)[NI], int (&s_)[NCH]) const {
         const int soff_k = (int)(it.k * cap) * 4;
         const int vg = cg[0] + it.base * 4, vs = cs_[0] + it.base * 4;

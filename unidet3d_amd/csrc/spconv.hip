@@ -758,129 +758,6 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
             for (int r = 0; r < 4; ++r) out[((a * NXW + b) * 4 + r) * 64] = acc[a][b][r];
 }
 
-// ---- narrow rows (<= 64 channels on both sides): whole-row loads + wave-private LDS transposition -------------------------------
-// Timing ablations of spconv_wgrad_k<2, 2> (32 x 32 channels, level 1 of cfg2: 141 us per launch) showed that the walk above is
-// NOT bound by its MFMAs there (118 us with the MFMAs removed) and not by memory latency (no change when every gather hits the
-// same 64 rows): a lane fetches its NG = 2 floats of a row with dword loads, i.e. 24 vector-memory instructions per 16 pairs, each
-// touching four cache lines for 256 bytes -- the texture-address path is the bound.  Here a load instruction fetches WHOLE rows
-// (16 bytes per lane, 64 / (C/4) rows per instruction: 8 instead of 24 instructions per 16 pairs at 32 channels, every line
-// looked up once), the wave writes them to a private LDS image [16 pairs][C + 4] and reads its MFMA operands from there
-// (lane (i16, q): NG resp. NX consecutive floats of pair 4u + q; LDS operations of one wave execute in order: no barrier).
-// Same pair <-> MFMA k-slot assignment, accumulator layout and partial blocks as spconv_wgrad_k; the four waves of a workgroup
-// walk four consecutive ranges and add their accumulators through LDS.
-template <int NG, int NX>
-__global__ __launch_bounds__(256) void spconv_wgrad_rows_k(WgParams p) {
-    constexpr int CD = NG * 16, CS = NX * 16;
-    constexpr int LG = CD / 4, LX = CS / 4;                 // lanes per row (16-byte pieces)
-    constexpr int RG = 64 / LG, RX = 64 / LX;               // rows per load instruction
-    constexpr int IG = 16 / RG, IX = 16 / RX;               // load instructions per 16-pair trip (IG = LG / 4)
-    constexpr int SG_ = CD + 4, SX_ = CS + 4;               // padded image rows (floats)
-    constexpr int EW = NG * NX * 256;
-    static_assert(LG <= 16 && LX <= 16 && LG >= 4 && LX >= 4, "16 .. 64 channels per row");
-    __shared__ __attribute__((aligned(16))) float img[4][16 * (SG_ + SX_)];
-    __shared__ float red[2][EW];
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int k = j % p.K;
-    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int range = ((j / p.K) * 8 + xcd) * 4 + wave;
-    const bool active = range < p.n_tiles;               // wave-uniform
-    const int lo = active ? p.ts[(int64_t)k * (p.n_tiles + 1) + range] : 0;
-    const int hi = active ? p.ts[(int64_t)k * (p.n_tiles + 1) + range + 1] : 0;
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_g = make_rsrc(p.dy), rs_rx = make_rsrc(p.rows_x), rs_rg = make_rsrc(p.rows_dy);
-    const int ksoff = (int)(k * p.cap) * 4;
-    float* ig = img[wave];
-    float* ixm = ig + 16 * SG_;
-    // per-lane constants: which row of a trip this lane loads (and its 16-byte piece), where it writes it, where its operands are
-    const int rg_row = lane / LG, rg_pc = (lane % LG) * 4, rx_row = lane / LX, rx_pc = (lane % LX) * 4;
-    f32x4 acc[NG][NX];
-#pragma unroll
-    for (int a = 0; a < NG; ++a)
-#pragma unroll
-        for (int b = 0; b < NX; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int ioA[IG], ixA[IX], ioB[IG], ixB[IX];
-    f32x4 gA[IG], xA[IX], gB[IG], xB[IX];
-    // pair indices of trip starting at b (clamped into the range: a pair past the end repeats the last one and is masked to zero)
-    auto load_idx = [&](int (&io)[IG], int (&ix)[IX], int b) {
-#pragma unroll
-        for (int i = 0; i < IG; ++i) io[i] = bload32(rs_rg, min(b + i * RG + rg_row, hi - 1) * 4, ksoff);
-#pragma unroll
-        for (int i = 0; i < IX; ++i) ix[i] = bload32(rs_rx, min(b + i * RX + rx_row, hi - 1) * 4, ksoff);
-    };
-    auto load_rows = [&](f32x4 (&gv)[IG], f32x4 (&xv)[IX], const int (&io)[IG], const int (&ix)[IX]) {
-#pragma unroll
-        for (int i = 0; i < IG; ++i) gv[i] = bload128(rs_g, (int)__umul24(io[i], CD * 4) + rg_pc * 4, 0);
-#pragma unroll
-        for (int i = 0; i < IX; ++i) xv[i] = bload128(rs_x, (int)__umul24(ix[i], CS * 4) + rx_pc * 4, 0);
-    };
-    // rows of a trip -> LDS image -> MFMA operands -> 4 k-steps; `left` = pairs of the trip that exist (>= 16: all)
-    auto mfmas = [&](const f32x4 (&gv)[IG], const f32x4 (&xv)[IX], int left) {
-#pragma unroll
-        for (int i = 0; i < IG; ++i) {
-            f32x4 v = gv[i];
-            if (i * RG + rg_row >= left) v = f32x4{0.f, 0.f, 0.f, 0.f};          // pairs past the end contribute exact zeros
-            *reinterpret_cast<f32x4*>(ig + (i * RG + rg_row) * SG_ + rg_pc) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < IX; ++i) *reinterpret_cast<f32x4*>(ixm + (i * RX + rx_row) * SX_ + rx_pc) = xv[i];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float ga[NG], xb[NX];
-            const float* gr = ig + (4 * u + q) * SG_ + NG * i16;
-            const float* xr = ixm + (4 * u + q) * SX_ + NX * i16;
-#pragma unroll
-            for (int a = 0; a < NG; ++a) ga[a] = gr[a];
-#pragma unroll
-            for (int b = 0; b < NX; ++b) xb[b] = xr[b];
-#pragma unroll
-            for (int a = 0; a < NG; ++a)
-#pragma unroll
-                for (int b = 0; b < NX; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], xb[b], acc[a][b], 0, 0, 0);
-        }
-    };
-    const int ntrip = (hi - lo + 15) >> 4;
-    if (ntrip > 0) {
-        // three-deep software pipeline as in spconv_wgrad_k: MFMAs of trip t, rows of t+1, indices of t+2 in flight
-        const int last = lo + (ntrip - 1) * 16;
-        load_idx(ioA, ixA, lo);
-        load_idx(ioB, ixB, min(lo + 16, last));
-        load_rows(gA, xA, ioA, ixA);
-        for (int t = 0; t < ntrip; t += 2) {
-            load_rows(gB, xB, ioB, ixB);
-            load_idx(ioA, ixA, min(lo + (t + 2) * 16, last));
-            mfmas(gA, xA, hi - (lo + t * 16));
-            if (t + 1 >= ntrip) break;
-            load_rows(gA, xA, ioA, ixA);
-            load_idx(ioB, ixB, min(lo + (t + 3) * 16, last));
-            mfmas(gB, xB, hi - (lo + (t + 1) * 16));
-        }
-    }
-    // ((w0 + w2) + (w1 + w3)) through LDS, one partial block per workgroup (see spconv_wgrad_k)
-    float* mine = red[wave & 1] + lane;
-    if (wave < 2) {
-#pragma unroll
-        for (int a = 0; a < NG; ++a)
-#pragma unroll
-            for (int b = 0; b < NX; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mine[((a * NX + b) * 4 + r) * 64] = acc[a][b][r];
-    }
-    __syncthreads();
-    if (wave >= 2) {
-#pragma unroll
-        for (int a = 0; a < NG; ++a)
-#pragma unroll
-            for (int b = 0; b < NX; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mine[((a * NX + b) * 4 + r) * 64] += acc[a][b][r];
-    }
-    __syncthreads();
-    if ((range & ~3) >= p.n_tiles) return;
-    float* out = p.partial + ((int64_t)k * ceil_div(p.n_tiles, 4) + (range >> 2)) * (CD * CS);
-    for (int e = threadIdx.x; e < EW; e += 256) out[e] = red[0][e] + red[1][e];
-}
-
 // dW[co][k][ci] = sum over the row tiles of offset k (fixed order -> deterministic; overwrites dW)
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ partial, int n_tiles, int K, int NG, int NX, int SG, int SX,
                                                       float* __restrict__ dW) {
@@ -932,16 +809,6 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     // software-pipelined walk unless its second register set would push the kernel below two waves per SIMD
     static const int pipe_env = [] { const char* e = getenv("U3D_WGRAD_PIPE"); return e ? atoi(e) : -1; }();
     const bool pipe = pipe_env >= 0 ? pipe_env != 0 : (NG / SG) * (NX / SX) <= 16;
-    // narrow rows (<= 64 channels on both sides, <= 8 accumulators): whole-row loads + LDS transposition (spconv_wgrad_rows_k);
-    // U3D_WGRAD_ROWS=0 keeps the direct walk (A/B measurements)
-    static const bool rows_on = [] { const char* e = getenv("U3D_WGRAD_ROWS"); return !e || atoi(e) != 0; }();
-    if constexpr (!BF && NG <= 4 && NX <= 4 && NG * NX <= 8) {
-        if (rows_on) {
-            hipLaunchKernelGGL((spconv_wgrad_rows_k<NG, NX>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
-            hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, (int)ceil_div(p.n_tiles, 4), p.K, NG, NX, 1, 1, dW);
-            return check_launch("spconv_wgrad_rows");
-        }
-    }
     if (pipe) hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, BF, true>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, BF, false>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
     const int n_blocks = SPLIT == 1 ? (int)ceil_div(p.n_tiles, 4) : p.n_tiles;       // partial blocks per offset (see the LDS reduction in the kernel)

@@ -2,7 +2,7 @@
 # HBM traffic of every kernel of the bench step from PMC counters (two separate passes, kernel-trace only):
 # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide coalesced streams
 # (MI355X_MICROARCH.md, HBM section) -> doubled below; WRITE_SIZE is used as reported (uncalibrated).
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${PMC_TAG:-pmc_bench}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 > /dev/null 2>&1

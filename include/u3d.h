@@ -63,11 +63,12 @@ int64_t u3d_vox_scene_stats_ws_bytes(int B);
  * row(b,x,y,z) = word_rank[w] + popc(bitmap[w] & ((1<<bit)-1)) IS the canonical row.
  * This is a direct-address (perfect-hash) table over the grid EXTENT -- north_star's "hash-built rulebook" with the hash replaced
  * by the cell address, which is what makes the rows come out in canonical order without a sort.  Its size does not depend on
- * occupancy: 12 bytes per 64 z-cells.  u3d_index_words returns the word count, or a negative code when the grid is invalid or
+ * occupancy: 12 bytes per 64 z-cells; large extents use the hashed form further down.  u3d_index_words returns the word count, or a negative code when the grid is invalid or
  * would need more than U3D_INDEX_MAX_WORDS words (refused, never allocated). */
 #define U3D_INDEX_MAX_WORDS (1LL << 31)
 int64_t u3d_index_words(int B, int X, int Y, int Z);
-/* sets the bit of every point's cell; writes pt_cell int64 [n_pts] = word*64 + bit. bitmap must be zeroed. */
+/* sets the bit of every point's cell; writes pt_cell int64 [n_pts] = word*64 + bit (the cell id).  bitmap must be zeroed; bitmap ==
+ * NULL: only the cell ids are written (hashed index, below). */
 int u3d_vox_mark(const float* points, const float* coord_src, const int64_t* pt_offsets, int B,
                  int64_t max_pts_per_scene, const float* stats, float voxel_size, int div_mode, int X, int Y,
                  int Z, uint64_t* bitmap, int64_t* pt_cell, u3d_stream_t stream);
@@ -80,10 +81,27 @@ int u3d_index_coords(const uint64_t* bitmap, const int32_t* word_rank, int B, in
 /* inverse int64 [n_pts] (point -> voxel row); CSR of points per voxel (vox_offsets int32 [n_vox+1],
  * vox_points int32 [n_pts]); feats [n_vox,6] = unweighted mean of [rgb, xyz - mean_xyz(scene)]. */
 int u3d_vox_finalize(const float* points, const int64_t* pt_offsets, int B, int64_t n_pts, const float* stats,
-                     const int64_t* pt_cell, const uint64_t* bitmap, const int32_t* word_rank, int64_t n_vox,
+                     const int64_t* pt_cell, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots /* 0: bitmap index */, int64_t n_vox,
                      int64_t* inverse, int32_t* vox_offsets, int32_t* vox_points, float* feats, int feat_ld,
                      void* ws, u3d_stream_t stream);
 int64_t u3d_vox_finalize_ws_bytes(int64_t n_pts, int64_t n_vox);
+
+/* Hashed form of the index ("hash-built rulebook in HBM", csrc/hashidx.hip) for grids whose extent makes the direct-address
+ * table impractical: memory follows OCCUPANCY.  Same contract (cell -> canonical row, rows ascending in the cell id):
+ *   u3d_hash_index_build: cells int64 [n] (cell ids as u3d_vox_mark / u3d_cells_of_coords write them; duplicates allowed; entries
+ *     equal to INT64_MAX are ignored) -> radix sort -> unique: ukeys int64 [n] (the first *n_unique entries = the occupied cells
+ *     in canonical order), n_unique device int32 (host reads it back, like word_rank[n_words]) -> open-addressing table
+ *     table_keys uint64 [slots] / table_vals int32 [slots], slots = u3d_hash_index_slots(n) (power of two >= 2 n).
+ *   u3d_hash_index_coords: coords int32 [n,4] of the occupied cells; u3d_cells_of_coords: the (parent) cell of every voxel of a
+ *     level (shift = 1: next coarser level, parents outside the halved grid -> INT64_MAX).
+ * Every entry point that takes (bitmap, word_rank) also takes `hash_slots`: 0 = bitmap form; > 0 = the two pointers are
+ * (table_keys, table_vals) of a table with that many slots.  The rulebook / voxel kernels are the same for both forms. */
+int64_t u3d_hash_index_slots(int64_t n);
+int64_t u3d_hash_index_ws_bytes(int64_t n);
+int u3d_hash_index_build(const int64_t* cells, int64_t n, int64_t* ukeys, int32_t* n_unique, uint64_t* table_keys, int32_t* table_vals,
+                         int64_t slots, void* ws, u3d_stream_t stream);
+int u3d_hash_index_coords(const int64_t* ukeys, int64_t n, int X, int Y, int Z, int32_t* coords, u3d_stream_t stream);
+int u3d_cells_of_coords(const int32_t* coords, int64_t n, int shift, int B, int X2, int Y2, int Z2, int64_t* cells, u3d_stream_t stream);
 
 /* =====================================================================================
  * R2  SubMConv3d rulebook (spconv indice pairs, k=3) -- first conv of each indice_key
@@ -91,7 +109,7 @@ int64_t u3d_vox_finalize_ws_bytes(int64_t n_pts, int64_t n_vox);
  *     pair_in/pair_out int32 [27, n]; counts int32 [27]; offset k=(dx+1)*9+(dy+1)*3+(dz+1),
  *     input = output + (dx,dy,dz).
  * ===================================================================================== */
-int u3d_subm_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank,
+int u3d_subm_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots,
                       int B, int X, int Y, int Z, int32_t* pair_in, int32_t* pair_out, int32_t* counts,
                       void* ws, u3d_stream_t stream);
 int64_t u3d_subm_rulebook_ws_bytes(int64_t n);
@@ -105,7 +123,7 @@ int64_t u3d_subm_rulebook_ws_bytes(int64_t n);
  * shift = 1 builds the next (coarser) level, shift = 0 indexes a caller-supplied coordinate list. bitmap must be zeroed. */
 int u3d_index_mark(const int32_t* coords, int64_t n, int shift, int X, int Y, int Z, uint64_t* bitmap,
                    u3d_stream_t stream);
-int u3d_down_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap2, const int32_t* word_rank2,
+int u3d_down_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap2, const int32_t* word_rank2, int64_t hash_slots,
                       int B, int X2, int Y2, int Z2, int32_t* pair_in, int32_t* pair_out, int32_t* counts,
                       void* ws, u3d_stream_t stream);
 int64_t u3d_down_rulebook_ws_bytes(int64_t n);

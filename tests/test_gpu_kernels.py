@@ -254,6 +254,61 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(cin, cout, n_points,
         assert _rel(res[True][k], res[False][k]) < 2e-6, k
 
 
+def _check_levels_against_oracle(vb, pts_cpu, vs, B, n_levels=5):
+    """coords / inverse / features and the SubM + strided rulebooks of ``n_levels`` levels, bit-exact against the oracle"""
+    from unidet3d_amd import sparse
+    oc, of, oinv, oshape = so.voxelize(pts_cpu, vs, 128)
+    assert torch.equal(vb.coords.cpu(), oc) and torch.equal(vb.inverse.cpu(), oinv) and _rel(vb.feats, of) < 1e-6
+    coords, shape, index = vb.coords, vb.spatial_shape, vb.index
+    for level in range(n_levels):
+        want = so.build_subm_rulebook(oc, oshape)
+        for k, ((gi, go), (oi, oo)) in enumerate(zip(sparse.build_subm_rulebook(coords, index).lists(), want)):
+            assert np.array_equal(gi, oi) and np.array_equal(go, oo), f'level {level} offset {k}'
+        if level == n_levels - 1:
+            break
+        oc2, oshape2, opairs = so.build_down_rulebook(oc, oshape)
+        c2, shape2, ix2, rb2 = sparse.build_down_rulebook(coords, B, shape)
+        assert torch.equal(c2.cpu(), oc2) and shape2 == [int(x) for x in oshape2]
+        for k, ((gi, go), (oi, oo)) in enumerate(zip(rb2.lists(), opairs)):
+            assert np.array_equal(gi, oi) and np.array_equal(go, oo), f'level {level} down offset {k}'
+        coords, shape, index, oc, oshape = c2, shape2, ix2, oc2, oshape2
+    return index
+
+
+def test_hashed_index_is_bit_exact(monkeypatch):
+    """The hashed form of the voxel index (radix sort -> unique -> open-addressing table; csrc/hashidx.hip) forced onto an ordinary
+    batch: voxel coordinates, inverse map, voxel features and the rulebooks of all five levels equal the oracle's bit for bit --
+    the same kernels as with the bitmap index, fed through the table."""
+    from unidet3d_amd import ops, sparse
+    monkeypatch.setattr(sparse, '_INDEX_MODE', 'hash')
+    scenes = _scene_points(3, 30_000, seed0=61)
+    pts_cpu = [torch.from_numpy(s.points) for s in scenes]
+    vb = ops.voxelize([p.to(_dev()) for p in pts_cpu], 0.02, 128)
+    assert vb.index.hashed
+    last = _check_levels_against_oracle(vb, pts_cpu, 0.02, 3)
+    assert last.hashed
+
+
+def test_large_extent_scene_takes_the_hashed_index():
+    """Two rooms 300 m apart at 2 cm voxels: a 15 000^2 x 150 grid, whose direct-address table u3d_index_words refuses (3.4e10 words)
+    -- the hashed index takes over on its own; everything stays bit-exact against the oracle, and a convolution runs on it."""
+    from unidet3d_amd import _lib as L, ops, sparse
+    a, b = _scene_points(2, 25_000, seed0=71)
+    pa, pb = a.points.copy(), b.points.copy()
+    pb[:, 0] += 300.0; pb[:, 1] += 299.0
+    pts_cpu = [torch.from_numpy(np.concatenate((pa, pb)).astype(np.float32))]
+    vb = ops.voxelize([pts_cpu[0].to(_dev())], 0.02, 128)
+    assert max(vb.spatial_shape) > 14_000 and L.lib().u3d_index_words(1, *vb.spatial_shape) < 0 and vb.index.hashed
+    _check_levels_against_oracle(vb, pts_cpu, 0.02, 1, n_levels=3)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    n = vb.coords.shape[0]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 32, generator=g); w = torch.randn(32, 3, 3, 3, 32, generator=g) * 0.1
+    y = sparse.sparse_conv(x.to(_dev()), w.to(_dev()), rb)
+    yo = so.sparse_conv(x.double(), w.double(), so.build_subm_rulebook(vb.coords.cpu(), vb.spatial_shape), n)
+    assert _rel(y, yo) < 1e-5
+
+
 # ---------------------------------------------------------------------------- K11 / K12
 def test_superpoint_pool_and_centers():
     from unidet3d_amd import ops

@@ -29,12 +29,17 @@ PROTOTYPES = {
     'u3d_index_rank': (_i32, [_vp, _i64, _vp, _vp, _vp]),
     'u3d_index_rank_ws_bytes': (_i64, [_i64]),
     'u3d_index_coords': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    'u3d_vox_finalize': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'u3d_vox_finalize': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'u3d_hash_index_slots': (_i64, [_i64]),
+    'u3d_hash_index_ws_bytes': (_i64, [_i64]),
+    'u3d_hash_index_build': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'u3d_hash_index_coords': (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'u3d_cells_of_coords': (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'u3d_vox_finalize_ws_bytes': (_i64, [_i64, _i64]),
-    'u3d_subm_rulebook': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_subm_rulebook': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_subm_rulebook_ws_bytes': (_i64, [_i64]),
     'u3d_index_mark': (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
-    'u3d_down_rulebook': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_down_rulebook': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_down_rulebook_ws_bytes': (_i64, [_i64]),
     'u3d_tile_starts': (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp]),
     'u3d_spconv_gmm': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),

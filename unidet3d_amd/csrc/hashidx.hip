@@ -1,0 +1,122 @@
+// Hashed voxel index: "hash-built rulebook in HBM" for grids whose EXTENT makes the direct-address bitmap of voxelize.hip /
+// rulebook.hip impractical (12 bytes per 64 z-cells of the bounding grid: 100 MB for eight 512 x 512 x 256 indoor grids, tens of GB
+// for an outdoor scene at the same voxel size).  Same contract as the bitmap form -- key -> CANONICAL row, rows ascending in the
+// cell id ((b X + x) Y + y) Zw 64 + z -- built the way spconv / MinkowskiEngine build theirs (reference call sites
+// unidet3d/unidet3d.py:158-174, unidet3d/spconv_unet.py:43-56,148-154), with the order made deterministic:
+//   1. radix sort of the cell ids of all points (or of the parent cells of a level's voxels) -- hipcub::DeviceRadixSort;
+//   2. unique -> the sorted occupied cells; position = canonical row (hipcub::DeviceSelect::Unique);
+//   3. open-addressing table (murmur3 finaliser, linear probing, 64-bit atomicCAS) cell id -> row, capacity 2 .. 4 x occupancy.
+// Lookups (index_lookup / index_row_of_cell in u3d_common.h) are one hash + on average < 1.5 probes; the rulebook, voxel-feature and
+// strided-level kernels are the SAME kernels as for the bitmap form (the Index they receive carries either).
+#include <hipcub/hipcub.hpp>
+
+#include "u3d_common.h"
+
+namespace u3d {
+
+constexpr int64_t CELL_NONE = 0x7fffffffffffffffLL;       // parent outside the halved grid: sorts last, dropped after unique
+
+// parent cell id of every voxel of a level at `shift` (0: the voxel's own cell)
+__global__ __launch_bounds__(256) void cells_of_coords_k(const int32_t* __restrict__ coords, int64_t n, int shift, int X2, int Y2, int Z2, int Zw2,
+                                                         int64_t* __restrict__ cells) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = *reinterpret_cast<const int4*>(coords + i * 4);
+    const int x = c.y >> shift, y = c.z >> shift, z = c.w >> shift;
+    int64_t cell = CELL_NONE;
+    if ((unsigned)x < (unsigned)X2 && (unsigned)y < (unsigned)Y2 && (unsigned)z < (unsigned)Z2)      // odd extent: edge voxel dropped
+        cell = (((int64_t)(c.x * X2 + x) * Y2 + y) * Zw2 + (z >> 6)) * 64 + (z & 63);
+    cells[i] = cell;
+}
+
+// n_unique may count the CELL_NONE sentinel: drop it
+__global__ void hash_count_fix_k(const int64_t* __restrict__ ukeys, int32_t* n_unique) {
+    const int n = *n_unique;
+    if (n > 0 && ukeys[n - 1] == CELL_NONE) *n_unique = n - 1;
+}
+
+__global__ __launch_bounds__(256) void hash_insert_k(const int64_t* __restrict__ ukeys, const int32_t* __restrict__ n_unique, int64_t n_max,
+                                                     unsigned long long* keys, int32_t* vals, uint64_t mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_max || i >= *n_unique) return;
+    const unsigned long long key = (unsigned long long)ukeys[i];
+    uint64_t slot = hash_mix(key) & mask;
+    while (atomicCAS(&keys[slot], (unsigned long long)U3D_HASH_EMPTY, key) != (unsigned long long)U3D_HASH_EMPTY) slot = (slot + 1) & mask;   // keys are unique
+    vals[slot] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void hash_coords_k(const int64_t* __restrict__ ukeys, int64_t n, int X, int Y, int Zw, int32_t* __restrict__ coords) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t cell = ukeys[i];
+    const int bit = (int)(cell & 63);
+    int64_t w = cell >> 6;
+    const int zw = (int)(w % Zw); w /= Zw;
+    const int y = (int)(w % Y); w /= Y;
+    const int x = (int)(w % X);
+    const int b = (int)(w / X);
+    *reinterpret_cast<int4*>(coords + i * 4) = make_int4(b, x, y, zw * 64 + bit);
+}
+
+static size_t sort_ws(int64_t n) {
+    size_t a = 0, b = 0;
+    hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const int64_t*)nullptr, (int64_t*)nullptr, (int)n);
+    hipcub::DeviceSelect::Unique(nullptr, b, (const int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr, (int)n);
+    return (a > b ? a : b) + 256;
+}
+
+}  // namespace u3d
+
+using namespace u3d;
+
+extern "C" {
+
+// slots of the table for n occupied cells: the power of two in [2 n, 4 n)
+int64_t u3d_hash_index_slots(int64_t n) {
+    int64_t s = 64;
+    while (s < 2 * n) s <<= 1;
+    return s;
+}
+
+int64_t u3d_hash_index_ws_bytes(int64_t n) {
+    if (n <= 0 || n >= 0x7fffffffLL) return 0;
+    return (int64_t)sort_ws(n) + n * 8 + 256;
+}
+
+int u3d_cells_of_coords(const int32_t* coords, int64_t n, int shift, int B, int X2, int Y2, int Z2, int64_t* cells, u3d_stream_t stream) {
+    if (!coords || !cells || n <= 0 || X2 <= 0 || Y2 <= 0 || Z2 <= 0 || B <= 0 || shift < 0 || shift > 8) return U3D_EINVAL;
+    if ((long double)B * X2 * Y2 * ((Z2 + 63) / 64) * 64 >= 4.0e18L) { set_error("hash index: grid %d x %d x %d x %d exceeds 62-bit cell ids", B, X2, Y2, Z2); return U3D_EUNSUPPORTED; }
+    hipLaunchKernelGGL(cells_of_coords_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, coords, n, shift, X2, Y2, Z2,
+                       (Z2 + 63) / 64, cells);
+    return check_launch("cells_of_coords");
+}
+
+// cells [n] (duplicates allowed; CELL_NONE entries are ignored) -> ukeys [n] sorted unique cells (first *n_unique entries valid),
+// n_unique (device int32), table (keys uint64 [slots], vals int32 [slots]; slots = u3d_hash_index_slots(n)).
+int u3d_hash_index_build(const int64_t* cells, int64_t n, int64_t* ukeys, int32_t* n_unique, uint64_t* table_keys, int32_t* table_vals,
+                         int64_t slots, void* ws, u3d_stream_t stream) {
+    if (!cells || !ukeys || !n_unique || !table_keys || !table_vals || !ws || n <= 0 || n >= 0x7fffffffLL || slots < 2 * n || (slots & (slots - 1)))
+        return U3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_RULEBOOK, s, 0.0);
+    int64_t* sorted = (int64_t*)ws;
+    void* tmp = (char*)ws + ((n * 8 + 255) & ~(int64_t)255);
+    size_t tmp_bytes = sort_ws(n);
+    if (hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, cells, sorted, (int)n, 0, 63, s) != hipSuccess) { set_error("hash index: radix sort failed"); return U3D_ELAUNCH; }
+    tmp_bytes = sort_ws(n);
+    if (hipcub::DeviceSelect::Unique(tmp, tmp_bytes, (const int64_t*)sorted, ukeys, n_unique, (int)n, s) != hipSuccess) { set_error("hash index: unique failed"); return U3D_ELAUNCH; }
+    hipLaunchKernelGGL(hash_count_fix_k, dim3(1), dim3(1), 0, s, (const int64_t*)ukeys, n_unique);
+    hipMemsetAsync(table_keys, 0xff, (size_t)slots * 8, s);
+    hipLaunchKernelGGL(hash_insert_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, (const int64_t*)ukeys, (const int32_t*)n_unique, n,
+                       (unsigned long long*)table_keys, table_vals, (uint64_t)slots - 1);
+    return check_launch("hash_index_build");
+}
+
+int u3d_hash_index_coords(const int64_t* ukeys, int64_t n, int X, int Y, int Z, int32_t* coords, u3d_stream_t stream) {
+    if (!ukeys || !coords || n < 0 || X <= 0 || Y <= 0 || Z <= 0) return U3D_EINVAL;
+    if (n == 0) return U3D_OK;
+    hipLaunchKernelGGL(hash_coords_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ukeys, n, X, Y, (Z + 63) / 64, coords);
+    return check_launch("hash_index_coords");
+}
+
+}  // extern "C"

@@ -174,13 +174,13 @@ extern "C" {
 int64_t u3d_subm_rulebook_ws_bytes(int64_t n) { return (2 * 27 * ceil_div(n, RB_T) + 64) * 4; }      // block counts + bases only
 int64_t u3d_down_rulebook_ws_bytes(int64_t n) { return rb_ws_bytes(n, 8); }
 
-int u3d_subm_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int B,
+int u3d_subm_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots, int B,
                       int X, int Y, int Z, int32_t* pair_in, int32_t* pair_out, int32_t* counts, void* ws,
                       u3d_stream_t stream) {
     if (!coords || !bitmap || !word_rank || !pair_in || !pair_out || !counts || !ws || n <= 0) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_RULEBOOK, s, 0.0);
-    Index ix{bitmap, word_rank, B, X, Y, Z, (Z + 63) / 64};
+    const Index ix = make_index(bitmap, word_rank, B, X, Y, Z, hash_slots);
     const int nblk = (int)ceil_div(n, RB_T);
     int32_t* bc = (int32_t*)ws;
     int32_t* bb = bc + (int64_t)27 * nblk;
@@ -198,13 +198,13 @@ int u3d_index_mark(const int32_t* coords, int64_t n, int shift, int X2, int Y2, 
     return check_launch("index_mark");
 }
 
-int u3d_down_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap2, const int32_t* word_rank2, int B,
+int u3d_down_rulebook(const int32_t* coords, int64_t n, const uint64_t* bitmap2, const int32_t* word_rank2, int64_t hash_slots, int B,
                       int X2, int Y2, int Z2, int32_t* pair_in, int32_t* pair_out, int32_t* counts, void* ws,
                       u3d_stream_t stream) {
     if (!coords || !bitmap2 || !word_rank2 || !pair_in || !pair_out || !counts || !ws || n <= 0) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_RULEBOOK, s, 0.0);
-    Index ix{bitmap2, word_rank2, B, X2, Y2, Z2, (Z2 + 63) / 64};
+    const Index ix = make_index(bitmap2, word_rank2, B, X2, Y2, Z2, hash_slots);
     const int nblk = (int)ceil_div(n, RB_T);
     int32_t* val = (int32_t*)ws;
     int32_t* bc = val + 8 * n;

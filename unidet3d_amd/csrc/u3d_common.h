@@ -63,19 +63,57 @@ int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hip
 int64_t scan_ws_bytes(int64_t n);
 
 // ---- occupancy index (bitmap + popcount rank) ------------------------------------------
+// Key -> canonical row map of one level.  Two forms behind one lookup:
+//  * direct-address (default): occupancy bitmap + popcount rank per 64 z-cells; size follows the grid EXTENT;
+//  * hashed (hkeys != nullptr; csrc/hashidx.hip): open-addressing table cell id -> row built from the sorted unique cell ids;
+//    size follows the number of occupied voxels -- for extents where the bitmap would be impractical (outdoor scenes).
+// Cell id of (b, x, y, z) = ((b X + x) Y + y) Zw 64 + z in both forms (= bitmap word * 64 + bit): ascending id = canonical order.
 struct Index {
     const uint64_t* bitmap;
     const int32_t* rank;
     int B, X, Y, Z, Zw;
+    const uint64_t* hkeys = nullptr;      // hashed form: table of cell ids (U3D_HASH_EMPTY = free slot) ...
+    const int32_t* hvals = nullptr;       // ... and their rows
+    uint64_t hmask = 0;                   // slots - 1 (slots: power of two)
 };
+
+constexpr uint64_t U3D_HASH_EMPTY = ~0ull;
+__device__ __forceinline__ uint64_t hash_mix(uint64_t k) {      // murmur3 finaliser
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+__device__ __forceinline__ int hash_find(const Index& ix, uint64_t cell) {
+    uint64_t slot = hash_mix(cell) & ix.hmask;
+    while (true) {
+        const uint64_t k = ix.hkeys[slot];
+        if (k == cell) return ix.hvals[slot];
+        if (k == U3D_HASH_EMPTY) return -1;
+        slot = (slot + 1) & ix.hmask;
+    }
+}
+static inline Index make_index(const uint64_t* bitmap_or_keys, const int32_t* rank_or_vals, int B, int X, int Y, int Z, int64_t hash_slots) {
+    Index ix;
+    ix.B = B; ix.X = X; ix.Y = Y; ix.Z = Z; ix.Zw = (Z + 63) / 64;
+    if (hash_slots > 0) { ix.bitmap = nullptr; ix.rank = nullptr; ix.hkeys = bitmap_or_keys; ix.hvals = rank_or_vals; ix.hmask = (uint64_t)hash_slots - 1; }
+    else { ix.bitmap = bitmap_or_keys; ix.rank = rank_or_vals; }
+    return ix;
+}
 
 __device__ __forceinline__ int index_lookup(const Index& ix, int b, int x, int y, int z) {
     if ((unsigned)x >= (unsigned)ix.X || (unsigned)y >= (unsigned)ix.Y || (unsigned)z >= (unsigned)ix.Z) return -1;
     const int64_t w = ((int64_t)(b * ix.X + x) * ix.Y + y) * ix.Zw + (z >> 6);
-    const uint64_t word = ix.bitmap[w];
     const int bit = z & 63;
+    if (ix.hkeys) return hash_find(ix, (uint64_t)w * 64 + bit);
+    const uint64_t word = ix.bitmap[w];
     if (!((word >> bit) & 1ull)) return -1;
     return ix.rank[w] + __popcll(word & ((1ull << bit) - 1ull));
+}
+// row of a cell id (bitmap word * 64 + bit) that is known to be occupied
+__device__ __forceinline__ int index_row_of_cell(const Index& ix, int64_t cell) {
+    if (ix.hkeys) return hash_find(ix, (uint64_t)cell);
+    const int64_t w = cell >> 6;
+    const int bit = (int)(cell & 63);
+    return ix.rank[w] + __popcll(ix.bitmap[w] & ((1ull << bit) - 1ull));
 }
 
 }  // namespace u3d

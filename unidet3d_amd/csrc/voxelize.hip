@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void vox_mark_k(const float* __restrict__ poin
     int z = cell_of(c[2], stats[b * 12 + 2], vs, inv_vs, mode);
     x = min(max(x, 0), X - 1); y = min(max(y, 0), Y - 1); z = min(max(z, 0), Z - 1);
     const int64_t w = ((int64_t)(b * X + x) * Y + y) * Zw + (z >> 6);
-    atomicOr(&bitmap[w], 1ull << (z & 63));
+    if (bitmap) atomicOr(&bitmap[w], 1ull << (z & 63));       // (hashed index: only the cell ids are wanted)
     pt_cell[p] = w * 64 + (z & 63);
 }
 
@@ -126,15 +126,11 @@ __global__ __launch_bounds__(256) void index_coords_k(const uint64_t* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void vox_inverse_k(const int64_t* __restrict__ pt_cell, const uint64_t* __restrict__ bitmap,
-                                                     const int32_t* __restrict__ rank, int64_t n_pts, int64_t* inverse,
+__global__ __launch_bounds__(256) void vox_inverse_k(const int64_t* __restrict__ pt_cell, Index ix, int64_t n_pts, int64_t* inverse,
                                                      int32_t* cnt) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pts) return;
-    const int64_t cell = pt_cell[p];
-    const int64_t w = cell >> 6;
-    const int bit = (int)(cell & 63);
-    const int row = rank[w] + __popcll(bitmap[w] & ((1ull << bit) - 1ull));
+    const int row = index_row_of_cell(ix, pt_cell[p]);
     inverse[p] = row;
     atomicAdd(&cnt[row], 1);
 }
@@ -219,7 +215,8 @@ int64_t u3d_index_words(int B, int X, int Y, int Z) {
 int u3d_vox_mark(const float* points, const float* coord_src, const int64_t* pt_offsets, int B, int64_t max_pts,
                  const float* stats, float voxel_size, int div_mode, int X, int Y, int Z, uint64_t* bitmap,
                  int64_t* pt_cell, u3d_stream_t stream) {
-    if (!points || !pt_offsets || !stats || !bitmap || !pt_cell || B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return U3D_EINVAL;
+    if (!points || !pt_offsets || !stats || !pt_cell || B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return U3D_EINVAL;      // bitmap may be NULL
+    if ((long double)B * X * Y * ((Z + 63) / 64) * 64 >= 4.0e18L) { set_error("vox_mark: grid %d x %d x %d x %d exceeds 62-bit cell ids", B, X, Y, Z); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_VOXELIZE, s, 0.0);
     if (max_pts <= 0) return U3D_OK;
@@ -244,7 +241,7 @@ int64_t u3d_vox_finalize_ws_bytes(int64_t n_pts, int64_t n_vox) {
 }
 
 int u3d_vox_finalize(const float* points, const int64_t* pt_offsets, int B, int64_t n_pts, const float* stats,
-                     const int64_t* pt_cell, const uint64_t* bitmap, const int32_t* word_rank, int64_t n_vox,
+                     const int64_t* pt_cell, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots, int64_t n_vox,
                      int64_t* inverse, int32_t* vox_offsets, int32_t* vox_points, float* feats, int feat_ld, void* ws,
                      u3d_stream_t stream) {
     if (!points || !pt_offsets || !stats || !pt_cell || !bitmap || !word_rank || !inverse || !vox_offsets ||
@@ -258,7 +255,8 @@ int u3d_vox_finalize(const float* points, const int64_t* pt_offsets, int B, int6
     void* sws = (void*)(((uintptr_t)(cursor + n_vox + 1) + 63) & ~(uintptr_t)63);
     hipMemsetAsync(cnt, 0, (size_t)(2 * (n_vox + 1)) * 4, s);
     const unsigned gp = (unsigned)ceil_div(n_pts, 256);
-    hipLaunchKernelGGL(vox_inverse_k, dim3(gp), dim3(256), 0, s, pt_cell, bitmap, word_rank, n_pts, inverse, cnt);
+    // (only the table / bitmap pointers of the index are used here: cell ids carry the geometry)
+    hipLaunchKernelGGL(vox_inverse_k, dim3(gp), dim3(256), 0, s, pt_cell, make_index(bitmap, word_rank, B, 1, 1, 1, hash_slots), n_pts, inverse, cnt);
     int rc = exclusive_scan_i32(cnt, n_vox, vox_offsets, sws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_fill_k, dim3(gp), dim3(256), 0, s, (const int64_t*)inverse, (const int32_t*)vox_offsets,

@@ -54,11 +54,17 @@ def voxelize(points: List[torch.Tensor], voxel_size: float, min_spatial_shape: i
     L.call('u3d_vox_scene_stats', L.ptr(pts), L.ptr(csrc), L.ptr(offs), B, max(sizes), vs, div_mode,
            L.ptr(stats), L.ptr(gmax), L.ptr(w), L.stream())
     shape = [max(int(v) + 1, int(min_spatial_shape)) for v in gmax.tolist()]       # read-back #1
-    index = OccupancyIndex.alloc(B, shape, dev)
     pt_cell = torch.empty(n_pts, dtype=torch.int64, device=dev)
-    L.call('u3d_vox_mark', L.ptr(pts), L.ptr(csrc), L.ptr(offs), B, max(sizes), L.ptr(stats), vs, div_mode,
-           *shape, L.ptr(index.bitmap), L.ptr(pt_cell), L.stream())
-    index.build_rank()
+    if OccupancyIndex.wants_hash(B, shape):
+        # large extent: cell ids only, then sort -> unique -> hash table (memory follows occupancy, csrc/hashidx.hip)
+        L.call('u3d_vox_mark', L.ptr(pts), L.ptr(csrc), L.ptr(offs), B, max(sizes), L.ptr(stats), vs, div_mode,
+               *shape, None, L.ptr(pt_cell), L.stream())
+        index = OccupancyIndex.from_cells(pt_cell, B, shape)
+    else:
+        index = OccupancyIndex.alloc(B, shape, dev)
+        L.call('u3d_vox_mark', L.ptr(pts), L.ptr(csrc), L.ptr(offs), B, max(sizes), L.ptr(stats), vs, div_mode,
+               *shape, L.ptr(index.bitmap), L.ptr(pt_cell), L.stream())
+        index.build_rank()
     n_vox = index.count()                                                          # read-back #2
     coords = index.coords(n_vox)
     inverse = torch.empty(n_pts, dtype=torch.int64, device=dev)
@@ -66,8 +72,7 @@ def voxelize(points: List[torch.Tensor], voxel_size: float, min_spatial_shape: i
     vox_points = torch.empty(n_pts, dtype=torch.int32, device=dev)
     feats = torch.empty(n_vox, 6, dtype=torch.float32, device=dev)
     w2 = L.ws(L.lib().u3d_vox_finalize_ws_bytes(n_pts, n_vox), dev)
-    L.call('u3d_vox_finalize', L.ptr(pts), L.ptr(offs), B, n_pts, L.ptr(stats), L.ptr(pt_cell), L.ptr(index.bitmap),
-           L.ptr(index.rank), n_vox, L.ptr(inverse), L.ptr(vox_offsets), L.ptr(vox_points), L.ptr(feats), 6,
+    L.call('u3d_vox_finalize', L.ptr(pts), L.ptr(offs), B, n_pts, L.ptr(stats), L.ptr(pt_cell), *index.table(), n_vox, L.ptr(inverse), L.ptr(vox_offsets), L.ptr(vox_points), L.ptr(feats), 6,
            L.ptr(w2), L.stream())
     return VoxelBatch(coords, feats, inverse, shape, index, vox_offsets, vox_points, offs, stats, pts, csrc)
 

@@ -33,12 +33,37 @@ from . import account
 # ----------------------------------------------------------------------------------------
 # geometry: occupancy index + rulebooks
 # ----------------------------------------------------------------------------------------
-class OccupancyIndex:
-    """Bitmap + popcount rank of one level (key -> canonical row)."""
+# A grid whose direct-address table would exceed this many bytes (or that u3d_index_words refuses) gets the hashed index
+# (csrc/hashidx.hip: memory follows occupancy).  The six indoor configs stay far below (cfg2: 100 MB); U3D_INDEX=hash forces the
+# hashed form everywhere (tests), U3D_INDEX=bitmap forbids it.
+_INDEX_MODE = os.environ.get('U3D_INDEX', 'auto')
+_HASH_ABOVE_BYTES = int(float(os.environ.get('U3D_INDEX_HASH_ABOVE_MB', '4096')) * (1 << 20))
 
-    def __init__(self, bitmap, rank, B, shape):
-        self.bitmap, self.rank, self.B = bitmap, rank, B
+
+class OccupancyIndex:
+    """Cell -> canonical row of one level: bitmap + popcount rank over the grid extent, or -- large extents -- a hash table over the
+    occupied cells.  ``table()`` gives the (pointer, pointer, hash_slots) triple every C entry point takes."""
+
+    def __init__(self, bitmap, rank, B, shape, slots=0, ukeys=None, n_dev=None):
+        self.bitmap, self.rank, self.B = bitmap, rank, B          # hashed form: table keys (int64 view of uint64) / table values
         self.shape = [int(s) for s in shape]
+        self.slots, self.ukeys, self.n_dev = int(slots), ukeys, n_dev
+
+    @property
+    def hashed(self) -> bool:
+        return self.slots > 0
+
+    def table(self):
+        return L.ptr(self.bitmap), L.ptr(self.rank), self.slots
+
+    @staticmethod
+    def wants_hash(B, shape) -> bool:
+        if _INDEX_MODE == 'hash':
+            return True
+        nw = L.lib().u3d_index_words(B, *[int(s) for s in shape])
+        if _INDEX_MODE == 'bitmap':
+            return False
+        return nw < 0 or nw * 12 > _HASH_ABOVE_BYTES
 
     @staticmethod
     def alloc(B, shape, device):
@@ -49,22 +74,42 @@ class OccupancyIndex:
         rank = torch.empty(nw + 1, dtype=torch.int32, device=device)
         return OccupancyIndex(bitmap, rank, B, shape)
 
+    @staticmethod
+    def from_cells(cells: torch.Tensor, B: int, shape) -> 'OccupancyIndex':
+        """Hashed index of the cells in ``cells`` (int64 cell ids, duplicates allowed, INT64_MAX = none)."""
+        n, dev = cells.shape[0], cells.device
+        slots = L.lib().u3d_hash_index_slots(n)
+        ukeys = torch.empty(n, dtype=torch.int64, device=dev)
+        n_dev = torch.empty(1, dtype=torch.int32, device=dev)
+        keys = torch.empty(slots, dtype=torch.int64, device=dev)
+        vals = torch.empty(slots, dtype=torch.int32, device=dev)
+        w = L.ws(L.lib().u3d_hash_index_ws_bytes(n), dev)
+        L.call('u3d_hash_index_build', L.ptr(cells), n, L.ptr(ukeys), L.ptr(n_dev), L.ptr(keys), L.ptr(vals), slots, L.ptr(w), L.stream())
+        return OccupancyIndex(keys, vals, B, shape, slots, ukeys, n_dev)
+
     def build_rank(self):
         nw = self.bitmap.numel()
         w = L.ws(L.lib().u3d_index_rank_ws_bytes(nw), self.bitmap.device)
         L.call('u3d_index_rank', L.ptr(self.bitmap), nw, L.ptr(self.rank), L.ptr(w), L.stream())
 
     def count(self) -> int:
-        return int(self.rank[-1].item())       # documented read-back (one host sync)
+        return int((self.n_dev if self.hashed else self.rank[-1]).item())       # documented read-back (one host sync)
 
     def coords(self, n: int) -> torch.Tensor:
         c = torch.empty(n, 4, dtype=torch.int32, device=self.bitmap.device)
-        if n:
+        if n and self.hashed:
+            L.call('u3d_hash_index_coords', L.ptr(self.ukeys), n, *self.shape, L.ptr(c), L.stream())
+        elif n:
             L.call('u3d_index_coords', L.ptr(self.bitmap), L.ptr(self.rank), self.B, *self.shape, L.ptr(c), L.stream())
         return c
 
     @staticmethod
     def from_coords(coords: torch.Tensor, B: int, shape, shift: int = 0) -> 'OccupancyIndex':
+        shape = [int(s) for s in shape]
+        if OccupancyIndex.wants_hash(B, shape):
+            cells = torch.empty(coords.shape[0], dtype=torch.int64, device=coords.device)
+            L.call('u3d_cells_of_coords', L.ptr(coords), coords.shape[0], shift, B, *shape, L.ptr(cells), L.stream())
+            return OccupancyIndex.from_cells(cells, B, shape)
         ix = OccupancyIndex.alloc(B, shape, coords.device)
         L.call('u3d_index_mark', L.ptr(coords), coords.shape[0], shift, *ix.shape, L.ptr(ix.bitmap), L.stream())
         ix.build_rank()
@@ -119,7 +164,7 @@ def build_subm_rulebook(coords: torch.Tensor, index: OccupancyIndex) -> Rulebook
     pout = torch.empty(27, n, dtype=torch.int32, device=dev)
     cnt = torch.empty(27, dtype=torch.int32, device=dev)
     w = L.ws(L.lib().u3d_subm_rulebook_ws_bytes(n), dev)
-    L.call('u3d_subm_rulebook', L.ptr(coords), n, L.ptr(index.bitmap), L.ptr(index.rank), index.B, *index.shape,
+    L.call('u3d_subm_rulebook', L.ptr(coords), n, *index.table(), index.B, *index.shape,
            L.ptr(pin), L.ptr(pout), L.ptr(cnt), L.ptr(w), L.stream())
     return Rulebook(pin, pout, cnt, 27, n, n)
 
@@ -136,7 +181,7 @@ def build_down_rulebook(coords: torch.Tensor, B: int, shape):
     pout = torch.empty(8, n, dtype=torch.int32, device=dev)
     cnt = torch.empty(8, dtype=torch.int32, device=dev)
     w = L.ws(L.lib().u3d_down_rulebook_ws_bytes(n), dev)
-    L.call('u3d_down_rulebook', L.ptr(coords), n, L.ptr(ix2.bitmap), L.ptr(ix2.rank), B, *oshape,
+    L.call('u3d_down_rulebook', L.ptr(coords), n, *ix2.table(), B, *oshape,
            L.ptr(pin), L.ptr(pout), L.ptr(cnt), L.ptr(w), L.stream())
     return oc, oshape, ix2, Rulebook(pin, pout, cnt, 8, n, n2)
 

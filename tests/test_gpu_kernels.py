@@ -290,15 +290,17 @@ def test_hashed_index_is_bit_exact(monkeypatch):
 
 
 def test_large_extent_scene_takes_the_hashed_index():
-    """Two rooms 300 m apart at 2 cm voxels: a 15 000^2 x 150 grid, whose direct-address table u3d_index_words refuses (3.4e10 words)
-    -- the hashed index takes over on its own; everything stays bit-exact against the oracle, and a convolution runs on it."""
+    """Two rooms 300 m apart at 2 cm voxels: a 15 000 x 15 000 x 128 grid, whose direct-address table would take 5.5 GB for 26 k
+    voxels -- the hashed index (under 2 MB) takes over on its own; everything stays bit-exact against the oracle, and a
+    convolution runs on it."""
     from unidet3d_amd import _lib as L, ops, sparse
     a, b = _scene_points(2, 25_000, seed0=71)
     pa, pb = a.points.copy(), b.points.copy()
     pb[:, 0] += 300.0; pb[:, 1] += 299.0
     pts_cpu = [torch.from_numpy(np.concatenate((pa, pb)).astype(np.float32))]
     vb = ops.voxelize([pts_cpu[0].to(_dev())], 0.02, 128)
-    assert max(vb.spatial_shape) > 14_000 and L.lib().u3d_index_words(1, *vb.spatial_shape) < 0 and vb.index.hashed
+    assert max(vb.spatial_shape) > 14_000 and L.lib().u3d_index_words(1, *vb.spatial_shape) * 12 > 4 << 30 and vb.index.hashed
+    assert (vb.index.bitmap.numel() * 8 + vb.index.rank.numel() * 4) < 4 << 20
     _check_levels_against_oracle(vb, pts_cpu, 0.02, 1, n_levels=3)
     rb = sparse.build_subm_rulebook(vb.coords, vb.index)
     n = vb.coords.shape[0]

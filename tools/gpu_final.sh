@@ -1,16 +1,24 @@
 #!/bin/bash
-# Round-end evidence in one GPU-box visit: full -m gpu suite (log kept), default bench lines (fp32 with the CPU baseline, bf16),
-# rocprofv3 kernel stats of both, PMC traffic of the fp32 bench.   usage: tools/gpu_final.sh <tag>
+# Round-end evidence on one MI355X: full -m gpu suite (log + parity errors kept), default bench line (fp32 headline + cfg3 block +
+# cpu baseline), rocprofv3 kernel stats of the fp32 and bf16 bench, PMC traffic of the bench step.  usage: tools/gpu_final.sh <tag>
 TAG=${1:-final}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
 rm -f gpurun_out/parity_errors.jsonl
-timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.log
-timeout 300 python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.log
-python -c "
-import json
-for f in ('bench', 'bench_bf16'):
-    d = json.load(open('$OUT/' + f + '.json')); print(f, d['value'], d['ms_per_step'], {k: (round(v['ms_per_step'], 2), v['frac_mfma'] and round(v['frac_mfma'], 3)) for k, v in d['kernels'].items()})"
-bash tools/gpu_prof.sh $TAG > $OUT/prof.txt 2>&1; head -11 $OUT/prof.txt
-bash tools/pmc_bench.sh > $OUT/pmc.txt 2>&1; cp gpurun_out/pmc_bench/summary.json $OUT/pmc_summary.json; tail -4 $OUT/pmc.txt | cut -c1-200
-timeout 1150 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt
-tail -6 $OUT/pytest_gpu.txt
+T0=$(date +%s)
+timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt
+tail -6 $OUT/pytest_gpu.txt | cut -c1-300
 cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
+echo "t=$(( $(date +%s) - T0 ))s"
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.log || tail -5 $OUT/bench.log
+python - <<PY
+import json
+d = json.load(open('$OUT/bench.json'))
+print('fp32:', round(d['value'], 1), round(d['ms_per_step'], 2), {k: (round(v['ms_per_step'], 2), v['frac_mfma'] and round(v['frac_mfma'], 3)) for k, v in d['kernels'].items()}, d['config']['warmup_losses'])
+c = d.get('cfg3')
+if c: print('cfg3:', round(c['value'], 1), round(c['ms_per_step'], 2), {k: round(v['ms_per_step'], 2) for k, v in c['kernels'].items()})
+print('cpu:', d.get('cpu_baseline', {}).get('value'), 'traffic:', d['roofline']['traffic'])
+PY
+echo "t=$(( $(date +%s) - T0 ))s"
+bash tools/gpu_prof.sh ${TAG}_prof > $OUT/prof.log 2>&1; grep -E "GPU busy|steps in" $OUT/prof.log
+echo "t=$(( $(date +%s) - T0 ))s"
+PMC_TAG=${TAG}_pmc bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; grep -E "_spconv_gmm|spconv_gmm_k<2" $OUT/pmc.log | cut -c1-200
+echo "t=$(( $(date +%s) - T0 ))s"

@@ -49,7 +49,7 @@ def test_gpus_n_turns_itself_into_a_torchrun_launch(monkeypatch):
 
 def test_kept_bench_lines_follow_the_contract():
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round2_final_bench_*.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round2_final_bench_*.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'round3_bench_*.json')))
     assert files, 'no bench line kept under profiles/'
     for f in files:
         d = json.load(open(f))
@@ -69,5 +69,11 @@ def test_kept_bench_lines_follow_the_contract():
         if 'cpu_baseline' in d and d['cpu_baseline']:
             c = d['cpu_baseline']
             assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
-    main = json.load(open(os.path.join(ROOT, 'profiles', 'round2_final_bench_fp32.json')))
-    assert main['cpu_baseline'] and main['n_gpus'] == 1 and main['config']['global_batch'] == 8
+    for name in ('round2_final_bench_fp32.json', 'round3_bench_fp32.json'):
+        main = json.load(open(os.path.join(ROOT, 'profiles', name)))
+        assert main['cpu_baseline'] and main['n_gpus'] == 1 and main['config']['global_batch'] == 8 and main['dtype'] == 'f32'
+    # round 3: the driver-visible line carries BASELINE configs[2] as a block of its own
+    c3 = main['cfg3']
+    assert c3['dtype'] == 'bf16' and c3['config']['global_batch'] == 16 and 'cfg3' in c3['config']['workload']
+    assert abs(c3['value'] - 16 / c3['ms_per_step'] * 1e3) < 1e-6 * c3['value'] and c3['roofline']['peak'] == 2500.0
+    assert 'median of' in main['cpu_baseline']['sample'] and 'warm-up' in main['cpu_baseline']['sample']      # SURVEY 8(d) protocol

@@ -192,13 +192,10 @@ int u3d_weight_transpose(const float* w, float* wt, int Cd, int K, int Cs, u3d_s
  *     Split so that the caller can all-reduce the fp64 statistics between the two phases
  *     (SyncBatchNorm across data-parallel ranks).
  * ===================================================================================== */
-/* sums[0..C) = sum x, sums[C..2C) = sum x^2, sums[2C] = n (fp64).  ONE launch: per-workgroup partial rows in ws, the last
- * workgroup to finish (threadfence reduction on *ticket) adds them in a fixed order -> deterministic.
- * partial != NULL: the statistics come from the per-tile sums a convolution epilogue wrote (u3d_spconv_gmm bn_partial,
- * float [n_tiles][2][C]) and x is not read.  ws: u3d_bn_ws_bytes(C).  ticket: device int32, zero before the call on this
- * stream, zero again after it (one per stream; calls on one stream are ordered). */
-int u3d_bn_stats(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, double* sums, void* ws, int32_t* ticket,
-                 u3d_stream_t stream);
+/* sums[0..C) = sum x, sums[C..2C) = sum x^2, sums[2C] = n (fp64): per-workgroup partial rows in ws, added in a fixed order by a
+ * second launch -> deterministic.  partial != NULL: the statistics come from the per-tile sums a convolution epilogue wrote
+ * (u3d_spconv_gmm bn_partial, float [n_tiles][2][C]) and x is not read.  ws: u3d_bn_ws_bytes(C). */
+int u3d_bn_stats(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, double* sums, void* ws, u3d_stream_t stream);
 int64_t u3d_bn_ws_bytes(int C);
 /* mean/var from sums/count; scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place
  * (momentum, unbiased var) when running_mean != NULL.  count <= 0: the row count is read from sums[2C]
@@ -210,10 +207,9 @@ int u3d_bn_finalize(const double* sums, double count, const float* gamma, const 
 int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y,
                  u3d_stream_t stream);
 /* backward of y = relu(x*scale+shift): sums[0..C) = sum dy', sums[C..2C) = sum dy'*xhat  (dy' = dy*[y>0]);
- * sums[2C] is left untouched (the caller keeps the forward row count there).  One launch, ticket as in u3d_bn_stats. */
+ * sums[2C] is left untouched (the caller keeps the forward row count there). */
 int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd,
-                     const float* scale, const float* shift, int relu, int64_t n, int C, double* sums, void* ws, int32_t* ticket,
-                     u3d_stream_t stream);
+                     const float* scale, const float* shift, int relu, int64_t n, int C, double* sums, void* ws, u3d_stream_t stream);
 /* dx = scale*(dy' - sum_dy/count - xhat*sum_dyxhat/count); dgamma = sum_dyxhat, dbeta = sum_dy (fp32 out);
  * count <= 0: read from sums[2C]. */
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd,
@@ -221,16 +217,16 @@ int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const f
                      int64_t n, int C, float* dx, float* dgamma, float* dbeta, const float* addend /* nullable [n][C]: added to dx (a second gradient of x, e.g. the residual identity branch) */,
                      u3d_stream_t stream);
 
-/* Single-call forms for the non-distributed case: forward = statistics (+ finalize by the last workgroup) -> apply, two launches;
- * backward = bwd_stats -> bwd_apply, two launches.  st float [4C] = mean, invstd, scale, shift (saved for backward); sums double
- * [2C+1]; partial / n_tiles / ticket as in u3d_bn_stats. */
+/* Single-call forms for the non-distributed case: forward = statistics -> sum + finalize -> apply; backward = bwd_stats -> sum ->
+ * bwd_apply.  st float [4C] = mean, invstd, scale, shift (saved for backward); sums double [2C+1]; partial / n_tiles as in
+ * u3d_bn_stats. */
 int u3d_bn_forward(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st,
-                   double* sums, void* ws, int32_t* ticket, u3d_stream_t stream);
+                   double* sums, void* ws, u3d_stream_t stream);
 /* fwd_sums: the forward call's sums vector (its entry [2C] is the row count the backward divides by) */
 int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n,
                     int C, float* dx, float* dgamma, float* dbeta, const float* addend /* nullable, as in u3d_bn_bwd_apply */, void* ws,
-                    int32_t* ticket, u3d_stream_t stream);
+                    u3d_stream_t stream);
 
 /* =====================================================================================
  * K11/K12  superpoint pooling -- replaces x.features[inverse_mapping] + torch_scatter.scatter_mean

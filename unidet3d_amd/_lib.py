@@ -60,13 +60,13 @@ PROTOTYPES = {
     'u3d_trim_boxes': (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _f32, _vp, _vp]),
     'u3d_weight_pack': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_weight_transpose': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
-    'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'u3d_bn_ws_bytes': (_i64, [_i32]),
-    'u3d_bn_forward': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'u3d_bn_backward': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_forward': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_backward': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_bn_finalize': (_i32, [_vp, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_bn_apply': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
-    'u3d_bn_bwd_stats': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'u3d_bn_bwd_stats': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'u3d_bn_bwd_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     'u3d_csr_build_ws_bytes': (_i64, [_i64, _i64]),
@@ -170,21 +170,6 @@ def scratch(nbytes: int, device) -> torch.Tensor:
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 21), dtype=torch.uint8, device=device)
         _SCRATCH[key] = t
-    return t
-
-
-_TICKETS = {}
-
-
-def ticket(device) -> torch.Tensor:
-    """Zero-initialised int32 counter per (device, stream) for the kernels that finish with a threadfence reduction (the last
-    workgroup to arrive combines the partial results and resets the counter): launches on one stream are ordered, so one counter
-    per stream is enough; a side stream gets its own."""
-    key = (device, stream())
-    t = _TICKETS.get(key)
-    if t is None:
-        t = torch.zeros(16, dtype=torch.int32, device=device)
-        _TICKETS[key] = t
     return t
 
 

@@ -10,10 +10,9 @@
 
 namespace u3d {
 
-// What the LAST workgroup of a statistics kernel does after every workgroup has written its partial row (fp64 [2C]) to the
-// workspace: sum the rows of each column in a fixed order (deterministic), store sums[0..2C) (+ the row count) and, for the
-// forward pass, finalize the layer (mean / invstd / scale / shift, running statistics) -- the "sum partials" / "finalize"
-// launches of rounds 1-2 folded into the reduction (threadfence-reduction: release fence, ticket, acquire fence).
+// What follows a statistics kernel once every workgroup has written its partial row (fp64 [2C]) to the workspace: sum the rows of
+// each column in a fixed order (deterministic), store sums[0..2C) (+ the row count) and, for the forward pass, finalize the layer
+// (mean / invstd / scale / shift, running statistics).
 struct BnFin {
     double* sums;            // [2C+1]
     double rows;             // row count of this rank
@@ -64,24 +63,10 @@ __device__ __forceinline__ void bn_finish_body(const double* partial, int nblk, 
     }
 }
 
-// ticket != nullptr: threadfence reduction -- the last workgroup to arrive runs bn_finish_body (one launch instead of two).
-// Measured on MI355X (round 3, visit B): with a full fence in every workgroup the statistics kernels became 3-6x SLOWER (an
-// agent-scope acquire invalidates the XCD's L2 under the workgroups still streaming x), hence release-only on the way in,
-// acquire only in the last workgroup, and the two-launch form (ticket == nullptr + bn_sum_k) as the default until measured again.
-__device__ __forceinline__ void bn_finish(const double* partial, int nblk, int C, const BnFin& f, int* ticket) {
-    if (!ticket) return;                               // kernel-uniform
-    __shared__ int is_last;
-    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the wave that wrote this workgroup's partial row
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == nblk - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    bn_finish_body(partial, nblk, C, f, threadIdx.x >> 6, blockDim.x >> 6, true);
-    if (threadIdx.x == 0) *ticket = 0;                 // ready for the next launch on this stream
-}
-
-// second launch of the two-launch form: 4 channels per workgroup
+// Second launch of a statistics pass: sums the per-workgroup partial rows in a fixed order (deterministic) and, for the forward pass,
+// finalizes the layer; 4 channels per workgroup.  (Round 3 also tried folding this into the statistics kernel with a threadfence
+// reduction -- the last workgroup to arrive sums: one launch less per pass, but the agent-scope fences made the statistics kernels
+// 3-6x slower on the 8-XCD part, with full or with release- / acquire-only fences)
 __global__ __launch_bounds__(256) void bn_sum_k(const double* __restrict__ partial, int nblk, int C, BnFin f) {
     bn_finish_body(partial, nblk, C, f, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, blockIdx.x == 0);
 }
@@ -91,7 +76,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                   int64_t n, int C, double* sums /* partials [gridDim.x][2C] */, BnFin fin, int* ticket) {
+                                                   int64_t n, int C, double* sums /* partials [gridDim.x][2C] */) {
     __shared__ double sh[256 * 8];
     const int lpr = C >> 2;
     const int rpb = 256 / lpr;
@@ -160,13 +145,12 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
             out[C + tid * 4 + j] = tb[j];
         }
     }
-    bn_finish(sums, gridDim.x, C, fin, ticket);
 }
 
 // Statistics of a convolution output from the per-tile partial sums its epilogue wrote (spconv_gmm_k: float [n_tiles][2][C] =
 // sum x | sum x^2 over the <= 64 rows of a tile): no pass over x at all.  Workgroup b adds the tiles b, b + G, b + 2G, ... in
-// fp64; the last workgroup finishes as above.
-__global__ __launch_bounds__(256) void bn_partials_k(const float* __restrict__ partial, int64_t n_tiles, int C, double* ws, BnFin fin, int* ticket) {
+// fp64; bn_sum_k finishes.
+__global__ __launch_bounds__(256) void bn_partials_k(const float* __restrict__ partial, int64_t n_tiles, int C, double* ws) {
     __shared__ double sh[256];
     const int C2 = 2 * C, tid = threadIdx.x;
     double* out = ws + (int64_t)blockIdx.x * C2;
@@ -192,8 +176,6 @@ __global__ __launch_bounds__(256) void bn_partials_k(const float* __restrict__ p
         }
         __syncthreads();
     }
-    if (ticket) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // up to 256 threads wrote the row
-    bn_finish(ws, gridDim.x, C, fin, ticket);
 }
 
 
@@ -306,13 +288,7 @@ static int bn_partials_grid(int64_t n_tiles, int C) {
 
 int64_t u3d_bn_ws_bytes(int C) { return (int64_t)256 * 2 * C * sizeof(double) + 64; }
 
-// U3D_BN_FINISH=ticket: one launch (threadfence reduction); default: statistics kernel + bn_sum_k
-static bool bn_ticket_mode() {
-    static const bool on = [] { const char* e = getenv("U3D_BN_FINISH"); return e && e[0] == 't'; }();
-    return on;
-}
 static int bn_finish_launch(const void* ws, int nblk, int C, const BnFin& f, hipStream_t s) {
-    if (bn_ticket_mode()) return U3D_OK;
     hipLaunchKernelGGL(bn_sum_k, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)ws, nblk, C, f);
     return check_launch("bn_sum");
 }
@@ -325,26 +301,24 @@ static BnFin bn_fin(double* sums, double rows, int set_rows) {
 }
 
 // statistics of x [n][C] (pass over x), or -- partial != NULL -- from the per-tile sums a convolution epilogue wrote
-static int bn_stats_launch(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const BnFin& f, void* ws, int32_t* ticket,
-                           hipStream_t s) {
+static int bn_stats_launch(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const BnFin& f, void* ws, hipStream_t s) {
     if (partial) {
         if (n_tiles <= 0) return U3D_EINVAL;
         ProfScope prof(U3D_K_BN, s, (double)n_tiles * C * 8);
         const int g = bn_partials_grid(n_tiles, C);
-        hipLaunchKernelGGL(bn_partials_k, dim3(g), dim3(256), 0, s, partial, n_tiles, C, (double*)ws, f, bn_ticket_mode() ? (int*)ticket : (int*)nullptr);
+        hipLaunchKernelGGL(bn_partials_k, dim3(g), dim3(256), 0, s, partial, n_tiles, C, (double*)ws);
         return bn_finish_launch(ws, g, C, f, s);
     }
     ProfScope prof(U3D_K_BN, s, (double)n * C * 4);
     const int g = bn_grid(n, C);
     hipLaunchKernelGGL(bn_reduce_k<0>, dim3(g), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws, f, bn_ticket_mode() ? (int*)ticket : (int*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, n, C, (double*)ws);
     return bn_finish_launch(ws, g, C, f, s);
 }
 
-int u3d_bn_stats(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, double* sums, void* ws, int32_t* ticket,
-                 u3d_stream_t stream) {
-    if ((!x && !partial) || !sums || !ws || !ticket || !bn_ok(n, C)) return U3D_EINVAL;
-    return bn_stats_launch(x, n, C, partial, n_tiles, bn_fin(sums, (double)n, 1), ws, ticket, (hipStream_t)stream);
+int u3d_bn_stats(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, double* sums, void* ws, u3d_stream_t stream) {
+    if ((!x && !partial) || !sums || !ws || !bn_ok(n, C)) return U3D_EINVAL;
+    return bn_stats_launch(x, n, C, partial, n_tiles, bn_fin(sums, (double)n, 1), ws, (hipStream_t)stream);
 }
 
 int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
@@ -367,14 +341,13 @@ int u3d_bn_apply(const float* x, const float* scale, const float* shift, int rel
 }
 
 int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
-                     const float* shift, int relu, int64_t n, int C, double* sums, void* ws, int32_t* ticket, u3d_stream_t stream) {
-    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !ws || !ticket || !bn_ok(n, C)) return U3D_EINVAL;
+                     const float* shift, int relu, int64_t n, int C, double* sums, void* ws, u3d_stream_t stream) {
+    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !ws || !bn_ok(n, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
     const int g = bn_grid(n, C);
     const BnFin f = bn_fin(sums, 0.0, 0);
-    hipLaunchKernelGGL(bn_reduce_k<1>, dim3(g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws,
-                       f, bn_ticket_mode() ? (int*)ticket : (int*)nullptr);
+    hipLaunchKernelGGL(bn_reduce_k<1>, dim3(g), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, n, C, (double*)ws);
     return bn_finish_launch(ws, g, C, f, s);
 }
 
@@ -392,22 +365,22 @@ int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const f
 
 int u3d_bn_forward(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st,
-                   double* sums, void* ws, int32_t* ticket, u3d_stream_t stream) {
-    // ONE statistics launch (per-workgroup partials; the last workgroup sums them and finalizes the layer) -> apply
-    if (!x || !sums || !ws || !ticket || !gamma || !beta || !st || !y || !bn_ok(n, C)) return U3D_EINVAL;
+                   double* sums, void* ws, u3d_stream_t stream) {
+    // statistics (per-workgroup partial rows) -> bn_sum_k (sums them and finalizes the layer) -> apply
+    if (!x || !sums || !ws || !gamma || !beta || !st || !y || !bn_ok(n, C)) return U3D_EINVAL;
     BnFin f = bn_fin(sums, (double)n, 1);
     f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum; f.running_mean = running_mean; f.running_var = running_var;
     f.st = st; f.nbt = num_batches_tracked;
-    int rc = bn_stats_launch(x, n, C, partial, n_tiles, f, ws, ticket, (hipStream_t)stream);
+    int rc = bn_stats_launch(x, n, C, partial, n_tiles, f, ws, (hipStream_t)stream);
     if (rc) return rc;
     return u3d_bn_apply(x, st + 2 * C, st + 3 * C, relu, n, C, y, stream);
 }
 
 int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n, int C,
-                    float* dx, float* dgamma, float* dbeta, const float* addend, void* ws, int32_t* ticket, u3d_stream_t stream) {
+                    float* dx, float* dgamma, float* dbeta, const float* addend, void* ws, u3d_stream_t stream) {
     // sums[0..2C) are overwritten; sums[2C] (the row count) is taken from the forward pass's vector
     if (!fwd_sums) return U3D_EINVAL;
-    int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, ticket, stream);
+    int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, stream);
     if (rc) return rc;
     if (!dx) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;       // the row count is read from the forward pass's vector (no copy launch)

@@ -437,7 +437,7 @@ class _BNReLUFn(torch.autograd.Function):
             sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)   # [sum x, sum x^2, rows]
             if sync_on:
                 if n:
-                    L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(part), n_tiles, L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
+                    L.call('u3d_bn_stats', L.ptr(x), n, C, L.ptr(part), n_tiles, L.ptr(sums), L.ptr(ws), L.stream())
                 else:
                     sums.zero_()
                 allreduce_bn_sums(sums)          # rows ride along: no host read-back on the critical path
@@ -448,7 +448,7 @@ class _BNReLUFn(torch.autograd.Function):
                     L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
             else:                                # one call: stats -> finalize -> apply
                 L.call('u3d_bn_forward', L.ptr(x), n, C, L.ptr(part), n_tiles, L.ptr(gamma), L.ptr(beta), eps, momentum, L.ptr(running_mean),
-                       L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
+                       L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
         else:
             st[0] = running_mean
             st[1] = torch.rsqrt(running_var + eps)
@@ -488,7 +488,7 @@ class _BNReLUFn(torch.autograd.Function):
             if ctx.sync and _dist_on():
                 sums[2 * C:] = fsums[2 * C:]         # global row count of the forward pass
                 L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                       int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
+                       int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
                 dgb[1] = sums[:C].to(torch.float32)
                 dgb[0] = sums[C:2 * C].to(torch.float32)
                 dist.all_reduce(sums[:2 * C], op=dist.ReduceOp.SUM)
@@ -496,10 +496,10 @@ class _BNReLUFn(torch.autograd.Function):
                        int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.ptr(dskip), L.stream())
             else:                                    # one call: bwd_stats -> bwd_apply (+ dgamma / dbeta)
                 L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(fsums), L.ptr(sums), n, C, L.ptr(dx),
-                       L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(dskip), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
+                       L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(dskip), L.ptr(ws), L.stream())
         else:                                        # eval: statistics are constants -> dx = scale * dy'
             L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                   int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.ptr(L.ticket(dev)), L.stream())
+                   int(ctx.relu), n, C, L.ptr(sums), L.ptr(ws), L.stream())
             dgb[1] = sums[:C].to(torch.float32)
             dgb[0] = sums[C:2 * C].to(torch.float32)
             sums.zero_()

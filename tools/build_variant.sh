@@ -1,12 +1,16 @@
 #!/bin/bash
 # Build a variant of the kernel library for A/B runs (U3D_LIB_PATH=<out> python bench.py ...):
-#   tools/build_variant.sh <out.so> <file.hip> <extra hipcc flags...>      e.g.  tools/build_variant.sh tools/bin/libu3d_ald40.so spconv.hip -DU3D_GMM_ALD40
-# The named source is recompiled with the extra flags, every other object comes from the in-tree build.
+#   tools/build_variant.sh <out.so> <file.hip[,file2.hip...]> <extra hipcc flags...>
+#   e.g.  tools/build_variant.sh tools/bin/libu3d_ald40.so spconv.hip -DU3D_GMM_ALD40
+# The named sources are recompiled with the extra flags, every other object comes from the in-tree build.
 set -e
-R=$(cd "$(dirname "$0")/.." && pwd); OUT=$1; SRC=$2; shift 2
+R=$(cd "$(dirname "$0")/.." && pwd); OUT=$1; SRCS=${2//,/ }; shift 2
 C=$R/unidet3d_amd/csrc; TMP=$(mktemp -d)
-EXTRA=""; [ "$SRC" = "spconv.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; [ "$SRC" = "postproc.hip" ] && EXTRA="-ffp-contract=off"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -I $R/include -I $C $EXTRA "$@" -c $C/$SRC -o $TMP/v.o
-OBJS=""; for f in $C/*.o; do [ "$(basename $f)" = "${SRC%.hip}.o" ] && OBJS="$OBJS $TMP/v.o" || OBJS="$OBJS $f"; done
+for SRC in $SRCS; do
+    EXTRA=""; [ "$SRC" = "spconv.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; [ "$SRC" = "postproc.hip" ] && EXTRA="-ffp-contract=off"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -I $R/include -I $C $EXTRA "$@" -c $C/$SRC -o $TMP/${SRC%.hip}.o &
+done
+wait
+OBJS=""; for f in $C/*.o; do b=$(basename $f); [ -f $TMP/$b ] && OBJS="$OBJS $TMP/$b" || OBJS="$OBJS $f"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
 rm -rf $TMP; ls -la $OUT

@@ -35,6 +35,13 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 int u3d_version(void);
 const char* u3d_last_error(void);
+/* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
+ *   1 (default; env U3D_FP32_MATH=bf16x3): each fp32 operand is split exactly into three bf16 pieces and a product is six
+ *     bf16 MFMAs with fp32 accumulation -- fp32-level error (the dropped terms are below 2^-23 of a product), 2.7x less matrix
+ *     pipe time than
+ *   0 (env U3D_FP32_MATH=mfma): the native v_mfma_f32_* instructions.
+ * Returns the previous mode; any other argument only queries.  Process-wide, not thread-safe against running launches. */
+int u3d_fp32_math(int mode);
 
 /* ---- kernel timing (HIP events on the launch stream; used by bench.py's roofline) ---- */
 enum { U3D_K_CONV_FWD = 0, U3D_K_CONV_WGRAD = 1, U3D_K_BN = 2, U3D_K_POOL = 3, U3D_K_ATTN_FWD = 4,

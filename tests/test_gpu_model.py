@@ -170,6 +170,34 @@ def test_dense_linear_fwd_bwd(M, K, N):
     assert _rel(wg.grad, wo.grad) < 2e-5 and _rel(bg.grad, bo.grad) < 1e-5
 
 
+@pytest.mark.parametrize('M,K,N', [(16001, 256, 1024), (4097, 1024, 256), (2500, 256, 19), (130, 32, 256)])
+def test_dense_linear_bf16x3_is_as_accurate_as_the_native_fp32_mfma(M, K, N):
+    """The default fp32 path forms products from three exact bf16 pieces per operand on the bf16 matrix pipe
+    (csrc/u3d_common.h "bf16x3"; precision.fp32_math).  Its error against float64 must stay at the level of the native
+    v_mfma_f32 kernels (same fp32 accumulation; the dropped cross terms are below 2^-23 of a product) -- forward, input gradient,
+    weight gradient -- on inputs with a wide dynamic range (|x| over six decades) so that a plane with too few bits would show."""
+    import _parity as PA
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.dense import linear
+    g = torch.Generator().manual_seed(M + N + 5)
+    x = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 2.0)
+    w = torch.randn(N, K, generator=g) * 0.1 * torch.exp(torch.randn(N, K, generator=g))
+    b = torch.randn(N, generator=g); go = torch.randn(M, N, generator=g) * torch.exp(torch.randn(M, N, generator=g))
+    xo, wo, bo = [t.clone().double().requires_grad_() for t in (x, w, b)]
+    yo = torch.nn.functional.linear(xo, wo, bo); yo.backward(go.double())
+    err = {}
+    for mode in ('mfma', 'bf16x3'):
+        xg, wg, bg = [t.clone().to(DEV).requires_grad_() for t in (x, w, b)]
+        with P.fp32_math(mode):
+            assert P.get_fp32_math() == mode
+            yg = linear(xg, wg, bg); yg.backward(go.to(DEV))
+        err[mode] = [_rel(yg, yo), _rel(xg.grad, xo.grad), _rel(wg.grad, wo.grad), _rel(bg.grad, bo.grad)]
+    PA.log_errors(f'linear_fp32_math_{M}x{K}x{N}', err)
+    print('linear fp32 math errors (y, dx, dw, db) vs float64:', err)
+    for e3, e1 in zip(err['bf16x3'], err['mfma']):
+        assert e3 < max(1.5 * e1, 2e-6), err
+
+
 # ---------------------------------------------------------------------------- fused MLP (u3d_ffn_fwd / u3d_linear_dact)
 @pytest.mark.parametrize('M,d_in,hid,d_out,act', [(16001, 256, 1024, 256, 'gelu'), (4097, 32, 256, 256, 'relu'), (2500, 256, 256, 19, 'relu'),
                                                     (333, 256, 1024, 256, 'relu'), (1, 256, 256, 8, 'gelu'), (0, 32, 256, 256, 'relu')])

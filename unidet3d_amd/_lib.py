@@ -20,6 +20,7 @@ _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_dou
 PROTOTYPES = {
     'u3d_version': (_i32, []),
     'u3d_last_error': (C.c_char_p, []),
+    'u3d_fp32_math': (_i32, [_i32]),
     'u3d_prof_enable': (_i32, [_i32, _i32]),
     'u3d_prof_collect': (_i32, [_i32, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64)]),
     'u3d_vox_scene_stats': (_i32, [_vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp, _vp, _vp]),

@@ -252,6 +252,119 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
     nt_epilogue<TN, EPI, TM>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
 }
 
+// gemm_nt_k with the fp32 products on the bf16 pipe (u3d_common.h, "bf16x3"): the staged fp32 rows are split into three exact
+// bf16 planes, a tile pair takes the six MFMAs h.h, h.m, m.h, h.l, m.m, l.h (smallest terms first) -- 6 x 32 cycles for a
+// 32 x 32 x 16 block instead of the 8 x 64 cycles of v_mfma_f32_32x32x2_f32.  With the matrix time cut to 3/8 the kernel must
+// not be latency bound, so the loop is built differently from gemm_nt_k:
+//   * ONE LDS stage (3 planes x (TM + TN) rows x 80 B = 60 KB at 128 x 128) instead of two, so two workgroups share a CU and
+//     one computes while the other stages (their barriers are independent);
+//   * the raw fp32 rows of stage kt+1 wait in registers while stage kt is multiplied, are split AFTER the MFMAs were issued
+//     (VALU work under the matrix pipe, this wave's own and the partner workgroup's), and the loads of stage kt+2 are issued
+//     before the barrier: every global load has a full stage of matrix work to land.
+#ifndef U3D_NTX_ABL
+#define U3D_NTX_ABL 0          // timing ablations (wrong results): 1 no MFMAs, 2 no split arithmetic, 4 no global loads in the loop, 8 no LDS stores in the loop
+#endif
+template <int TN, int EPI, int TM = GT>
+__global__ __launch_bounds__(256) void gemm_nt_x3_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                    float* __restrict__ C, int64_t M, int N, int K, const float* __restrict__ aux,
+                                                    float* __restrict__ pre) {
+    constexpr int NB = TN / 64, TA = TM / 64;
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][TM * GLH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3][TN * GLH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
+    const int nt_ = (N + TN - 1) / TN;                       // XCD-aware 1-D grid, see gemm_nt_k
+    const int64_t wid_ = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t m0 = (wid_ / nt_) * TM;
+    const int n0 = (int)(wid_ % nt_) * TN;
+    const int rows_a = (int)min((int64_t)TM, M - m0), rows_b = min(TN, N - n0);
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + m0 * K, (int64_t)rows_a * K * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(W + (int64_t)n0 * K, (int64_t)rows_b * K * 4);
+    // staging map: thread -> (row = tid>>2 (+64 j), 8 floats at column 8 * (tid&3))
+    const int srow = tid >> 2, sc8 = tid & 3;
+    const int vo = (srow * K + sc8 * 8) * 4, vstep = 64 * K * 4;
+    f32x4 ra[TA][2], rb[NB][2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < TA; ++j) {
+            ra[j][0] = bload128(rs_a, vo + j * vstep, kt * (GKH * 4));
+            ra[j][1] = bload128(rs_a, vo + j * vstep + 16, kt * (GKH * 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            rb[j][0] = bload128(rs_b, vo + j * vstep, kt * (GKH * 4));
+            rb[j][1] = bload128(rs_b, vo + j * vstep + 16, kt * (GKH * 4));
+        }
+    };
+    bf16x8 pa[TA][3], pb[NB][3];
+    auto split = [&]() {
+        if constexpr (U3D_NTX_ABL & 2) {
+#pragma unroll
+            for (int j = 0; j < TA; ++j) { pa[j][0] = __builtin_bit_cast(bf16x8, ra[j][0]); pa[j][1] = __builtin_bit_cast(bf16x8, ra[j][1]); pa[j][2] = pa[j][0]; }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { pb[j][0] = __builtin_bit_cast(bf16x8, rb[j][0]); pb[j][1] = __builtin_bit_cast(bf16x8, rb[j][1]); pb[j][2] = pb[j][0]; }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < TA; ++j) split3_x8(ra[j][0], ra[j][1], pa[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) split3_x8(rb[j][0], rb[j][1], pb[j]);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int j = 0; j < TA; ++j) *reinterpret_cast<bf16x8*>(&As[q][(srow + 64 * j) * GLH + sc8 * 8]) = pa[j][q];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) *reinterpret_cast<bf16x8*>(&Bs[q][(srow + 64 * j) * GLH + sc8 * 8]) = pb[j][q];
+        }
+    };
+    f32x16 acc[TA][NB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nk = K / GKH;
+    gload(0);
+    split();
+    if (nk > 1) gload(1);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 af[3][TA], bf[3][NB];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t) af[q][t] = *reinterpret_cast<const bf16x8*>(&As[q][(wr * (TM / 2) + t * 32 + i32) * GLH + h * 16 + kh * 8]);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) bf[q][t] = *reinterpret_cast<const bf16x8*>(&Bs[q][(wc * (TN / 2) + t * 32 + i32) * GLH + h * 16 + kh * 8]);
+            }
+#pragma unroll
+            for (int o = 2; o >= 0; --o)           // plane-order sum qa + qb = o: smallest terms first
+#pragma unroll
+                for (int qa = 0; qa <= o; ++qa)
+#pragma unroll
+                    for (int a = 0; a < TA; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            if constexpr (U3D_NTX_ABL & 1) { if (o == 2 && qa == 0) acc[a][b][0] += (float)af[0][a][0] + (float)af[1][a][1] + (float)af[2][a][2] + (float)bf[0][b][0] + (float)bf[1][b][1] + (float)bf[2][b][2]; }
+                            else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], acc[a][b], 0, 0, 0);
+                        }
+        }
+        if (kt + 1 < nk) split();                  // stage kt+1 (loaded one iteration ago)
+        if (kt + 2 < nk && !(U3D_NTX_ABL & 4)) gload(kt + 2);
+        __syncthreads();                           // every wave has read stage kt
+        if (kt + 1 < nk && !(U3D_NTX_ABL & 8)) lstore();
+        __syncthreads();
+    }
+    nt_epilogue<TN, EPI, TM>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
+}
+
 // partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k].  T = 128 or 64 output rows AND columns per workgroup:
 // the weight gradients of this decoder are small (256 x 256, 768 x 256, 256 x 32, 19 x 256 ...) -- with 128 x 128 tiles a
 // 256 x 256 output has 4 tiles and needs ~96 row splits to fill 256 CUs, i.e. 25 MB of partials written and read back for 0.26 MB
@@ -361,6 +474,133 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
             }
     }
     if (sums && n0 + tid < N) partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = csum;
+}
+
+// gemm_tn_k with the fp32 products on the bf16 pipe (u3d_common.h, "bf16x3").  The reduction index is the ROW index of both
+// operands, and an MFMA lane wants 8 consecutive reduction elements in one register vector: the staging thread therefore loads
+// the same four columns of TWO consecutive rows and split3_pair() packs them into one dword per plane (low half: even row), so
+// the LDS tile is [row pair][column] dwords per plane and a fragment is four ds_read_b32 (conflict free: LD = T + 8 puts the two
+// half-waves, 4 row pairs apart, on disjoint banks).  Grid, split placement, partial layout and column sums as in gemm_tn_k.
+template <int T>
+__global__ __launch_bounds__(256) void gemm_tn_x3_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
+                                                    int colsum, int64_t M, int N, int K, int64_t rows_per_split, int S) {
+    const int tiles_n = (N + T - 1) / T, tiles = tiles_n * ((K + T - 1) / T);
+    const int slot = blockIdx.x >> 3, tile = slot % tiles;
+    const int split = (slot / tiles) * 8 + (blockIdx.x & 7);
+    if (split >= S) return;
+    constexpr int LD = T + 8;                   // dwords per row pair
+    constexpr int NF = T / 64;
+    constexpr int TPR = T / 4;                  // staging threads per row pair (float4 of each of its rows)
+    constexpr int RP = 256 / TPR;               // row pairs per stage: 8 (T = 128) / 16 (T = 64)
+    constexpr int KB = RP / 8;                  // 16-deep MFMA blocks per stage
+    constexpr int ROWS = RP * 2;
+    __shared__ __attribute__((aligned(16))) unsigned As[2][3][RP * LD];
+    __shared__ __attribute__((aligned(16))) unsigned Bs[2][3][RP * LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
+    const int n0 = (tile % tiles_n) * T, k0 = (tile / tiles_n) * T;
+    const int64_t mlo = (int64_t)split * rows_per_split;
+    const int64_t mhi = min(M, mlo + rows_per_split);
+    const int rows = (int)max((int64_t)0, mhi - mlo);
+    const int sp = tid / TPR, sc4 = tid % TPR;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + mlo * N, (int64_t)rows * N * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + mlo * K, (int64_t)rows * K * 4);
+    const int va = n0 + sc4 * 4 < N ? (2 * sp * N + n0 + sc4 * 4) * 4 : 0x7fffffff;
+    const int vb = k0 + sc4 * 4 < K ? (2 * sp * K + k0 + sc4 * 4) * 4 : 0x7fffffff;
+    const bool ca = va != 0x7fffffff, cb = vb != 0x7fffffff;
+    f32x4 ra[2], rb[2];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ra[j] = bload128(rs_a, ca ? va + j * N * 4 : va, t * (ROWS * N * 4));
+            rb[j] = bload128(rs_b, cb ? vb + j * K * 4 : vb, t * (ROWS * K * 4));
+        }
+    };
+    auto lstore = [&](int buf) {
+        cs += ra[0] + ra[1];
+        unsigned w[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split3_pair(ra[0][c], ra[1][c], w[0][c], w[1][c], w[2][c]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&As[buf][q][sp * LD + sc4 * 4]) = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split3_pair(rb[0][c], rb[1][c], w[0][c], w[1][c], w[2][c]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&Bs[buf][q][sp * LD + sc4 * 4]) = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+    };
+    auto frag = [&](const unsigned* t, int pair0, int col) {
+        const unsigned* q = t + pair0 * LD + col;
+        return __builtin_bit_cast(bf16x8, u32x4{q[0], q[LD], q[2 * LD], q[3 * LD]});
+    };
+    f32x16 acc[NF][NF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < NF; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nt = (rows + ROWS - 1) / ROWS;
+    if (nt > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            bf16x8 af[3][NF], bf[3][NF];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    af[q][u] = frag(As[buf][q], kb * 8 + kh * 4, wr * (T / 2) + u * 32 + i32);
+                    bf[q][u] = frag(Bs[buf][q], kb * 8 + kh * 4, wc * (T / 2) + u * 32 + i32);
+                }
+#pragma unroll
+            for (int o = 2; o >= 0; --o)
+#pragma unroll
+                for (int qa = 0; qa <= o; ++qa)
+#pragma unroll
+                    for (int a = 0; a < NF; ++a)
+#pragma unroll
+                        for (int b = 0; b < NF; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], acc[a][b], 0, 0, 0);
+        }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)split * pstride, (int64_t)N * K * 4);
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+        const int k = k0 + wc * (T / 2) + b * 32 + i32;
+        const int vo = k < K ? ((n0 + 4 * kh) * K + k) * 4 : 0x7fffffff;        // rows past N fall off the end of the descriptor
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * (T / 2) + a * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[a][b][r];
+                asm volatile("" : "+v"(v));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, row * K * 4, 0);
+            }
+    }
+    if (colsum && k0 == 0) {                    // column sums of A (the bias gradient): the staging threads' fp32 sums, added over the row pairs
+        float* cs_s = reinterpret_cast<float*>(&As[0][0][0]);          // [RP][T] floats fit in the first plane buffer (LD > T)
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&cs_s[sp * LD + sc4 * 4]) = cs;
+        __syncthreads();
+        if (tid < T && n0 + tid < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < RP; ++r) v += cs_s[r * LD + tid];
+            partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = v;
+        }
+    }
 }
 
 // bf16-operand form of gemm_tn_k (weight gradients of the Linear layers under BASELINE configs[2]): A (= dY) and B (= X) are
@@ -548,7 +788,7 @@ static int tn_splits(int64_t M, int N, int K, int T, bool bf) {
 // GEMMs 6.71 ms with 128x64 everywhere, 6.37 ms with 64x64 everywhere -> the overhead of the small tile is small: 4 % / 8 %.
 template <int EPI>
 static void launch_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, const float* aux, float* pre,
-                      bool bf16_operands, hipStream_t s) {
+                      bool bf16_operands, bool x3, hipStream_t s) {
     static const int force = [] { const char* e = getenv("U3D_NT_TILE"); return e ? atoi(e) : 0; }();       // 1 / 2 / 3 = 128x128 / 128x64 / 64x64
     const int tm[3] = {128, 128, 64}, tn[3] = {128, 64, 64};
     const double over[3] = {1.0, 1.04, 1.08};
@@ -565,7 +805,7 @@ static void launch_nt(const float* A, const float* W, const float* bias, float* 
     if (best == 0) hipLaunchKernelGGL((KERNEL<128, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);                \
     else if (best == 1) hipLaunchKernelGGL((KERNEL<64, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);            \
     else hipLaunchKernelGGL((KERNEL<64, EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
-    if (bf16_operands) { U3D_NT_LAUNCH(gemm_nt_bf16_k) } else { U3D_NT_LAUNCH(gemm_nt_k) }
+    if (bf16_operands) { U3D_NT_LAUNCH(gemm_nt_bf16_k) } else if (x3) { U3D_NT_LAUNCH(gemm_nt_x3_k) } else { U3D_NT_LAUNCH(gemm_nt_k) }
 #undef U3D_NT_LAUNCH
 }
 
@@ -575,16 +815,17 @@ static int gemm_nt_epi(const float* A, const float* W, const float* bias, float*
     const bool bf = (epi & 8) != 0;
     epi &= 7;
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 5 || (epi == 2 && !pre) || (epi >= 3 && !aux)) return U3D_EINVAL;
+    const bool x3 = !bf && fp32_x3() && K % GKH == 0;        // K = 16 (mod 32) keeps the native fp32 kernel
     if (K % (bf ? GKH : GK)) { set_error("gemm_nt: K=%d must be a multiple of %d", K, bf ? GKH : GK); return U3D_EUNSUPPORTED; }
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
     if ((int64_t)GT * K * 4 >= 0x7fffffffLL || (int64_t)GT * N * 4 >= 0x7fffffffLL) { set_error("gemm_nt: N=%d / K=%d too large for 32-bit tile offsets", N, K); return U3D_EUNSUPPORTED; }
     switch (epi) {
-        case 0: launch_nt<0>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
-        case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
-        case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
-        case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
-        case 4: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
-        default: launch_nt<5>(A, W, bias, C, M, N, K, aux, pre, bf, s); break;
+        case 0: launch_nt<0>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
+        case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
+        case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
+        case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
+        case 4: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
+        default: launch_nt<5>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
     }
     return check_launch("gemm_nt");
 }
@@ -659,7 +900,7 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
     const int S = tn_splits(M, N, K, bf ? GT : tn_tile(N, K), bf);
     const int64_t rps = ceil_div(ceil_div(M, S), GK) * GK;
-    if ((int64_t)(rps + GK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + GK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
+    if ((int64_t)(rps + 2 * GK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + 2 * GK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
         set_error("gemm_tn: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
         return U3D_EUNSUPPORTED;
     }
@@ -667,7 +908,10 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     else {
         const int T = tn_tile(N, K);
         const unsigned grid = (unsigned)(ceil_div(S, 8) * 8 * ceil_div(N, T) * ceil_div(K, T));       // whole groups of 8 splits
-        if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+        if (fp32_x3()) {
+            if (T == 64) hipLaunchKernelGGL(gemm_tn_x3_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+            else hipLaunchKernelGGL(gemm_tn_x3_k<GT>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+        } else if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
         else hipLaunchKernelGGL(gemm_tn_k<GT>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
     }
     const int64_t n4_main = (int64_t)N * K / 4, n4 = n4_main + (colsum_A ? N / 4 : 0);

@@ -11,6 +11,15 @@ namespace u3d {
 
 static thread_local char g_err[512] = "";
 
+int g_fp32_math = -1;
+bool fp32_x3() {
+    if (g_fp32_math < 0) {
+        const char* e = getenv("U3D_FP32_MATH");
+        g_fp32_math = (e && !strcmp(e, "mfma")) ? 0 : 1;
+    }
+    return g_fp32_math == 1;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -159,6 +168,11 @@ int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hip
 extern "C" {
 
 int u3d_version(void) { return 100; }
+int u3d_fp32_math(int mode) {
+    const int prev = u3d::fp32_x3() ? 1 : 0;
+    if (mode == 0 || mode == 1) u3d::g_fp32_math = mode;
+    return prev;
+}
 const char* u3d_last_error(void) { return u3d::g_err; }
 
 int u3d_prof_enable(int c, int on) {

@@ -57,6 +57,44 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64
 }
 #endif
 
+// ---- fp32 products on the bf16 matrix pipe ("bf16x3") -------------------------------------------------------------------
+// The fp32 MFMAs of gfx950 run at the fp32 VALU rate (157 TFLOP/s, 32 MAC / cycle / SIMD); the bf16 ones at 16x that.  An fp32
+// value splits EXACTLY into three bf16 pieces x = h + m + l (8 significant bits each: h = x truncated to its top 16 bits,
+// m = (x - h) truncated, l = x - h - m; every subtraction is exact), and a product becomes
+//     x y = hx hy + (hx my + mx hy) + (hx ly + mx my + lx hy) + [terms below 2^-23 |x y|, dropped]:
+// six bf16 MFMAs (products of 8-bit significands are exact in the fp32 accumulator) instead of sixteen MFMA-equivalents of fp32
+// issue time, with the error of an fp32 FMA chain (tests/test_gpu_kernels.py measures both against fp64).  U3D_FP32_MATH=mfma
+// selects the native fp32 MFMA kernels instead.
+extern int g_fp32_math;
+bool fp32_x3();
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+// two fp32 values -> one dword per plane (low half: a, high half: b)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned ab = __builtin_bit_cast(unsigned, a), bb = __builtin_bit_cast(unsigned, b);
+    const float a1 = a - __builtin_bit_cast(float, ab & 0xffff0000u), b1 = b - __builtin_bit_cast(float, bb & 0xffff0000u);
+    const unsigned a1b = __builtin_bit_cast(unsigned, a1), b1b = __builtin_bit_cast(unsigned, b1);
+    const float a2 = a1 - __builtin_bit_cast(float, a1b & 0xffff0000u), b2 = b1 - __builtin_bit_cast(float, b1b & 0xffff0000u);
+    h = __builtin_amdgcn_perm(bb, ab, 0x07060302u);
+    m = __builtin_amdgcn_perm(b1b, a1b, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b2), __builtin_bit_cast(unsigned, a2), 0x07060302u);
+}
+// eight fp32 values -> the three bf16x8 planes
+__device__ __forceinline__ void split3_x8(const f32x4& lo, const f32x4& hi, bf16x8_t (&out)[3]) {
+    unsigned w[3][4];
+    split3_pair(lo[0], lo[1], w[0][0], w[1][0], w[2][0]);
+    split3_pair(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);
+    split3_pair(hi[0], hi[1], w[0][2], w[1][2], w[2][2]);
+    split3_pair(hi[2], hi[3], w[0][3], w[1][3], w[2][3]);
+    u32x4 p[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q] = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = __builtin_bit_cast(bf16x8_t, p[q]);
+}
+#endif
+
 // exclusive scan of n int32 values produced by a functor; out has n+1 entries (out[n] = total)
 int exclusive_scan_popc64(const uint64_t* words, int64_t n, int32_t* out, void* ws, hipStream_t s);
 int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hipStream_t s);

@@ -1,6 +1,9 @@
 """MFMA operand precision of the hot path (BASELINE configs[1] vs configs[2]).
 
-``fp32`` (default): v_mfma_f32_*_f32 everywhere -- the reference's arithmetic without ``--amp``; the headline bench line.
+``fp32`` (default): fp32 operands and fp32-accurate products -- the reference's arithmetic without ``--amp``; the headline bench
+line.  HOW the fp32 products are formed is a second, library-wide switch (``fp32_math``): ``'bf16x3'`` (default) splits every
+operand exactly into three bf16 pieces and runs six bf16 MFMAs per product (error of an fp32 FMA chain, 2.7x less matrix-pipe
+time), ``'mfma'`` uses the native v_mfma_f32_*_f32 instructions (include/u3d.h: u3d_fp32_math; env U3D_FP32_MATH).
 ``bf16``: feature / weight / probability operands are rounded to bf16 (round to nearest even) inside the kernels, on their way
 into LDS or registers, and multiplied on v_mfma_f32_*_bf16; tensors stay fp32 in HBM, accumulators, batch-norm statistics,
 softmax statistics, LayerNorm, the loss and the optimizer stay fp32 -- the mixed-precision recipe of the reference's
@@ -39,3 +42,28 @@ def operands(mode: str):
         yield
     finally:
         set_operand_dtype(prev)
+
+
+_FP32_MATH = {'mfma': 0, 'bf16x3': 1}
+
+
+def get_fp32_math() -> str:
+    from . import _lib as L
+    return 'bf16x3' if L.lib().u3d_fp32_math(-1) == 1 else 'mfma'
+
+
+def set_fp32_math(mode: str) -> str:
+    """'bf16x3' | 'mfma' (see the module docstring); returns the previous mode.  Process-wide."""
+    from . import _lib as L
+    if mode not in _FP32_MATH:
+        raise ValueError("fp32 math must be 'bf16x3' or 'mfma'")
+    return 'bf16x3' if L.lib().u3d_fp32_math(_FP32_MATH[mode]) == 1 else 'mfma'
+
+
+@contextlib.contextmanager
+def fp32_math(mode: str):
+    prev = set_fp32_math(mode)
+    try:
+        yield
+    finally:
+        set_fp32_math(prev)

@@ -1,0 +1,409 @@
+// K13 (fp32 math on the bf16 matrix pipe, u3d_common.h "bf16x3"): the varlen flash attention of attn.hip with every fp32
+// operand split exactly into three bf16 planes and every product formed from six v_mfma_f32_16x16x32_bf16 -- the error of an
+// fp32 FMA chain at 6 x 16 instead of 8 x 32 matrix-pipe cycles per 16 x 16 x 32 block.  The default path of
+// u3d_attn_varlen_fwd / _bwd (reference: nn.MultiheadAttention inside unidet3d/encoder.py:19-21,55-61; oracle/model.py);
+// U3D_FP32_MATH=mfma selects the native fp32 MFMA kernels of attn.hip.
+//
+// Shapes as in attn_bf16.hip: lane (i = lane & 15, g = lane >> 4) holds the 8 reduction elements k = 8g .. 8g+7 of row i (A) /
+// column i (B); head_dim = 32 is one instruction's reduction depth.
+//   S^T (16 keys x 16 queries) = K_tile . Q^T       A = K rows, natural [key][dim] planes in LDS (one 16-byte read per plane),
+//                                                   B = own Q rows, split once into registers
+//   O (16 queries x 16 dims) += P . V               A = two C fragments (keys {4g..4g+3} of two 16-key tiles), split in registers,
+//                                                   B = V in the PAIR layout: the staging thread loads the same four dims of
+//       two consecutive keys and split3_pair() packs them into one dword per plane; the LDS tile is [dim][key-pair slot] dwords
+//       with the slots ordered so that the fragment k = 8g + e <-> key 32t + 16 (e >> 2) + 4g + (e & 3) is FOUR CONSECUTIVE
+//       dwords: one ds_read_b128 per plane (the bf16 kernel needs eight 2-byte reads; with three planes that would put the LDS
+//       pipe level with the matrix pipe).  Slots are XOR-swizzled by the dim group so that the dword stores of the staging
+//       threads (8 threads x the same slot) spread over the banks; 40-dword columns keep the 16-byte reads conflict-free.
+// The backward kernels use the same two layouts in both orientations; tiles that are read both ways are staged in both.
+#include "u3d_common.h"
+
+namespace u3d {
+
+typedef bf16x8_t bf16x8;
+
+constexpr float X_LOG2E = 1.44269504088896340736f, X_LN2 = 0.69314718055994530942f;
+constexpr int XLD = 40;                  // halves per row of a natural plane: 32 + 8 pad (80-byte rows: conflict-free 16-byte reads)
+constexpr int XPD = 40;                  // dwords per dim (column) of a pair plane: 32 key-pair slots + 8 pad
+constexpr int XN = 64 * XLD;             // halves per natural plane
+constexpr int XP = 32 * XPD;             // dwords per pair plane
+#define U3D_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// c += a . b with both operands in three planes takes h.l, m.m, l.h, h.m, m.h, h.h (smallest terms first);
+// two independent accumulators side by side (dependent MFMAs wait for their predecessor; alternating chains fills the gaps)
+__device__ __forceinline__ void mfma_x3_2a(const bf16x8 (&a0)[3], const bf16x8 (&a1)[3], const bf16x8 (&b)[3], f32x4& c0, f32x4& c1) {
+#pragma unroll
+    for (int o = 2; o >= 0; --o)
+#pragma unroll
+        for (int qa = 0; qa <= o; ++qa) {
+            c0 = U3D_MFMA_X(a0[qa], b[o - qa], c0);
+            c1 = U3D_MFMA_X(a1[qa], b[o - qa], c1);
+        }
+}
+__device__ __forceinline__ void mfma_x3_2b(const bf16x8 (&a)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], f32x4& c0, f32x4& c1) {
+#pragma unroll
+    for (int o = 2; o >= 0; --o)
+#pragma unroll
+        for (int qa = 0; qa <= o; ++qa) {
+            c0 = U3D_MFMA_X(a[qa], b0[o - qa], c0);
+            c1 = U3D_MFMA_X(a[qa], b1[o - qa], c1);
+        }
+}
+
+// Stage 64 rows x 32 floats of `base` (rows >= len are zero, values scaled before the split): thread (p = tid >> 3, c = tid & 7)
+// holds dims 4c .. 4c+3 of rows 2p and 2p+1.  NAT: natural planes nat[3][64][XLD] halves; PAIR: pair planes pr[3][32 dims][XPD]
+// dwords, row pair p = (t, half, g, w) bits 4 | 3 | 2-1 | 0 in slot 16 t + 4 g + 2 half + w, XORed with 4 * (dim >> 2).
+template <bool NAT, bool PAIR>
+__device__ __forceinline__ void stage_x3(const float* __restrict__ base, int ld, int row0, int len, float scale, __bf16* nat, unsigned* pr, int tid) {
+    const int p = tid >> 3, c = tid & 7;
+    const int r0 = row0 + 2 * p;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (r0 < len) a = *reinterpret_cast<const f32x4*>(base + (int64_t)r0 * ld + c * 4);
+    if (r0 + 1 < len) b = *reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + 1) * ld + c * 4);
+    a *= scale;
+    b *= scale;
+    if constexpr (PAIR) {
+        unsigned w[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_pair(a[j], b[j], w[0][j], w[1][j], w[2][j]);
+        const int slot = ((p & 16) | ((p & 6) << 1) | ((p & 8) >> 2) | (p & 1)) ^ (4 * c);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pr[q * XP + (4 * c + j) * XPD + slot] = w[q][j];
+    }
+    if constexpr (NAT) {
+        unsigned wa[3][2], wb[3][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            split3_pair(a[2 * j], a[2 * j + 1], wa[0][j], wa[1][j], wa[2][j]);
+            split3_pair(b[2 * j], b[2 * j + 1], wb[0][j], wb[1][j], wb[2][j]);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p) * XLD + c * 4) = make_uint2(wa[q][0], wa[q][1]);
+            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p + 1) * XLD + c * 4) = make_uint2(wb[q][0], wb[q][1]);
+        }
+    }
+}
+
+// own row -> B operand planes: 8 consecutive dims of row `ptr` (nullptr: zeros), scaled
+__device__ __forceinline__ void row_frag_x3(const float* ptr, float scale, bf16x8 (&out)[3]) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (ptr) { a = *reinterpret_cast<const f32x4*>(ptr); b = *reinterpret_cast<const f32x4*>(ptr + 4); }
+    a *= scale;
+    b *= scale;
+    split3_x8(a, b, out);
+}
+
+// A operand planes from two C fragments: k = 8g + e <-> row 16 (e >> 2) + 4g + (e & 3) of the 32-row block
+__device__ __forceinline__ void pair_frag_x3(const float (&lo)[4], const float (&hi)[4], bf16x8 (&out)[3]) {
+    split3_x8(f32x4{lo[0], lo[1], lo[2], lo[3]}, f32x4{hi[0], hi[1], hi[2], hi[3]}, out);
+}
+
+// natural planes: rows 16 kb + i, dims 8g .. 8g+7
+__device__ __forceinline__ void nat_frag_x3(const __bf16* nat, int kb, int i16, int g, bf16x8 (&out)[3]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = *reinterpret_cast<const bf16x8*>(nat + q * XN + (kb * 16 + i16) * XLD + g * 8);
+}
+
+// pair planes: column (dim) `col`, rows {4g..4g+3} and {16+4g..16+4g+3} of the 32-row block t: slots 16 t + 4 g .. + 3
+__device__ __forceinline__ void pair_col_frag_x3(const unsigned* pr, int t, int g, int col, bf16x8 (&out)[3]) {
+    const unsigned* s = pr + col * XPD + ((16 * t + 4 * g) ^ (4 * ((col >> 2) & 7)));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + q * XP));
+}
+
+struct AttnWorkX { int b, h, tile; };
+__device__ __forceinline__ AttnWorkX attn_decode_x(int H, int B, int n_tiles) {      // (scene, head) -> XCD, see attn.hip
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int hb = (j / n_tiles) * 8 + x;
+    AttnWorkX w;
+    w.tile = j % n_tiles;
+    w.h = hb % H;
+    w.b = hb / H;
+    return w;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale,
+                                                     float* __restrict__ out, float* __restrict__ lse, int64_t n_total, int B, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) __bf16 Kn[3 * XN];
+    __shared__ __attribute__((aligned(16))) unsigned Vp[3 * XP];
+    const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
+    const int b = wk_.b, h = wk_.h;
+    if (b >= B) return;
+    const int start = cu[b], len = cu[b + 1] - start;
+    const int q0 = wk_.tile * 64;
+    if (q0 >= len) return;
+    const int D = H * 32, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const float* base = qkv + (int64_t)start * ld + h * 32;
+    const int qrow = q0 + wave * 16 + i16;
+    bf16x8 qf[3];                                // scores in log2 units: q carries scale * log2(e)
+    row_frag_x3(qrow < len ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int ntiles = (len + 63) >> 6;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        stage_x3<true, false>(base + D, ld, kt * 64, len, 1.f, Kn, nullptr, tid);
+        stage_x3<false, true>(base + 2 * D, ld, kt * 64, len, 1.f, nullptr, Vp, tid);
+        __syncthreads();
+        float st[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; kb += 2) {
+            bf16x8 a0[3], a1[3];
+            nat_frag_x3(Kn, kb, i16, g, a0);
+            nat_frag_x3(Kn, kb + 1, i16, g, a1);
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            mfma_x3_2a(a0, a1, qf, s0, s1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kb][r] = s0[r]; st[kb + 1][r] = s1[r]; }
+        }
+        if (kt == ntiles - 1 && (len & 63)) {          // only the last tile can hold keys past the end (wave-uniform)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 64 + kb * 16 + g * 4 + r >= len) st[kb][r] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                st[kb][r] = p;
+                ps += p;
+            }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, g * 4 + r, 64);
+            o[0][r] *= ar;
+            o[1][r] *= ar;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 pa[3], v0[3], v1[3];
+            pair_frag_x3(st[2 * t], st[2 * t + 1], pa);
+            pair_col_frag_x3(Vp, t, g, i16, v0);
+            pair_col_frag_x3(Vp, t, g, 16 + i16, v1);
+            mfma_x3_2b(pa, v0, v1, o[0], o[1]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lr = __shfl(l, g * 4 + r, 64);
+        const int row = q0 + wave * 16 + g * 4 + r;
+        if (row < len) {
+            const float inv = 1.f / lr;
+            float* op = out + (int64_t)(start + row) * D + h * 32 + i16;
+            op[0] = o[0][r] * inv;
+            op[16] = o[1][r] * inv;
+        }
+    }
+    if (g == 0 && qrow < len) lse[(int64_t)h * n_total + start + qrow] = m * X_LN2 + __logf(l);      // natural-log units
+}
+
+__global__ __launch_bounds__(256) void attn_delta_x3_k(const float* __restrict__ o, const float* __restrict__ dout, int64_t n, int H, float* delta) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * H) return;
+    const int64_t i = idx / H;
+    const int h = (int)(idx % H);
+    const float4* a = reinterpret_cast<const float4*>(o + i * H * 32 + h * 32);
+    const float4* b = reinterpret_cast<const float4*>(dout + i * H * 32 + h * 32);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 x = a[j], y = b[j];
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    delta[(int64_t)h * n + i] = s;
+}
+
+// dQ: one workgroup per 64-query tile, keys streamed.  K is staged in both layouts (natural for S, pairs for dQ += dS . K).
+__global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                                                        const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
+                                                        float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) __bf16 Kn[3 * XN];
+    __shared__ __attribute__((aligned(16))) __bf16 Vn[3 * XN];
+    __shared__ __attribute__((aligned(16))) unsigned Kp[3 * XP];
+    const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
+    const int b = wk_.b, h = wk_.h;
+    if (b >= B) return;
+    const int start = cu[b], len = cu[b + 1] - start;
+    const int q0 = wk_.tile * 64;
+    if (q0 >= len) return;
+    const int D = H * 32, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const float* base = qkv + (int64_t)start * ld + h * 32;
+    const int qrow = q0 + wave * 16 + i16;
+    const bool qok = qrow < len;
+    bf16x8 qf[3], dof[3];
+    row_frag_x3(qok ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
+    row_frag_x3(qok ? dout + (int64_t)(start + qrow) * D + h * 32 + g * 8 : nullptr, 1.f, dof);
+    // log2 units; rows past the end get +inf so that exp2(s - lse) = 0 masks them without a select per element
+    const float lse_q = qok ? lse[(int64_t)h * n_total + start + qrow] * X_LOG2E : INFINITY;
+    const float del_q = qok ? delta[(int64_t)h * n_total + start + qrow] : 0.f;
+    f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int ntiles = (len + 63) >> 6;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        stage_x3<true, true>(base + D, ld, kt * 64, len, 1.f, Kn, Kp, tid);
+        stage_x3<true, false>(base + 2 * D, ld, kt * 64, len, 1.f, Vn, nullptr, tid);
+        __syncthreads();
+        const bool last = kt == ntiles - 1 && (len & 63);          // wave-uniform
+        float ds[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            bf16x8 ak[3], av[3];
+            nat_frag_x3(Kn, kb, i16, g, ak);
+            nat_frag_x3(Vn, kb, i16, g, av);
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = s4;
+#pragma unroll
+            for (int o = 2; o >= 0; --o)
+#pragma unroll
+                for (int qa = 0; qa <= o; ++qa) {
+                    s4 = U3D_MFMA_X(ak[qa], qf[o - qa], s4);
+                    dp4 = U3D_MFMA_X(av[qa], dof[o - qa], dp4);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(s4[r] - lse_q);
+                if (last && kt * 64 + kb * 16 + g * 4 + r >= len) p = 0.f;        // zero-padded keys of the last tile
+                ds[kb][r] = p * (dp4[r] - del_q);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 da[3], k0[3], k1[3];
+            pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
+            pair_col_frag_x3(Kp, t, g, i16, k0);
+            pair_col_frag_x3(Kp, t, g, 16 + i16, k1);
+            mfma_x3_2b(da, k0, k1, dq[0], dq[1]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q0 + wave * 16 + g * 4 + r;
+        if (row < len) {
+            float* op = dqkv + (int64_t)(start + row) * ld + h * 32 + i16;
+            op[0] = dq[0][r] * scale;
+            op[16] = dq[1][r] * scale;
+        }
+    }
+}
+
+// dK, dV: one workgroup per 64-key tile, queries streamed.  Q and dO are staged in both layouts.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                                                         const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
+                                                         float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) __bf16 Qn[3 * XN];
+    __shared__ __attribute__((aligned(16))) __bf16 On[3 * XN];
+    __shared__ __attribute__((aligned(16))) unsigned Qp[3 * XP];
+    __shared__ __attribute__((aligned(16))) unsigned Op[3 * XP];
+    __shared__ float lse_s[64], del_s[64];
+    const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
+    const int b = wk_.b, h = wk_.h;
+    if (b >= B) return;
+    const int start = cu[b], len = cu[b + 1] - start;
+    const int k0 = wk_.tile * 64;
+    if (k0 >= len) return;
+    const int D = H * 32, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const float* base = qkv + (int64_t)start * ld + h * 32;
+    const float* dobase = dout + (int64_t)start * D + h * 32;
+    const int krow = k0 + wave * 16 + i16;
+    bf16x8 kf[3], vf[3];
+    row_frag_x3(krow < len ? base + (int64_t)krow * ld + D + g * 8 : nullptr, 1.f, kf);
+    row_frag_x3(krow < len ? base + (int64_t)krow * ld + 2 * D + g * 8 : nullptr, 1.f, vf);
+    f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int ntiles = (len + 63) >> 6;
+    for (int qt = 0; qt < ntiles; ++qt) {
+        __syncthreads();
+        stage_x3<true, true>(base, ld, qt * 64, len, scale * X_LOG2E, Qn, Qp, tid);        // log2 units; dK is rescaled by ln 2 at the end
+        stage_x3<true, true>(dobase, D, qt * 64, len, 1.f, On, Op, tid);
+        if (tid < 64) {
+            const int q = qt * 64 + tid;
+            lse_s[tid] = q < len ? lse[(int64_t)h * n_total + start + q] * X_LOG2E : INFINITY;   // exp2(s - inf) = 0 masks the row
+            del_s[tid] = q < len ? delta[(int64_t)h * n_total + start + q] : 0.f;
+        }
+        __syncthreads();
+        float p[4][4], ds[4][4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            bf16x8 aq[3], ao[3];
+            nat_frag_x3(Qn, qb, i16, g, aq);
+            nat_frag_x3(On, qb, i16, g, ao);
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = s4;
+#pragma unroll
+            for (int o = 2; o >= 0; --o)
+#pragma unroll
+                for (int qa = 0; qa <= o; ++qa) {
+                    s4 = U3D_MFMA_X(aq[qa], kf[o - qa], s4);
+                    dp4 = U3D_MFMA_X(ao[qa], vf[o - qa], dp4);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = qb * 16 + g * 4 + r;
+                p[qb][r] = __builtin_amdgcn_exp2f(s4[r] - lse_s[qq]);
+                ds[qb][r] = p[qb][r] * (dp4[r] - del_s[qq]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 pa[3], da[3], f0[3], f1[3];
+            pair_frag_x3(p[2 * t], p[2 * t + 1], pa);
+            pair_col_frag_x3(Op, t, g, i16, f0);
+            pair_col_frag_x3(Op, t, g, 16 + i16, f1);
+            mfma_x3_2b(pa, f0, f1, dv[0], dv[1]);
+            pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
+            pair_col_frag_x3(Qp, t, g, i16, f0);
+            pair_col_frag_x3(Qp, t, g, 16 + i16, f1);
+            mfma_x3_2b(da, f0, f1, dk[0], dk[1]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = k0 + wave * 16 + g * 4 + r;
+        if (row < len) {
+            float* op = dqkv + (int64_t)(start + row) * ld + h * 32 + i16;
+            op[D] = dk[0][r] * X_LN2;
+            op[D + 16] = dk[1][r] * X_LN2;
+            op[2 * D] = dv[0][r];
+            op[2 * D + 16] = dv[1][r];
+        }
+    }
+}
+
+// launchers, called from attn.hip's entry points when fp32_x3() (arguments already validated there)
+void attn_fwd_x3_launch(const float* qkv, const int32_t* cu, int B, int max_len, int64_t n_total, int H, float scale, float* out, float* lse,
+                        hipStream_t s) {
+    const int n_tiles = (max_len + 63) / 64;
+    const unsigned grid = (unsigned)(((H * B + 7) / 8) * 8 * n_tiles);
+    hipLaunchKernelGGL(attn_fwd_x3_k, dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
+}
+
+void attn_bwd_x3_launch(const float* qkv, const float* out, const float* dout, const float* lse, const int32_t* cu, int B, int max_len,
+                        int64_t n_total, int H, float scale, float* dqkv, float* delta_ws, hipStream_t s) {
+    hipLaunchKernelGGL(attn_delta_x3_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, out, dout, n_total, H, delta_ws);
+    const int n_tiles = (max_len + 63) / 64;
+    const dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * n_tiles));
+    hipLaunchKernelGGL(attn_bwd_dq_x3_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+    hipLaunchKernelGGL(attn_bwd_dkv_x3_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+}
+
+}  // namespace u3d

@@ -23,7 +23,8 @@ namespace u3d {
 typedef bf16x8_t bf16x8;
 
 constexpr float X_LOG2E = 1.44269504088896340736f, X_LN2 = 0.69314718055994530942f;
-constexpr int XLD = 40;                  // halves per row of a natural plane: 32 + 8 pad (80-byte rows: conflict-free 16-byte reads)
+constexpr int XLD = 32;                  // halves per row of a natural plane: unpadded, the 16-byte chunk index is XORed with (row >> 1) & 3
+                                         // (conflict-free ds_read_b128 for the lane -> (row = lane & 15, chunk = lane >> 4) map)
 constexpr int XPD = 40;                  // dwords per dim (column) of a pair plane: 32 key-pair slots + 8 pad
 constexpr int XN = 64 * XLD;             // halves per natural plane
 constexpr int XP = 32 * XPD;             // dwords per pair plane
@@ -51,17 +52,24 @@ __device__ __forceinline__ void mfma_x3_2b(const bf16x8 (&a)[3], const bf16x8 (&
 }
 
 // Stage 64 rows x 32 floats of `base` (rows >= len are zero, values scaled before the split): thread (p = tid >> 3, c = tid & 7)
-// holds dims 4c .. 4c+3 of rows 2p and 2p+1.  NAT: natural planes nat[3][64][XLD] halves; PAIR: pair planes pr[3][32 dims][XPD]
+// holds dims 4c .. 4c+3 of rows 2p and 2p+1; load_x3 issues the global loads (one tile ahead of their use: the compute phase of
+// the tile before covers their latency), store_x3 splits and writes.  NAT: natural planes nat[3][64][XLD] halves; PAIR: pair planes pr[3][32 dims][XPD]
 // dwords, row pair p = (t, half, g, w) bits 4 | 3 | 2-1 | 0 in slot 16 t + 4 g + 2 half + w, XORed with 4 * (dim >> 2).
-template <bool NAT, bool PAIR>
-__device__ __forceinline__ void stage_x3(const float* __restrict__ base, int ld, int row0, int len, float scale, __bf16* nat, unsigned* pr, int tid) {
+struct StageRegs { f32x4 a, b; };
+__device__ __forceinline__ StageRegs load_x3(const float* __restrict__ base, int ld, int row0, int len, int tid) {
     const int p = tid >> 3, c = tid & 7;
     const int r0 = row0 + 2 * p;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-    if (r0 < len) a = *reinterpret_cast<const f32x4*>(base + (int64_t)r0 * ld + c * 4);
-    if (r0 + 1 < len) b = *reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + 1) * ld + c * 4);
-    a *= scale;
-    b *= scale;
+    StageRegs r;
+    r.a = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.b = r.a;
+    if (r0 < len) r.a = *reinterpret_cast<const f32x4*>(base + (int64_t)r0 * ld + c * 4);
+    if (r0 + 1 < len) r.b = *reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + 1) * ld + c * 4);
+    return r;
+}
+template <bool NAT, bool PAIR>
+__device__ __forceinline__ void store_x3(StageRegs r, float scale, __bf16* nat, unsigned* pr, int tid) {
+    const int p = tid >> 3, c = tid & 7;
+    const f32x4 a = r.a * scale, b = r.b * scale;
     if constexpr (PAIR) {
         unsigned w[3][4];
 #pragma unroll
@@ -79,10 +87,11 @@ __device__ __forceinline__ void stage_x3(const float* __restrict__ base, int ld,
             split3_pair(a[2 * j], a[2 * j + 1], wa[0][j], wa[1][j], wa[2][j]);
             split3_pair(b[2 * j], b[2 * j + 1], wb[0][j], wb[1][j], wb[2][j]);
         }
+        const int off = (((c >> 1) ^ (p & 3)) * 8) + (c & 1) * 4;          // rows 2p and 2p+1 share (row >> 1) & 3 = p & 3
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p) * XLD + c * 4) = make_uint2(wa[q][0], wa[q][1]);
-            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p + 1) * XLD + c * 4) = make_uint2(wb[q][0], wb[q][1]);
+            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p) * XLD + off) = make_uint2(wa[q][0], wa[q][1]);
+            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p + 1) * XLD + off) = make_uint2(wb[q][0], wb[q][1]);
         }
     }
 }
@@ -104,7 +113,7 @@ __device__ __forceinline__ void pair_frag_x3(const float (&lo)[4], const float (
 // natural planes: rows 16 kb + i, dims 8g .. 8g+7
 __device__ __forceinline__ void nat_frag_x3(const __bf16* nat, int kb, int i16, int g, bf16x8 (&out)[3]) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) out[q] = *reinterpret_cast<const bf16x8*>(nat + q * XN + (kb * 16 + i16) * XLD + g * 8);
+    for (int q = 0; q < 3; ++q) out[q] = *reinterpret_cast<const bf16x8*>(nat + q * XN + (kb * 16 + i16) * XLD + ((g ^ ((i16 >> 1) & 3)) * 8));
 }
 
 // pair planes: column (dim) `col`, rows {4g..4g+3} and {16+4g..16+4g+3} of the 32-row block t: slots 16 t + 4 g .. + 3
@@ -144,10 +153,15 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
     float m = -INFINITY, l = 0.f;
     f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
+    StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        stage_x3<true, false>(base + D, ld, kt * 64, len, 1.f, Kn, nullptr, tid);
-        stage_x3<false, true>(base + 2 * D, ld, kt * 64, len, 1.f, nullptr, Vp, tid);
+        store_x3<true, false>(rk, 1.f, Kn, nullptr, tid);
+        store_x3<false, true>(rv, 1.f, nullptr, Vp, tid);
+        if (kt + 1 < ntiles) {
+            rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
+            rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
+        }
         __syncthreads();
         float st[4][4];
 #pragma unroll
@@ -260,10 +274,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     const float del_q = qok ? delta[(int64_t)h * n_total + start + qrow] : 0.f;
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
+    StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        stage_x3<true, true>(base + D, ld, kt * 64, len, 1.f, Kn, Kp, tid);
-        stage_x3<true, false>(base + 2 * D, ld, kt * 64, len, 1.f, Vn, nullptr, tid);
+        store_x3<true, true>(rk, 1.f, Kn, Kp, tid);
+        store_x3<true, false>(rv, 1.f, Vn, nullptr, tid);
+        if (kt + 1 < ntiles) {
+            rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
+            rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
+        }
         __syncthreads();
         const bool last = kt == ntiles - 1 && (len & 63);          // wave-uniform
         float ds[4][4];
@@ -332,10 +351,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
     row_frag_x3(krow < len ? base + (int64_t)krow * ld + 2 * D + g * 8 : nullptr, 1.f, vf);
     f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
+    StageRegs rq = load_x3(base, ld, 0, len, tid), ro = load_x3(dobase, D, 0, len, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
-        stage_x3<true, true>(base, ld, qt * 64, len, scale * X_LOG2E, Qn, Qp, tid);        // log2 units; dK is rescaled by ln 2 at the end
-        stage_x3<true, true>(dobase, D, qt * 64, len, 1.f, On, Op, tid);
+        store_x3<true, true>(rq, scale * X_LOG2E, Qn, Qp, tid);        // log2 units; dK is rescaled by ln 2 at the end
+        store_x3<true, true>(ro, 1.f, On, Op, tid);
+        if (qt + 1 < ntiles) {
+            rq = load_x3(base, ld, qt * 64 + 64, len, tid);
+            ro = load_x3(dobase, D, qt * 64 + 64, len, tid);
+        }
         if (tid < 64) {
             const int q = qt * 64 + tid;
             lse_s[tid] = q < len ? lse[(int64_t)h * n_total + start + q] * X_LOG2E : INFINITY;   // exp2(s - inf) = 0 masks the row

@@ -162,9 +162,19 @@ int u3d_spconv_gmm_bf16(const float* src, int64_t n_src, const void* w_rows_bf16
                         const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
                         int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream);
 int u3d_weight_pack_bf16(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream);
+/* fp32 products on the bf16 matrix pipe (see u3d_fp32_math): same arguments and results at fp32-level error; the gathered rows are
+ * split exactly into three bf16 planes as the MFMA operand is formed, the weights come pre-split from u3d_weight_pack_x3
+ * (Cd*K*Cs*6 bytes: three consecutive 1 KB plane blocks per (32-channel group, 16-column block) of the bf16 form's order), a
+ * fragment pair takes six v_mfma_f32_16x16x32_bf16.  Cs % 32 == 0.  The host picks this form over u3d_spconv_gmm when
+ * u3d_fp32_math(-1) == 1 -- the packed-weight layout belongs to the entry point, so the library does not switch it silently. */
+int u3d_spconv_gmm_x3(const float* src, int64_t n_src, const void* w_rows_x3, const int32_t* gather, const int32_t* scatter,
+                      const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                      int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream);
+int u3d_weight_pack_x3(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream);
 /* all packs of a model in one launch: desc = device array of n_desc records of eight int64
- * {src pointer, dst pointer, Cd, K, Cs, transposed, bf16 (0/1), first block}; record i owns blocks [first_i, first_{i+1}) of 256
- * threads, one 16-byte output vector per thread (Cd*K*Cs/4 vectors in fp32 form, Cd*K*Cs/8 in bf16 form). */
+ * {src pointer, dst pointer, Cd, K, Cs, transposed, format (0 fp32, 1 bf16, 2 x3), first block}; record i owns blocks
+ * [first_i, first_{i+1}) of 256 threads: one 16-byte output vector per thread in the fp32 (Cd*K*Cs/4 threads) and bf16 (Cd*K*Cs/8)
+ * forms, the three plane vectors of one bf16-form position per thread in the x3 form (Cd*K*Cs/8 threads). */
 int u3d_weight_pack_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream);
 /* Launch plan for a shape: tile_rows (rows per wave-tile = the tile height to pass to u3d_tile_starts) and
  * k_groups (kernel offsets are split into that many groups when the level has too few rows to fill the chip;

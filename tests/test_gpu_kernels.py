@@ -104,8 +104,17 @@ def _level_geometry(n_points=12_000, vs=0.05):
     return vb, oc, oshape
 
 
+@pytest.fixture(params=['bf16x3', 'mfma'])
+def math_mode(request):
+    """both ways of forming fp32 products (precision.fp32_math): three exact bf16 planes per operand on the bf16 matrix pipe
+    (the default) and the native fp32 MFMAs"""
+    from unidet3d_amd import precision as P
+    with P.fp32_math(request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize('cin,cout', CONV_SHAPES)
-def test_subm_conv_fwd_bwd(cin, cout):
+def test_subm_conv_fwd_bwd(cin, cout, math_mode):
     from unidet3d_amd import sparse
     vb, oc, oshape = _level_geometry()
     n = len(oc)
@@ -131,8 +140,35 @@ def test_subm_conv_fwd_bwd(cin, cout):
     assert _rel(ag.grad, ao.grad) < 1e-6
 
 
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 64), (128, 128)])
+def test_subm_conv_bf16x3_is_as_accurate_as_the_native_fp32_mfma(cin, cout):
+    """Forward and input gradient of a 3x3x3 submanifold convolution in both fp32 math modes against the float64 oracle, on
+    inputs spanning six decades: the three-plane products must not lose anything against the native fp32 MFMAs."""
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    vb, oc, oshape = _level_geometry()
+    n = len(oc)
+    g = torch.Generator().manual_seed(cin * 77 + cout)
+    x = torch.randn(n, cin, generator=g) * torch.exp(torch.randn(n, cin, generator=g) * 2.0)
+    w = torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1 * torch.exp(torch.randn(cout, 3, 3, 3, cin, generator=g))
+    go = torch.randn(n, cout, generator=g) * torch.exp(torch.randn(n, cout, generator=g))
+    xo, wo = x.clone().double().requires_grad_(), w.clone().double().requires_grad_()
+    pairs = so.build_subm_rulebook(oc, oshape)
+    yo = so.sparse_conv(xo, wo, pairs, n); yo.backward(go.double())
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    err = {}
+    for mode in ('mfma', 'bf16x3'):
+        xg, wg = [t.clone().to(_dev()).requires_grad_() for t in (x, w)]
+        with P.fp32_math(mode):
+            yg = sparse.sparse_conv(xg, wg, rb, 'fwd'); yg.backward(go.to(_dev()))
+        err[mode] = [_rel(yg, yo), _rel(xg.grad, xo.grad), _rel(wg.grad, wo.grad)]
+    print('conv fp32 math errors (y, dx, dw) vs float64:', err)
+    for e3, e1 in zip(err['bf16x3'], err['mfma']):
+        assert e3 < max(1.5 * e1, 2e-6), err
+
+
 @pytest.mark.parametrize('cin,cout', [(32, 64), (64, 96), (96, 128), (128, 160)])
-def test_strided_and_inverse_conv_fwd_bwd(cin, cout):
+def test_strided_and_inverse_conv_fwd_bwd(cin, cout, math_mode):
     from unidet3d_amd import sparse
     vb, oc, oshape = _level_geometry()
     n = len(oc)

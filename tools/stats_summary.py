@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 --stats kernel_stats.csv: python tools/stats_summary.py file.csv [n_steps|auto] [n_rows]
 The number of profiled steps is derived from the trace itself (auto, the default): the decoder runs attn_fwd_k once per layer and
-step, so steps = calls(attn_fwd*_k) / 6 for the 6-layer ScanNet model (U3D_DECODER_LAYERS overrides 6) -- a hand-passed count
+step, so steps = calls(attn_fwd{,_bf16,_x3}_k) / 6 for the 6-layer ScanNet model (U3D_DECODER_LAYERS overrides 6) -- a hand-passed count
 was wrong by one step in round 2 (warm-up + timed + instrumented steps all appear in the trace)."""
 import collections
 import csv
@@ -12,7 +12,7 @@ import os
 arg = sys.argv[2] if len(sys.argv) > 2 else 'auto'
 if arg == 'auto':
     layers = int(os.environ.get('U3D_DECODER_LAYERS', '6'))
-    calls = sum(int(r['Calls']) for r in rows if re.search(r'attn_fwd(_bf16)?_k', r['Name']))
+    calls = sum(int(r['Calls']) for r in rows if re.search(r'attn_fwd(_bf16|_x3)?_k', r['Name']))
     assert calls and calls % layers == 0, f'cannot derive the step count: {calls} attn_fwd launches for {layers} layers'
     steps = calls / layers
     print(f'steps in this trace: {steps:.0f} (= {calls} attn_fwd launches / {layers} decoder layers)')

@@ -47,6 +47,8 @@ PROTOTYPES = {
     'u3d_spconv_gmm_bf16': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
     'u3d_weight_pack_batch': (_i32, [_vp, _i32, _i64, _vp]),
     'u3d_weight_pack_bf16': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'u3d_spconv_gmm_x3': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
+    'u3d_weight_pack_x3': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_spconv_plan': (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
     'u3d_spconv_wgrad': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
     'u3d_spconv_wgrad_bf16': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),

@@ -95,10 +95,10 @@ __device__ __forceinline__ int gmm_acc_idx(int r, int c4) { return GMM_SWZ ? r *
 //    a load instruction therefore reads 64/PPR COMPLETE rows (PPR = JB*4 lanes x 16 B each), and the wave
 //    transposes them to MFMA fragments through a private XOR-swizzled LDS image (ds_write_b128 -> ds_read_b128,
 //    both conflict-free; LDS operations of one wave execute in order, so no barrier).
-template <int NI, int JB>
+template <int NI, int JB, int NW = 2>
 struct GmmBuf {
     f32x4 a[NI];         // instruction i: rows i*RPI + lane/PPR of the item, 16-byte piece lane%PPR of the unit
-    f32x4 b[JB][2];
+    f32x4 b[JB][NW];     // weight fragments: fp32 [16-channel group][column block], bf16 [32-channel group][column block], x3 [(group, block)][plane]
 };
 
 struct GmmItem {
@@ -113,8 +113,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // v_mfma_f32_16x16x32_bf16 (k = 8q + e <-> channel 16 (2 jl + (e >> 2)) + 4q + (e & 3) for lane group q), the weight
 // fragments come pre-rounded in that order from u3d_weight_pack_bf16 (half the weight bytes); accumulation, the LDS
 // accumulator tile and the output stay fp32.  8 fp32 MFMAs (256 SIMD cycles) become one bf16 MFMA (16) + 4 v_cvt_pk.
-template <int CS16, int R, int JB_, bool BF = false>
+// PR = 0: fp32 MFMAs; 1: bf16 operands (above); 2: fp32 products from three exact bf16 planes per operand (u3d_common.h "bf16x3"):
+// same operand shapes as PR = 1, the gathered rows are split where PR = 1 rounds them, the weights come pre-split from
+// u3d_weight_pack_x3 (three 1 KB blocks per (32-channel group, column block)), and a fragment pair takes six MFMAs.
+template <int CS16, int R, int JB_, int PR = 0>
 struct GmmWave {
+    static constexpr bool BF = PR == 1, X3 = PR == 2;
     static constexpr int NCH = R / 32;            // 16-pair chunks per item
     static constexpr int JB = JB_;                // 16-channel groups per unit (1, 2 or 4)
     static constexpr int NJB = CS16 / JB;
@@ -125,7 +129,7 @@ struct GmmWave {
     static constexpr int IPC = 16 / RPI;          // load instructions per 16-row chunk
     static constexpr int TRASH = R;               // scratch accumulator row for lanes past the end of a range
     static_assert(CS16 % JB == 0 && (JB == 1 || JB == 2 || JB == 4), "unit shape");
-    using Buf = GmmBuf<NI, JB>;
+    using Buf = GmmBuf<NI, JB, X3 ? 3 : 2>;
 
     __amdgpu_buffer_rsrc_t rs_src, rs_g, rs_s, rs_w;
     char* accq;                                   // accumulator tile + this lane's column offset (q*16 bytes)
@@ -206,7 +210,15 @@ struct GmmWave {
     __device__ __forceinline__ void issue(Buf& buf, const int (&g)[NI], int k, int u) const {
 #pragma unroll
         for (int i = 0; i < NI; ++i) buf.a[i] = bload128(rs_src, (int)__umul24(g[i], cs4) + lp16, u * (JB * 64));
-        if constexpr (BF) {      // 32-channel groups: (jl, nb) blocks of 1 KB (8 bf16 per lane)
+        if constexpr (X3) {      // 32-channel groups: (jl, nb, plane) blocks of 1 KB (8 bf16 per lane)
+            const int wso = ((slice * K + k) * (CS16 / 2) + u * (JB / 2)) * 6144;
+#pragma unroll
+            for (int j = 0; j < JB / 2; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) buf.b[j * 2 + nb][q] = bload128(rs_w, lane16 + (nb * 3 + q) * 1024, wso + j * 6144);
+        } else if constexpr (BF) {      // 32-channel groups: (jl, nb) blocks of 1 KB (8 bf16 per lane)
             const int wso = ((slice * K + k) * (CS16 / 2) + u * (JB / 2)) * 2048;
 #pragma unroll
             for (int j = 0; j < JB / 2; ++j) {
@@ -300,7 +312,34 @@ struct GmmWave {
         } else {
             issue(nxt, g_cur, it0.k, U + 1);
         }
-        if constexpr (BF) {
+        if constexpr (X3) {
+#pragma unroll
+            for (int j = 0; j < JB / 2; ++j) {
+                bf16x8 x0[3];
+                split3_x8(f0.v[2 * j], f0.v[2 * j + 1], x0);
+#pragma unroll
+                for (int o = 2; o >= 0; --o)
+#pragma unroll
+                    for (int qa = 0; qa <= o; ++qa) {
+                        d00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x0[o - qa], d00, 0, 0, 0);
+                        d01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x0[o - qa], d01, 0, 0, 0);
+                    }
+            }
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < JB / 2; ++j) {
+                    bf16x8 x1[3];
+                    split3_x8(f1.v[2 * j], f1.v[2 * j + 1], x1);
+#pragma unroll
+                    for (int o = 2; o >= 0; --o)
+#pragma unroll
+                        for (int qa = 0; qa <= o; ++qa) {
+                            d10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x1[o - qa], d10, 0, 0, 0);
+                            d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x1[o - qa], d11, 0, 0, 0);
+                        }
+                }
+            }
+        } else if constexpr (BF) {
 #pragma unroll
             for (int j = 0; j < JB / 2; ++j) {
                 const bf16x8 x0 = cvt8(f0.v[2 * j], f0.v[2 * j + 1]);
@@ -395,7 +434,7 @@ constexpr int gmm_jb(int cs16, int r) { return (cs16 % 4 == 0 && r == 32) ? 4 : 
 constexpr int gmm_acc_rows(int r) { return GMM_SWZ ? r : r + 1; }
 constexpr int gmm_wave_lds(int cs16, int r) { return gmm_acc_rows(r) * GMM_ALD + 16 * gmm_jb(cs16, r) * 16; }
 
-template <int CS16, int R, bool BF = false>
+template <int CS16, int R, int PR = 0>
 __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -421,8 +460,8 @@ __global__ __launch_bounds__(256) void spconv_gmm_k(GmmParams p) {
         *reinterpret_cast<float4*>(acc + gmm_acc_idx(r, c4)) = v;
     }
 
-    static_assert(!BF || CS16 % 2 == 0, "bf16 operands pair 16-channel groups");
-    GmmWave<CS16, R, gmm_jb(CS16, R), BF> w;
+    static_assert(PR == 0 || CS16 % 2 == 0, "bf16 operands pair 16-channel groups");
+    GmmWave<CS16, R, gmm_jb(CS16, R), PR> w;
     w.init(p, acc, acc + gmm_acc_rows(R) * GMM_ALD, lane, slice, row0);
     const int k_lo = g * p.kper;
     w.k_hi = min(p.K, k_lo + p.kper);
@@ -494,11 +533,11 @@ static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
     *G = g;
 }
 
-template <int CS16, int R, bool BF = false>
+template <int CS16, int R, int PR = 0>
 static int launch_gmm(const GmmParams& p, hipStream_t s) {
     const size_t lds = (size_t)4 * gmm_wave_lds(CS16, R) * sizeof(float);
     const int64_t waves = p.n_sub * p.n_slices * p.G;
-    hipLaunchKernelGGL((spconv_gmm_k<CS16, R, BF>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((spconv_gmm_k<CS16, R, PR>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), lds, s, p);
     return check_launch("spconv_gmm");
 }
 
@@ -867,8 +906,37 @@ __global__ __launch_bounds__(256) void weight_pack_bf16_k(const float* __restric
     wp[idx] = v;
 }
 
+// x3 form (u3d_common.h "bf16x3"): the bf16 form's vectors, three planes per (lane, 32-channel group jj, column block nb):
+// wp[((((slice*K + k)*CS32 + jj)*2 + nb)*3 + plane)*64 + lane][e] = plane `plane` of the exact split of the same W element
+__device__ __forceinline__ void weight_x3_vectors(const float* __restrict__ w, bf16x8* __restrict__ wp, int64_t idx, int Cd, int K, int Cs, int transposed) {
+    const int cs32 = Cs / 32;
+    const int lane = (int)(idx & 63);
+    int64_t t = idx >> 6;
+    const int nb = (int)(t & 1); t >>= 1;
+    const int jj = (int)(t % cs32); t /= cs32;
+    const int k = (int)(t % K);
+    const int slice = (int)(t / K);
+    const int n = slice * 32 + nb * 16 + (lane & 15), q = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = (2 * jj + (e >> 2)) * 16 + q * 4 + (e & 3);
+        v[e] = transposed ? w[((int64_t)c * K + k) * Cd + n] : w[((int64_t)n * K + k) * Cs + c];
+    }
+    bf16x8 pl[3];
+    split3_x8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, pl);
+    const int64_t o = (idx >> 6) * 192 + lane;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) wp[o + pq * 64] = pl[pq];
+}
+__global__ __launch_bounds__(256) void weight_pack_x3_k(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cd, int K, int Cs, int transposed) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one (lane, jj, nb) triple of vectors per thread
+    if (idx >= (int64_t)(Cd / 32) * K * (Cs / 32) * 2 * 64) return;
+    weight_x3_vectors(w, wp, idx, Cd, K, Cs, transposed);
+}
+
 // every convolution weight of the model, both orientations, in ONE launch (the weights change once per optimizer step; 89 single
-// packs cost 0.38 ms of launch latency per step).  desc[i] = {src, dst, Cd, K, Cs, transposed, bf16, first block}: block b belongs
+// packs cost 0.38 ms of launch latency per step).  desc[i] = {src, dst, Cd, K, Cs, transposed, format (0 fp32, 1 bf16, 2 x3), first block}: block b belongs
 // to the last descriptor whose first block is <= b.
 struct PackDesc { const float* src; void* dst; int64_t Cd, K, Cs, transposed, bf, block0; };
 __global__ __launch_bounds__(256) void weight_pack_batch_k(const PackDesc* __restrict__ desc, int n_desc) {
@@ -883,7 +951,10 @@ __global__ __launch_bounds__(256) void weight_pack_batch_k(const PackDesc* __res
     const int lane = (int)(idx & 63);
     int64_t t = idx >> 6;
     const int nb = (int)(t & 1); t >>= 1;
-    if (d.bf) {
+    if (d.bf == 2) {
+        if (idx >= (int64_t)(Cd / 32) * K * (Cs / 32) * 2 * 64) return;
+        weight_x3_vectors(d.src, reinterpret_cast<bf16x8*>(d.dst), idx, Cd, K, Cs, (int)d.transposed);
+    } else if (d.bf) {
         const int cs32 = Cs / 32;
         if (idx >= (int64_t)(Cd / 32) * K * cs32 * 2 * 64) return;
         const int jj = (int)(t % cs32); t /= cs32;
@@ -943,8 +1014,8 @@ int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k
 
 static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
                            const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
-                           int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream, bool bf) {
-    if (bf && Cs % 32) { set_error("spconv_gmm_bf16: Cs=%d must be a multiple of 32", Cs); return U3D_EUNSUPPORTED; }
+                           int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream, int pr) {
+    if (pr && Cs % 32) { set_error("spconv_gmm_%s: Cs=%d must be a multiple of 32", pr == 1 ? "bf16" : "x3", Cs); return U3D_EUNSUPPORTED; }
     if (!src || !w_rows || !gather || !scatter || !tile_starts || !dst || K <= 0 || K > 32 || n_dst <= 0 || n_src <= 0 || cap <= 0) return U3D_EINVAL;
     // the kernel addresses through 32-bit buffer offsets and multiplies row indices with v_mul_u32_u24
     if (n_src >= (1 << 24) || n_dst >= (1 << 24) || n_src * Cs * 4 >= 0x7fffffffLL || (int64_t)K * cap * 4 >= 0x7fffffffLL) {
@@ -969,14 +1040,18 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
     const int cs16 = Cs / 16;
     int rc = U3D_EUNSUPPORTED;
 #define U3D_GMM_CASE(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64>(p, s) : launch_gmm<cs, 32>(p, s);
-#define U3D_GMM_CASE_BF(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64, true>(p, s) : launch_gmm<cs, 32, true>(p, s);
-    if (bf) {
+#define U3D_GMM_CASE_BF(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64, 1>(p, s) : launch_gmm<cs, 32, 1>(p, s);
+#define U3D_GMM_CASE_X3(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64, 2>(p, s) : launch_gmm<cs, 32, 2>(p, s);
+    if (pr == 1) {
         U3D_GMM_CASE_BF(2) U3D_GMM_CASE_BF(4) U3D_GMM_CASE_BF(6) U3D_GMM_CASE_BF(8) U3D_GMM_CASE_BF(10) U3D_GMM_CASE_BF(12) U3D_GMM_CASE_BF(16)
+    } else if (pr == 2) {
+        U3D_GMM_CASE_X3(2) U3D_GMM_CASE_X3(4) U3D_GMM_CASE_X3(6) U3D_GMM_CASE_X3(8) U3D_GMM_CASE_X3(10) U3D_GMM_CASE_X3(12) U3D_GMM_CASE_X3(16)
     } else {
         U3D_GMM_CASE(1) U3D_GMM_CASE(2) U3D_GMM_CASE(4) U3D_GMM_CASE(6) U3D_GMM_CASE(8) U3D_GMM_CASE(10) U3D_GMM_CASE(12) U3D_GMM_CASE(16)
     }
 #undef U3D_GMM_CASE
 #undef U3D_GMM_CASE_BF
+#undef U3D_GMM_CASE_X3
     if (rc != U3D_OK) return rc;
     if (G > 1) {
         const int64_t n4 = n_dst * Cd / 4;
@@ -992,14 +1067,28 @@ int u3d_spconv_gmm(const float* src, int64_t n_src, const float* w_rows, const i
                    const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
                    int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream) {
     return spconv_gmm_impl(src, n_src, w_rows, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups, addend, dst, ws,
-                           bn_partial, flops_hint, stream, false);
+                           bn_partial, flops_hint, stream, 0);
 }
 
 int u3d_spconv_gmm_bf16(const float* src, int64_t n_src, const void* w_rows_bf16, const int32_t* gather, const int32_t* scatter,
                         const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
                         int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream) {
     return spconv_gmm_impl(src, n_src, (const float*)w_rows_bf16, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups,
-                           addend, dst, ws, bn_partial, flops_hint, stream, true);
+                           addend, dst, ws, bn_partial, flops_hint, stream, 1);
+}
+
+int u3d_spconv_gmm_x3(const float* src, int64_t n_src, const void* w_rows_x3, const int32_t* gather, const int32_t* scatter,
+                      const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                      int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream) {
+    return spconv_gmm_impl(src, n_src, (const float*)w_rows_x3, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups,
+                           addend, dst, ws, bn_partial, flops_hint, stream, 2);
+}
+
+int u3d_weight_pack_x3(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {
+    if (!w || !wp || Cd <= 0 || K <= 0 || Cs <= 0 || Cd % 32 || Cs % 32) return U3D_EINVAL;
+    const int64_t total8 = (int64_t)Cd * K * Cs / 8;
+    hipLaunchKernelGGL(weight_pack_x3_k, dim3((unsigned)ceil_div(total8, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16x8*)wp, Cd, K, Cs, transposed);
+    return check_launch("weight_pack_x3");
 }
 
 int u3d_weight_pack_bf16(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {

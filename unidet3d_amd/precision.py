@@ -45,19 +45,26 @@ def operands(mode: str):
 
 
 _FP32_MATH = {'mfma': 0, 'bf16x3': 1}
+_X3 = None              # cached library state (u3d_fp32_math is process-wide)
 
 
 def get_fp32_math() -> str:
-    from . import _lib as L
-    return 'bf16x3' if L.lib().u3d_fp32_math(-1) == 1 else 'mfma'
+    global _X3
+    if _X3 is None:
+        from . import _lib as L
+        _X3 = L.lib().u3d_fp32_math(-1) == 1
+    return 'bf16x3' if _X3 else 'mfma'
 
 
 def set_fp32_math(mode: str) -> str:
     """'bf16x3' | 'mfma' (see the module docstring); returns the previous mode.  Process-wide."""
+    global _X3
     from . import _lib as L
     if mode not in _FP32_MATH:
         raise ValueError("fp32 math must be 'bf16x3' or 'mfma'")
-    return 'bf16x3' if L.lib().u3d_fp32_math(_FP32_MATH[mode]) == 1 else 'mfma'
+    prev = 'bf16x3' if L.lib().u3d_fp32_math(_FP32_MATH[mode]) == 1 else 'mfma'
+    _X3 = mode == 'bf16x3'
+    return prev
 
 
 @contextlib.contextmanager
@@ -67,3 +74,14 @@ def fp32_math(mode: str):
         yield
     finally:
         set_fp32_math(prev)
+
+
+FMT_FP32, FMT_BF16, FMT_X3 = 0, 1, 2
+
+
+def conv_format() -> int:
+    """Operand format of the sparse-convolution kernels for the current modes: the packed-weight layout and the entry point
+    (u3d_spconv_gmm / _bf16 / _x3) go together, so the choice is made here, once per op, and remembered for its backward."""
+    if _MODE == 'bf16':
+        return FMT_BF16
+    return FMT_X3 if get_fp32_math() == 'bf16x3' else FMT_FP32

@@ -240,7 +240,7 @@ class WeightPacks:
     def refresh(self):
         if not self.convs:
             return
-        bf = P.bf16()
+        bf = P.conv_format()           # 0 fp32 fragments, 1 bf16, 2 three bf16 planes (precision.conv_format)
         dev = self.convs[0].weight.device
         state = (bf, str(dev), tuple((m.weight.data_ptr(), m.weight._version) for m in self.convs))
         if state == self.state and not self.root.training and not self.dirty:
@@ -259,9 +259,9 @@ class WeightPacks:
                 for transposed, (Cd, Cs) in ((0, (m.out_channels, m.in_channels)), (1, (m.in_channels, m.out_channels))):
                     if Cd % 32 or Cs % 16:
                         continue
-                    use_bf = bf and Cs % 32 == 0
-                    buf = torch.empty(w.numel() // (2 if use_bf else 1), dtype=torch.float32, device=dev)
-                    nvec = w.numel() // (8 if use_bf else 4)
+                    use_bf = bf if Cs % 32 == 0 else 0
+                    buf = torch.empty(_pack_floats(w.numel(), use_bf), dtype=torch.float32, device=dev)
+                    nvec = w.numel() // (8 if use_bf else 4)          # threads of the pack kernel (x3: three vectors per thread)
                     rows.append([w.data_ptr(), buf.data_ptr(), Cd, K, Cs, transposed, int(use_bf), blocks])
                     blocks += (nvec + 255) // 256
                     self.bufs[(w.data_ptr(), transposed, use_bf)] = (buf, w)
@@ -273,13 +273,21 @@ class WeightPacks:
         self.state = state
 
 
-def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=False, stats_out=None):
+_GMM_ENTRY = {0: ('u3d_weight_pack', 'u3d_spconv_gmm'), 1: ('u3d_weight_pack_bf16', 'u3d_spconv_gmm_bf16'), 2: ('u3d_weight_pack_x3', 'u3d_spconv_gmm_x3')}
+
+
+def _pack_floats(numel: int, fmt: int) -> int:
+    """size of a packed weight buffer in floats: fp32 fragments, bf16 (half), three bf16 planes (one and a half)"""
+    return {0: numel, 1: numel // 2, 2: numel * 3 // 2}[fmt]
+
+
+def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=0, stats_out=None):
     """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in).
     ``stats_out`` (a dict, or None): asks the kernel's epilogue for the per-tile column sums of dst that the batch norm behind
     this convolution needs (``partial`` float [n_tiles, 2, Cd], ``n_tiles``); left empty when the launch splits the kernel
     offsets over groups (deep levels: a few thousand rows, the norm then makes its own pass).
-    ``bf``: bf16 MFMA operands (precision.py); source channel counts that are not a multiple of 32 (the 6 -> 32 input
-    convolution, padded to 16) stay on the fp32 kernel."""
+    ``bf``: operand format (precision.conv_format: 0 fp32 MFMAs, 1 bf16 operands, 2 fp32 products from three bf16 planes);
+    source channel counts that are not a multiple of 32 (the 6 -> 32 input convolution, padded to 16) stay on the fp32 kernel."""
     Cs, Cd = src.shape[1], (weight.shape[2] if transposed else weight.shape[0])
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     if n_dst:
@@ -292,14 +300,15 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
             n_tiles = (n_dst + R - 1) // R
             partial = torch.empty(n_tiles, 2, Cd, dtype=torch.float32, device=src.device)
             stats_out.update(partial=partial, n_tiles=n_tiles)
-        bf = bf and Cs % 32 == 0
+        bf = int(bf) if Cs % 32 == 0 else 0
+        pack_fn, gmm_fn = _GMM_ENTRY[bf]
         hit = _PACKED.get((weight.data_ptr(), int(transposed), bf))
         if hit is not None and hit[2] == weight._version and hit[1].device == src.device:
             wp = hit[0]                                   # packed with all the model's weights by WeightPacks.refresh()
         else:
-            wp = torch.empty(weight.numel() // (2 if bf else 1), dtype=torch.float32, device=src.device)       # MFMA-fragment order
-            L.call('u3d_weight_pack_bf16' if bf else 'u3d_weight_pack', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
-        L.call('u3d_spconv_gmm_bf16' if bf else 'u3d_spconv_gmm', L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
+            wp = torch.empty(_pack_floats(weight.numel(), bf), dtype=torch.float32, device=src.device)       # MFMA-fragment order
+            L.call(pack_fn, L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
+        L.call(gmm_fn, L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
                rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), L.ptr(partial), float(flops), L.stream())
     return dst
 
@@ -349,7 +358,7 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
-        ctx.bf = P.bf16()
+        ctx.bf = P.conv_format()
         dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops, ctx.bf,
                    stats_out)
         ctx.save_for_backward(src, weight)
@@ -378,7 +387,7 @@ class _SparseConvFn(torch.autograd.Function):
             ts = rb.tile_starts(role, Tw)
             # the weight-gradient walk is bound by its row gathers: bf16 operands pay off only where the matrix
             # work is a visible share -- measured (tools/prof_wgrad.py): 32x32 channels 179 us fp32 vs 221 us bf16, 64x64 150 vs 104
-            wg = 'u3d_spconv_wgrad_bf16' if ctx.bf and cin * cout >= 64 * 64 else 'u3d_spconv_wgrad'
+            wg = 'u3d_spconv_wgrad_bf16' if ctx.bf == P.FMT_BF16 and cin * cout >= 64 * 64 else 'u3d_spconv_wgrad'
             # the weight gradient and the input gradient of a layer are independent: the former runs on a side stream so
             # the two kernels (neither fills the machine alone) share the GPU; joined before the layer's backward returns
             if _WGRAD_SIDE_STREAM and ctx.needs_input_grad[0]:

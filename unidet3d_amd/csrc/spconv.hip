@@ -583,8 +583,11 @@ __device__ __forceinline__ void load_row_part(float (&v)[N], __amdgpu_buffer_rsr
 // NG = Cd/16, NX = Cs/16 floats per lane per row; SG x SX waves share one pair range.
 // BF (BASELINE configs[2]): the same walk with v_mfma_f32_16x16x32_bf16 -- 32 pairs per instruction, lane group q takes pairs
 // 8q .. 8q+7 of a trip and rounds its row parts to bf16 (RNE) as it forms the operands; fp32 accumulation and partials.
-template <int NG, int NX, int SG, int SX, bool BF = false, bool PIPE = true>
+// PR = 2 (u3d_common.h "bf16x3"): the BF walk with both row parts split exactly into three bf16 planes and six MFMAs per block
+// pair -- fp32-level error; used only for the widest layers (see spconv_wgrad_impl for the measurements).
+template <int NG, int NX, int SG, int SX, int PR = 0, bool PIPE = true>
 __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
+    constexpr bool BF = PR != 0, X3 = PR == 2;
     constexpr int NGW = NG / SG, NXW = NX / SX, SPLIT = SG * SX, RPW = 4 / SPLIT;   // RPW ranges per workgroup
     constexpr int CD = NG * 16, CS = NX * 16;
     // A range is the set of pairs of offset k whose dy row lies in row tile t (tile_starts), so the 27 offsets of
@@ -645,6 +648,24 @@ __global__ __launch_bounds__(256) void spconv_wgrad_k(WgParams p) {
 #pragma unroll
                     for (int a = 0; a < NGW; ++a) gv[u][a] = 0.f;
                 }
+            }
+            if constexpr (X3) {
+                bf16x8 xb[NXW][3];
+#pragma unroll
+                for (int b = 0; b < NXW; ++b)
+                    split3_x8(f32x4{xv[0][b], xv[1][b], xv[2][b], xv[3][b]}, f32x4{xv[4][b], xv[5][b], xv[6][b], xv[7][b]}, xb[b]);
+#pragma unroll
+                for (int a = 0; a < NGW; ++a) {
+                    bf16x8 ga[3];
+                    split3_x8(f32x4{gv[0][a], gv[1][a], gv[2][a], gv[3][a]}, f32x4{gv[4][a], gv[5][a], gv[6][a], gv[7][a]}, ga);
+#pragma unroll
+                    for (int o = 2; o >= 0; --o)
+#pragma unroll
+                        for (int qa = 0; qa <= o; ++qa)
+#pragma unroll
+                            for (int b = 0; b < NXW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[qa], xb[b][o - qa], acc[a][b], 0, 0, 0);
+                }
+                continue;
             }
             bf16x8 xb[NXW];
 #pragma unroll
@@ -836,7 +857,7 @@ static int plan_wgrad_rows(int K, int64_t n_rows, int Cs, int Cd) {
     return (int)ceil_div(n_rows, nt);
 }
 
-template <int NX, int NG, bool BF = false>     // (Cs/16, Cd/16) as the dispatch macro passes them
+template <int NX, int NG, int PR = 0>     // (Cs/16, Cd/16) as the dispatch macro passes them
 static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     // split over the 4 waves until a wave's sub-block is <= 32 accumulators (128 VGPRs)
     constexpr int SG = (NG * NX > 32 && NG % 2 == 0 && NG >= NX) ? 2 : ((NG * NX > 64 && NG % 2 == 0) ? 2 : 1);
@@ -848,8 +869,8 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     // software-pipelined walk unless its second register set would push the kernel below two waves per SIMD
     static const int pipe_env = [] { const char* e = getenv("U3D_WGRAD_PIPE"); return e ? atoi(e) : -1; }();
     const bool pipe = pipe_env >= 0 ? pipe_env != 0 : (NG / SG) * (NX / SX) <= 16;
-    if (pipe) hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, BF, true>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, BF, false>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
+    if (pipe) hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, PR, true>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((spconv_wgrad_k<NG, NX, SG, SX, PR, false>), dim3((unsigned)(groups * p.K)), dim3(256), 0, s, p);
     const int n_blocks = SPLIT == 1 ? (int)ceil_div(p.n_tiles, 4) : p.n_tiles;       // partial blocks per offset (see the LDS reduction in the kernel)
     hipLaunchKernelGGL(wgrad_reduce_k, dim3(NG * NX, p.K), dim3(256), 0, s, (const float*)p.partial, n_blocks, p.K, NG, NX, SG, SX, dW);
     return check_launch("spconv_wgrad");
@@ -1129,7 +1150,13 @@ static int spconv_wgrad_impl(const float* x, int64_t n_rows_x, const float* dy, 
     p.n_tiles = (int)ceil_div(n_rows_dy, tile_rows);
     const int cs16 = Cs / 16, cd16 = Cd / 16;
     if (Cs % 16 || Cd % 32) return U3D_EUNSUPPORTED;
-#define U3D_WG_CASE(cs, cd) if (cs16 == cs && cd16 == cd) return bf ? launch_wgrad<cs, cd, true>(p, dW, s) : launch_wgrad<cs, cd, false>(p, dW, s);
+    // fp32 operands: the three-plane bf16 walk only where it measured faster than the pipelined fp32 walk (tools/prof_wgrad.py,
+    // 8 scenes, TFLOP/s fp32 MFMA vs x3: 32 ch 62.1 / 36.6, 64 ch 65.6 / 57.3, 96 ch 51.4 / 48.6, 128 ch 29.4 / 27.0,
+    // 160 ch 9.2 / 16.0 -- the walk is bound by its two-level gathers, and splitting 8 values x (NG + NX) blocks per trip costs
+    // more VALU time than the six bf16 MFMAs save below 160 channels), unless U3D_FP32_MATH=mfma
+    static const int x3_min = [] { const char* e = getenv("U3D_WGRAD_X3_MIN"); return e ? atoi(e) : 160 * 160; }();
+    const int pr = bf ? 1 : ((fp32_x3() && Cs * Cd >= x3_min) ? 2 : 0);
+#define U3D_WG_CASE(cs, cd) if (cs16 == cs && cd16 == cd) return pr == 1 ? launch_wgrad<cs, cd, 1>(p, dW, s) : (pr == 2 ? launch_wgrad<cs, cd, 2>(p, dW, s) : launch_wgrad<cs, cd, 0>(p, dW, s));
     U3D_WG_CASE(1, 2) U3D_WG_CASE(2, 2) U3D_WG_CASE(4, 2) U3D_WG_CASE(4, 4) U3D_WG_CASE(8, 4)
     U3D_WG_CASE(6, 6) U3D_WG_CASE(12, 6) U3D_WG_CASE(8, 8) U3D_WG_CASE(16, 8) U3D_WG_CASE(10, 10)
     U3D_WG_CASE(2, 4) U3D_WG_CASE(4, 6) U3D_WG_CASE(6, 8) U3D_WG_CASE(8, 10)

@@ -11,6 +11,7 @@ for SRC in $SRCS; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -I $R/include -I $C $EXTRA "$@" -c $C/$SRC -o $TMP/${SRC%.hip}.o &
 done
 wait
+for SRC in $SRCS; do [ -f $TMP/${SRC%.hip}.o ] || { echo "compile of $SRC failed"; exit 1; }; done
 OBJS=""; for f in $C/*.o; do b=$(basename $f); [ -f $TMP/$b ] && OBJS="$OBJS $TMP/$b" || OBJS="$OBJS $f"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
 rm -rf $TMP; ls -la $OUT

@@ -328,12 +328,23 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_k(const float* __restrict__ A,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int nk = K / GKH;
+#ifdef U3D_NTX_TRACE          // phase timestamps of wave 0 (tools/trace_gemm.py; `pre` is the trace buffer, EPI 0 only)
+    uint64_t tr_[12];
+#define U3D_TR(i) tr_[i] = __builtin_amdgcn_s_memtime()
+#define U3D_TRK(i) if (kt == 3) U3D_TR(i)
+#else
+#define U3D_TR(i)
+#define U3D_TRK(i)
+#endif
+    U3D_TR(0);
     gload(0);
     split();
     if (nk > 1) gload(1);
     lstore();
     __syncthreads();
+    U3D_TR(1);
     for (int kt = 0; kt < nk; ++kt) {
+        U3D_TRK(2);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             bf16x8 af[3][TA], bf[3][NB];
@@ -357,12 +368,37 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_k(const float* __restrict__ A,
                         }
         }
         if (kt + 1 < nk) split();                  // stage kt+1 (loaded one iteration ago)
+        U3D_TRK(3);
         if (kt + 2 < nk && !(U3D_NTX_ABL & 4)) gload(kt + 2);
+        U3D_TRK(4);
         __syncthreads();                           // every wave has read stage kt
+        U3D_TRK(5);
         if (kt + 1 < nk && !(U3D_NTX_ABL & 8)) lstore();
+        U3D_TRK(6);
         __syncthreads();
+        U3D_TRK(7);
     }
+    U3D_TR(8);
     nt_epilogue<TN, EPI, TM>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
+#ifdef U3D_NTX_TRACE
+    if constexpr (EPI == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        U3D_TR(9);
+        if (pre && tid == 0) {
+            unsigned hw;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            hw |= (xcc & 0xf) << 28;
+            uint64_t* o = reinterpret_cast<uint64_t*>(pre) + (int64_t)blockIdx.x * 12;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) o[i] = tr_[i];
+            o[10] = hw;
+        }
+    }
+#endif
+#undef U3D_TR
+#undef U3D_TRK
 }
 
 // partial[s][n][k] = sum over this split's rows of A[m][n] * B[m][k].  T = 128 or 64 output rows AND columns per workgroup:

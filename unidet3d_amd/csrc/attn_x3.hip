@@ -31,7 +31,10 @@ constexpr int XP = 32 * XPD;             // dwords per pair plane
 #define U3D_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // c += a . b with both operands in three planes takes h.l, m.m, l.h, h.m, m.h, h.h (smallest terms first);
-// two independent accumulators side by side (dependent MFMAs wait for their predecessor; alternating chains fills the gaps)
+// two independent accumulators side by side (dependent MFMAs wait for their predecessor; alternating chains fills the gaps).
+// The accumulators handed in are tile-local (zero at the start of a key tile); the running sums O / dQ / dK / dV are updated by
+// VALU adds once per tile: a bf16 MFMA truncates its products at the C operand's exponent, always towards zero
+// (tools/bias_probe.py), which is harmless inside a tile but a coherent bias when it hits a running sum 30 times per row.
 __device__ __forceinline__ void mfma_x3_2a(const bf16x8 (&a0)[3], const bf16x8 (&a1)[3], const bf16x8 (&b)[3], f32x4& c0, f32x4& c1) {
 #pragma unroll
     for (int o = 2; o >= 0; --o)
@@ -209,14 +212,17 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
             o[0][r] *= ar;
             o[1][r] *= ar;
         }
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;       // tile-local sums, added to the running O by the VALU (see mfma_x3_2a)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 pa[3], v0[3], v1[3];
             pair_frag_x3(st[2 * t], st[2 * t + 1], pa);
             pair_col_frag_x3(Vp, t, g, i16, v0);
             pair_col_frag_x3(Vp, t, g, 16 + i16, v1);
-            mfma_x3_2b(pa, v0, v1, o[0], o[1]);
+            mfma_x3_2b(pa, v0, v1, t0, t1);
         }
+        o[0] += t0;
+        o[1] += t1;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -306,14 +312,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
                 ds[kb][r] = p * (dp4[r] - del_q);
             }
         }
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 da[3], k0[3], k1[3];
             pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
             pair_col_frag_x3(Kp, t, g, i16, k0);
             pair_col_frag_x3(Kp, t, g, 16 + i16, k1);
-            mfma_x3_2b(da, k0, k1, dq[0], dq[1]);
+            mfma_x3_2b(da, k0, k1, t0, t1);
         }
+        dq[0] += t0;
+        dq[1] += t1;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -387,18 +396,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
                 ds[qb][r] = p[qb][r] * (dp4[r] - del_s[qq]);
             }
         }
+        f32x4 tv0 = {0.f, 0.f, 0.f, 0.f}, tv1 = tv0, tk0 = tv0, tk1 = tv0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 pa[3], da[3], f0[3], f1[3];
             pair_frag_x3(p[2 * t], p[2 * t + 1], pa);
             pair_col_frag_x3(Op, t, g, i16, f0);
             pair_col_frag_x3(Op, t, g, 16 + i16, f1);
-            mfma_x3_2b(pa, f0, f1, dv[0], dv[1]);
+            mfma_x3_2b(pa, f0, f1, tv0, tv1);
             pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
             pair_col_frag_x3(Qp, t, g, i16, f0);
             pair_col_frag_x3(Qp, t, g, 16 + i16, f1);
-            mfma_x3_2b(da, f0, f1, dk[0], dk[1]);
+            mfma_x3_2b(da, f0, f1, tk0, tk1);
         }
+        dv[0] += tv0; dv[1] += tv1;
+        dk[0] += tk0; dk[1] += tk1;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -313,6 +313,13 @@ struct GmmWave {
             issue(nxt, g_cur, it0.k, U + 1);
         }
         if constexpr (X3) {
+            // The six products of a fragment pair are summed in a ZERO-initialised MFMA accumulator and added to the running
+            // accumulator row by the VALU: the bf16 MFMA aligns its 32 products to the exponent of the C operand and truncates
+            // them there (measured, tools/bias_probe.py: -2^-32 |C| per instruction, always towards zero) -- harmless for one
+            // block, but accumulated into the running sum it is a coherent bias that sums over hundreds of thousands of rows do
+            // not average out (weight gradients: 4x larger errors end to end).  Block-local sums truncate relative to the block.
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 t00 = z, t01 = z, t10 = z, t11 = z;
 #pragma unroll
             for (int j = 0; j < JB / 2; ++j) {
                 bf16x8 x0[3];
@@ -321,8 +328,8 @@ struct GmmWave {
                 for (int o = 2; o >= 0; --o)
 #pragma unroll
                     for (int qa = 0; qa <= o; ++qa) {
-                        d00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x0[o - qa], d00, 0, 0, 0);
-                        d01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x0[o - qa], d01, 0, 0, 0);
+                        t00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x0[o - qa], t00, 0, 0, 0);
+                        t01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x0[o - qa], t01, 0, 0, 0);
                     }
             }
             if (two) {
@@ -334,11 +341,13 @@ struct GmmWave {
                     for (int o = 2; o >= 0; --o)
 #pragma unroll
                         for (int qa = 0; qa <= o; ++qa) {
-                            d10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x1[o - qa], d10, 0, 0, 0);
-                            d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x1[o - qa], d11, 0, 0, 0);
+                            t10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x1[o - qa], t10, 0, 0, 0);
+                            t11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x1[o - qa], t11, 0, 0, 0);
                         }
                 }
+                d10 += t10; d11 += t11;
             }
+            d00 += t00; d01 += t01;
         } else if constexpr (BF) {
 #pragma unroll
             for (int j = 0; j < JB / 2; ++j) {

@@ -59,24 +59,32 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64
 
 // ---- fp32 products on the bf16 matrix pipe ("bf16x3") -------------------------------------------------------------------
 // The fp32 MFMAs of gfx950 run at the fp32 VALU rate (157 TFLOP/s, 32 MAC / cycle / SIMD); the bf16 ones at 16x that.  An fp32
-// value splits EXACTLY into three bf16 pieces x = h + m + l (8 significant bits each: h = x truncated to its top 16 bits,
-// m = (x - h) truncated, l = x - h - m; every subtraction is exact), and a product becomes
-//     x y = hx hy + (hx my + mx hy) + (hx ly + mx my + lx hy) + [terms below 2^-23 |x y|, dropped]:
+// value splits EXACTLY into three bf16 pieces x = h + m + l: h = x rounded to 8 significant bits, m = x - h truncated to 8 bits,
+// l = x - h - m; both subtractions are exact and l has at most 8 significant bits, so it is a bf16 value.  A product becomes
+//     x y = hx hy + (hx my + mx hy) + (hx ly + mx my + lx hy) + [mx ly + lx my + lx ly, dropped: ~2^-26 |x y|, either sign]:
 // six bf16 MFMAs (products of 8-bit significands are exact in the fp32 accumulator) instead of sixteen MFMA-equivalents of fp32
-// issue time, with the error of an fp32 FMA chain (tests/test_gpu_kernels.py measures both against fp64).  U3D_FP32_MATH=mfma
-// selects the native fp32 MFMA kernels instead.
+// issue time, with the error of an fp32 FMA chain (tests/test_gpu_kernels.py / test_gpu_model.py measure both modes against
+// fp64, per kernel and end to end).  U3D_FP32_MATH=mfma selects the native fp32 MFMA kernels instead.
 extern int g_fp32_math;
 bool fp32_x3();
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
-// two fp32 values -> one dword per plane (low half: a, high half: b)
+// two fp32 values -> one dword per plane (low half: a, high half: b).  h is x ROUNDED to 8 significant bits (add half an ulp to
+// the bit pattern, clear the low 16 bits: round to nearest, ties away), m is x - h TRUNCATED to 8 bits, l the exact rest:
+// |x - h| <= 2^-8 |x| with either sign, |l| < 2^-7 |x - h|, so the dropped cross terms m.l + l.m are <= 2^-22 of a product in the
+// worst case, ~2^-26 on average, and of either sign -- the level of an fp32 multiply-add's own rounding.  13 VALU instructions
+// per pair.  Measured alternatives (tools/split_rate.hip, SIMD cycles per pair incl. the loop body: 50 / 65 / 65):
+//   * truncating h as well (11 instructions): remainders twice as large and all of the product's sign -- dropped terms up to
+//     2^-20, biased towards zero; 2.5x larger backbone-gradient errors end to end (tests/test_gpu_full_size.py cfg4 over 1e-3);
+//   * v_cvt_pk_bf16_f32 for both levels (round to nearest even, 11 instructions but slower ones), or add-half on both levels
+//     (15): attention +22 %, GEMM +10 % kernel time for errors this variant already brings to the fp32 level.
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned ab = __builtin_bit_cast(unsigned, a), bb = __builtin_bit_cast(unsigned, b);
-    const float a1 = a - __builtin_bit_cast(float, ab & 0xffff0000u), b1 = b - __builtin_bit_cast(float, bb & 0xffff0000u);
+    const unsigned ah = (__builtin_bit_cast(unsigned, a) + 0x8000u) & 0xffff0000u, bh = (__builtin_bit_cast(unsigned, b) + 0x8000u) & 0xffff0000u;
+    const float a1 = a - __builtin_bit_cast(float, ah), b1 = b - __builtin_bit_cast(float, bh);
     const unsigned a1b = __builtin_bit_cast(unsigned, a1), b1b = __builtin_bit_cast(unsigned, b1);
     const float a2 = a1 - __builtin_bit_cast(float, a1b & 0xffff0000u), b2 = b1 - __builtin_bit_cast(float, b1b & 0xffff0000u);
-    h = __builtin_amdgcn_perm(bb, ab, 0x07060302u);
+    h = __builtin_amdgcn_perm(bh, ah, 0x07060302u);
     m = __builtin_amdgcn_perm(b1b, a1b, 0x07060302u);
     l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b2), __builtin_bit_cast(unsigned, a2), 0x07060302u);
 }

@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
                     help="MFMA operand precision of the HEADLINE: fp32 = BASELINE configs[1] (default), bf16 = configs[2] "
                          "(bf16 operands, fp32 accumulate / statistics / optimizer; unidet3d_amd/precision.py)")
+    ap.add_argument('--fp32-math', default=None, choices=['bf16x3', 'mfma'],
+                    help="how the fp32 path forms its products: 'bf16x3' (library default) = three exact bf16 planes per operand, six bf16 "
+                         "MFMAs per product, fp32-level error; 'mfma' = native v_mfma_f32_* (round 1-2 headline kernels)")
     ap.add_argument('--no-cfg3', action='store_true', help='skip the cfg3 block (bf16 operands, 16 scenes/GPU) appended to the fp32 line')
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--voxel-size', type=float, default=0.02)
@@ -196,6 +199,9 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev):
     from unidet3d_amd.synthetic import make_scene
 
     precision.set_operand_dtype(dtype)
+    if getattr(args, 'fp32_math', None):
+        precision.set_fp32_math(args.fp32_math)
+    x3 = dtype == 'fp32' and precision.get_fp32_math() == 'bf16x3'
     torch.manual_seed(0)
     model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)
     model.train()
@@ -292,6 +298,11 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev):
     # which MFMA peak prices a family: the bf16-operand kernels exist for the sparse conv forward / input gradient, the
     # decoder's NT GEMMs and attention; weight gradients keep fp32 operands below 64x64 channels
     peak = {k: (PEAK_BF16_MFMA_TFLOPS if bf and k in ('conv_gmm', 'attn_fwd', 'attn_bwd') else PEAK_F32_MFMA_TFLOPS) for k in prof}
+    # fp32 math from three bf16 planes: the instructions that run are bf16 MFMAs, six per fp32-equivalent product, so the hardware
+    # ceiling of those kernels is the bf16 dense peak / 6; `frac` stays priced against the dtype's own (fp32) MFMA peak so that it is
+    # comparable across rounds and modes, the second fraction is reported next to it (weight gradients below 160 channels and the
+    # 16-channel input convolution stay on fp32 MFMAs)
+    x3_ceiling = PEAK_BF16_MFMA_TFLOPS / 6.0
     kernels = {}
     for k, v in prof.items():
         t = v['ms'] * 1e-3
@@ -301,6 +312,7 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev):
                       'algorithmic_gflop_per_step': v['flops'] / prof_steps / 1e9, 'algorithmic_MB_per_step': v['bytes'] / prof_steps / 1e6,
                       'tflops': tf, 'mfma_peak': peak[k] if k != 'gemm' else ('mixed' if bf else PEAK_F32_MFMA_TFLOPS),
                       'frac_mfma': (tf / peak[k] if tf and (k != 'gemm' or not bf) else None),
+                      **({'bf16x3_ceiling': x3_ceiling, 'frac_bf16x3_ceiling': tf / x3_ceiling} if x3 and tf and k != 'conv_wgrad' else {}),
                       'hbm_gbs': gbs, 'frac_hbm': gbs / PEAK_HBM_GBS if gbs else None}
     g = prof['conv_gmm']
     ach = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
@@ -314,16 +326,21 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev):
         'config': {'workload': f'{"cfg3" if bf else "cfg2"}: {batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
                                f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, '
                                + ('bf16 MFMA operands (sparse conv fwd/dgrad/wgrad, Linear fwd/dX/dW, attention), fp32 accumulate/BN/softmax/optimizer; '
-                                  if bf else 'fp32; ') +
+                                  if bf else ('fp32 (products from three exact bf16 planes per operand on the bf16 matrix pipe, fp32 accumulation, '
+                                              'fp32-level error; --fp32-math mfma = native fp32 MFMAs); ' if x3 else 'fp32 (native fp32 MFMAs); ')) +
                                'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else f'+clip+{args.optimizer}')
                                + ('' if args.no_prefetch else "; each step's voxelise+rulebook part is queued on a side stream during "
                                   "the previous step's backward"),
-                   'front_prefetch': not args.no_prefetch,
+                   'front_prefetch': not args.no_prefetch, 'fp32_math': ('bf16x3' if x3 else 'mfma') if not bf else None,
                    'global_batch': batch * world, 'points_per_scene': args.points,
                    'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val, 'warmup_losses': warm_losses},
         'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
                      'bound': 'mfma', 'achieved': ach, 'peak': peak['conv_gmm'], 'unit': 'TFLOP/s',
-                     'frac': ach / peak['conv_gmm'], 'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
+                     'frac': ach / peak['conv_gmm'],
+                     **({'math': 'bf16x3: six v_mfma_f32_16x16x32_bf16 per fp32-equivalent product; peak is the fp32 dense MFMA peak (the dtype\'s), '
+                                 'instruction_peak the ceiling of the instructions that run (bf16 dense peak / 6)',
+                         'instruction_peak': x3_ceiling, 'frac_of_instruction_peak': ach / x3_ceiling} if x3 else {}),
+                     'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
                      'traffic_source': traffic_src,
                      'algorithmic_bytes_per_launch': g['bytes'] / max(g['launches'], 1),
                      'hbm_achieved_gbs': kernels['conv_gmm']['hbm_gbs'], 'hbm_frac': kernels['conv_gmm']['frac_hbm'],

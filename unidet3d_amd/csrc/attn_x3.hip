@@ -32,9 +32,10 @@ constexpr int XP = 32 * XPD;             // dwords per pair plane
 
 // c += a . b with both operands in three planes takes h.l, m.m, l.h, h.m, m.h, h.h (smallest terms first);
 // two independent accumulators side by side (dependent MFMAs wait for their predecessor; alternating chains fills the gaps).
-// The accumulators handed in are tile-local (zero at the start of a key tile); the running sums O / dQ / dK / dV are updated by
-// VALU adds once per tile: a bf16 MFMA truncates its products at the C operand's exponent, always towards zero
-// (tools/bias_probe.py), which is harmless inside a tile but a coherent bias when it hits a running sum 30 times per row.
+// A bf16 MFMA truncates its 32 products at the exponent of its C operand, always towards zero: plane products 2^-8 .. 2^-16 below
+// a running sum lose their low bits every time -- a coherent bias (tools/bias_probe.py: -1.2e-8 mean error after 8 blocks, zero
+// for fp32 MFMAs) that reductions over thousands of rows downstream do not average out.  So chains that start from zero (S, dP)
+// run smallest terms first, and the running sums O / dQ / dK / dV keep the low-order products in accumulators of their own.
 __device__ __forceinline__ void mfma_x3_2a(const bf16x8 (&a0)[3], const bf16x8 (&a1)[3], const bf16x8 (&b)[3], f32x4& c0, f32x4& c1) {
 #pragma unroll
     for (int o = 2; o >= 0; --o)
@@ -44,14 +45,19 @@ __device__ __forceinline__ void mfma_x3_2a(const bf16x8 (&a0)[3], const bf16x8 (
             c1 = U3D_MFMA_X(a1[qa], b[o - qa], c1);
         }
 }
-__device__ __forceinline__ void mfma_x3_2b(const bf16x8 (&a)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], f32x4& c0, f32x4& c1) {
+// running sums: the h.h product goes to (c0, c1), the five low-order plane products to their own accumulators (l0, l1), joined
+// once at the end of the kernel
+__device__ __forceinline__ void mfma_x3_2b(const bf16x8 (&a)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], f32x4& c0, f32x4& c1,
+                                           f32x4& l0, f32x4& l1) {
 #pragma unroll
-    for (int o = 2; o >= 0; --o)
+    for (int o = 2; o >= 1; --o)
 #pragma unroll
         for (int qa = 0; qa <= o; ++qa) {
-            c0 = U3D_MFMA_X(a[qa], b0[o - qa], c0);
-            c1 = U3D_MFMA_X(a[qa], b1[o - qa], c1);
+            l0 = U3D_MFMA_X(a[qa], b0[o - qa], l0);
+            l1 = U3D_MFMA_X(a[qa], b1[o - qa], l1);
         }
+    c0 = U3D_MFMA_X(a[0], b0[0], c0);
+    c1 = U3D_MFMA_X(a[0], b1[0], c1);
 }
 
 // Stage 64 rows x 32 floats of `base` (rows >= len are zero, values scaled before the split): thread (p = tid >> 3, c = tid & 7)
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
     bf16x8 qf[3];                                // scores in log2 units: q carries scale * log2(e)
     row_frag_x3(qrow < len ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
     float m = -INFINITY, l = 0.f;
-    f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // h.h | low-order products
     const int ntiles = (len + 63) >> 6;
     StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -211,19 +217,20 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
             const float ar = __shfl(alpha, g * 4 + r, 64);
             o[0][r] *= ar;
             o[1][r] *= ar;
+            ol[0][r] *= ar;
+            ol[1][r] *= ar;
         }
-        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;       // tile-local sums, added to the running O by the VALU (see mfma_x3_2a)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 pa[3], v0[3], v1[3];
             pair_frag_x3(st[2 * t], st[2 * t + 1], pa);
             pair_col_frag_x3(Vp, t, g, i16, v0);
             pair_col_frag_x3(Vp, t, g, 16 + i16, v1);
-            mfma_x3_2b(pa, v0, v1, t0, t1);
+            mfma_x3_2b(pa, v0, v1, o[0], o[1], ol[0], ol[1]);
         }
-        o[0] += t0;
-        o[1] += t1;
     }
+    o[0] += ol[0];
+    o[1] += ol[1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float lr = __shfl(l, g * 4 + r, 64);
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     // log2 units; rows past the end get +inf so that exp2(s - lse) = 0 masks them without a select per element
     const float lse_q = qok ? lse[(int64_t)h * n_total + start + qrow] * X_LOG2E : INFINITY;
     const float del_q = qok ? delta[(int64_t)h * n_total + start + qrow] : 0.f;
-    f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dql[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
     StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -312,18 +319,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
                 ds[kb][r] = p * (dp4[r] - del_q);
             }
         }
-        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 da[3], k0[3], k1[3];
             pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
             pair_col_frag_x3(Kp, t, g, i16, k0);
             pair_col_frag_x3(Kp, t, g, 16 + i16, k1);
-            mfma_x3_2b(da, k0, k1, t0, t1);
+            mfma_x3_2b(da, k0, k1, dq[0], dq[1], dql[0], dql[1]);
         }
-        dq[0] += t0;
-        dq[1] += t1;
     }
+    dq[0] += dql[0];
+    dq[1] += dql[1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = q0 + wave * 16 + g * 4 + r;
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
     row_frag_x3(krow < len ? base + (int64_t)krow * ld + D + g * 8 : nullptr, 1.f, kf);
     row_frag_x3(krow < len ? base + (int64_t)krow * ld + 2 * D + g * 8 : nullptr, 1.f, vf);
     f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 dkl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dvl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // low-order plane products
     const int ntiles = (len + 63) >> 6;
     StageRegs rq = load_x3(base, ld, 0, len, tid), ro = load_x3(dobase, D, 0, len, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
@@ -396,22 +403,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
                 ds[qb][r] = p[qb][r] * (dp4[r] - del_s[qq]);
             }
         }
-        f32x4 tv0 = {0.f, 0.f, 0.f, 0.f}, tv1 = tv0, tk0 = tv0, tk1 = tv0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 pa[3], da[3], f0[3], f1[3];
             pair_frag_x3(p[2 * t], p[2 * t + 1], pa);
             pair_col_frag_x3(Op, t, g, i16, f0);
             pair_col_frag_x3(Op, t, g, 16 + i16, f1);
-            mfma_x3_2b(pa, f0, f1, tv0, tv1);
+            mfma_x3_2b(pa, f0, f1, dv[0], dv[1], dvl[0], dvl[1]);
             pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
             pair_col_frag_x3(Qp, t, g, i16, f0);
             pair_col_frag_x3(Qp, t, g, 16 + i16, f1);
-            mfma_x3_2b(da, f0, f1, tk0, tk1);
+            mfma_x3_2b(da, f0, f1, dk[0], dk[1], dkl[0], dkl[1]);
         }
-        dv[0] += tv0; dv[1] += tv1;
-        dk[0] += tk0; dk[1] += tk1;
     }
+    dv[0] += dvl[0]; dv[1] += dvl[1];
+    dk[0] += dkl[0]; dk[1] += dkl[1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = k0 + wave * 16 + g * 4 + r;

@@ -327,6 +327,17 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_k(const float* __restrict__ A,
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // The five low-order plane products accumulate in their OWN running tile `lo`, added to `acc` once at the end: a bf16 MFMA
+    // truncates its 32 products at the exponent of its C operand, always towards zero (tools/bias_probe.py: -1.2e-8 mean error
+    // at K = 256 with everything in one tile -- a coherent bias that reductions over many rows downstream do not average out);
+    // products 2^-8 .. 2^-16 below the running sum lose the most, against their own small tile they lose nothing that matters.
+    f32x16 lo[TA][NB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lo[a][b][r] = 0.f;
     const int nk = K / GKH;
 #ifdef U3D_NTX_TRACE          // phase timestamps of wave 0 (tools/trace_gemm.py; `pre` is the trace buffer, EPI 0 only)
     uint64_t tr_[12];
@@ -364,7 +375,8 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_k(const float* __restrict__ A,
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
                             if constexpr (U3D_NTX_ABL & 1) { if (o == 2 && qa == 0) acc[a][b][0] += (float)af[0][a][0] + (float)af[1][a][1] + (float)af[2][a][2] + (float)bf[0][b][0] + (float)bf[1][b][1] + (float)bf[2][b][2]; }
-                            else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], acc[a][b], 0, 0, 0);
+                            else if (o == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], acc[a][b], 0, 0, 0);
+                            else lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], lo[a][b], 0, 0, 0);
                         }
         }
         if (kt + 1 < nk) split();                  // stage kt+1 (loaded one iteration ago)
@@ -379,6 +391,10 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_k(const float* __restrict__ A,
         U3D_TRK(7);
     }
     U3D_TR(8);
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] += lo[a][b];
     nt_epilogue<TN, EPI, TM>(acc, C, bias, aux, pre, m0, n0, rows_a, N, wr, wc, i32, kh);
 #ifdef U3D_NTX_TRACE
     if constexpr (EPI == 0) {
@@ -577,6 +593,13 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_k(const float* __restrict__ A,
         for (int b = 0; b < NF; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x16 lo[NF][NF];                              // low-order plane products, see gemm_nt_x3_k
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < NF; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lo[a][b][r] = 0.f;
     const int nt = (rows + ROWS - 1) / ROWS;
     if (nt > 0) {
         gload(0);
@@ -603,12 +626,18 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_k(const float* __restrict__ A,
 #pragma unroll
                     for (int a = 0; a < NF; ++a)
 #pragma unroll
-                        for (int b = 0; b < NF; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], acc[a][b], 0, 0, 0);
+                        for (int b = 0; b < NF; ++b) {
+                            if (o == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], acc[a][b], 0, 0, 0);
+                            else lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], lo[a][b], 0, 0, 0);
+                        }
         }
         if (t + 1 < nt) lstore(buf ^ 1);
         __syncthreads();
     }
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < NF; ++b) acc[a][b] += lo[a][b];
     const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)split * pstride, (int64_t)N * K * 4);
 #pragma unroll
@@ -830,18 +859,23 @@ static void launch_nt(const float* A, const float* W, const float* bias, float* 
     const double over[3] = {1.0, 1.04, 1.08};
     int best = 0;
     double best_t = 0.0;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = x3 ? 1 : 0; c < 3; ++c) {         // bf16x3: 128 x 64 at most -- the low-order tile doubles the accumulator registers
         const int64_t wgs = ceil_div(M, tm[c]) * ceil_div(N, tn[c]);
         const double t = (double)ceil_div(wgs, 256) * tm[c] * tn[c] * over[c];
-        if (c == 0 || t < best_t) { best = c; best_t = t; }
+        if (c == (x3 ? 1 : 0) || t < best_t) { best = c; best_t = t; }
     }
     if (force >= 1 && force <= 3) best = force - 1;
+    if (x3 && best == 0) best = 1;
     const dim3 grid((unsigned)(ceil_div(M, tm[best]) * ceil_div(N, tn[best])));       // (row tile, column tile) decoded in the kernel
 #define U3D_NT_LAUNCH(KERNEL)                                                                                                          \
     if (best == 0) hipLaunchKernelGGL((KERNEL<128, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);                \
     else if (best == 1) hipLaunchKernelGGL((KERNEL<64, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);            \
     else hipLaunchKernelGGL((KERNEL<64, EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
-    if (bf16_operands) { U3D_NT_LAUNCH(gemm_nt_bf16_k) } else if (x3) { U3D_NT_LAUNCH(gemm_nt_x3_k) } else { U3D_NT_LAUNCH(gemm_nt_k) }
+    if (bf16_operands) { U3D_NT_LAUNCH(gemm_nt_bf16_k) }
+    else if (x3) {
+        if (best == 1) hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+        else hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    } else { U3D_NT_LAUNCH(gemm_nt_k) }
 #undef U3D_NT_LAUNCH
 }
 
@@ -923,6 +957,7 @@ int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W
 
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) {
     // the fp32 and the bf16 kernel pick their split counts independently (U3D_TN_WGS moves only the former): size for the larger
+    // (the bf16x3 kernel's 64 x 64 tiles never need more splits than the tilings below)
     const int s32 = tn_splits(M, N, K, GT, false), s32b = tn_splits(M, N, K, tn_tile(N, K), false), s16 = tn_splits(M, N, K, GT, true);
     const int smax = s32 > s16 ? (s32 > s32b ? s32 : s32b) : (s16 > s32b ? s16 : s32b);
     return (int64_t)(smax + 8) * ((int64_t)N * K + N) * 4 + 256;       // + 8: the fp32 grid is padded to whole groups of 8 splits
@@ -934,7 +969,10 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     if (N % 4 || K % 4) { set_error("gemm_tn: N=%d, K=%d must be multiples of 4", N, K); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
-    const int S = tn_splits(M, N, K, bf ? GT : tn_tile(N, K), bf);
+    const bool x3 = !bf && fp32_x3();
+    // bf16x3: 64 x 64 tiles only (the low-order accumulator tile doubles the accumulator registers: 128 x 128 would not fit two waves per SIMD)
+    const int T = bf ? GT : (x3 ? 64 : tn_tile(N, K));
+    const int S = tn_splits(M, N, K, T, bf);
     const int64_t rps = ceil_div(ceil_div(M, S), GK) * GK;
     if ((int64_t)(rps + 2 * GK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + 2 * GK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
         set_error("gemm_tn: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
@@ -942,12 +980,9 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     }
     if (bf) hipLaunchKernelGGL(gemm_tn_bf16_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
     else {
-        const int T = tn_tile(N, K);
         const unsigned grid = (unsigned)(ceil_div(S, 8) * 8 * ceil_div(N, T) * ceil_div(K, T));       // whole groups of 8 splits
-        if (fp32_x3()) {
-            if (T == 64) hipLaunchKernelGGL(gemm_tn_x3_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
-            else hipLaunchKernelGGL(gemm_tn_x3_k<GT>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
-        } else if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+        if (x3) hipLaunchKernelGGL(gemm_tn_x3_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+        else if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
         else hipLaunchKernelGGL(gemm_tn_k<GT>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
     }
     const int64_t n4_main = (int64_t)N * K / 4, n4 = n4_main + (colsum_A ? N / 4 : 0);

@@ -313,11 +313,12 @@ struct GmmWave {
             issue(nxt, g_cur, it0.k, U + 1);
         }
         if constexpr (X3) {
-            // The six products of a fragment pair are summed in a ZERO-initialised MFMA accumulator and added to the running
-            // accumulator row by the VALU: the bf16 MFMA aligns its 32 products to the exponent of the C operand and truncates
-            // them there (measured, tools/bias_probe.py: -2^-32 |C| per instruction, always towards zero) -- harmless for one
-            // block, but accumulated into the running sum it is a coherent bias that sums over hundreds of thousands of rows do
-            // not average out (weight gradients: 4x larger errors end to end).  Block-local sums truncate relative to the block.
+            // The h.h product of a fragment pair accumulates straight into the running row (the MFMA's C operand), the five
+            // low-order plane products into a ZERO-initialised accumulator that the VALU adds at the end of the unit: the bf16
+            // MFMA aligns its 32 products to the exponent of its C operand and truncates them there, always towards zero
+            // (tools/bias_probe.py), so products 2^-8 .. 2^-16 below a running sum lose low bits on every instruction -- a
+            // coherent bias that sums over hundreds of thousands of rows (weight gradients, batch-norm statistics) do not
+            // average out: 4x larger gradient errors end to end.  Against their own sum they lose nothing that matters.
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             f32x4 t00 = z, t01 = z, t10 = z, t11 = z;
 #pragma unroll
@@ -325,12 +326,14 @@ struct GmmWave {
                 bf16x8 x0[3];
                 split3_x8(f0.v[2 * j], f0.v[2 * j + 1], x0);
 #pragma unroll
-                for (int o = 2; o >= 0; --o)
+                for (int o = 2; o >= 1; --o)
 #pragma unroll
                     for (int qa = 0; qa <= o; ++qa) {
                         t00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x0[o - qa], t00, 0, 0, 0);
                         t01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x0[o - qa], t01, 0, 0, 0);
                     }
+                d00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][0]), x0[0], d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][0]), x0[0], d01, 0, 0, 0);
             }
             if (two) {
 #pragma unroll
@@ -338,12 +341,14 @@ struct GmmWave {
                     bf16x8 x1[3];
                     split3_x8(f1.v[2 * j], f1.v[2 * j + 1], x1);
 #pragma unroll
-                    for (int o = 2; o >= 0; --o)
+                    for (int o = 2; o >= 1; --o)
 #pragma unroll
                         for (int qa = 0; qa <= o; ++qa) {
                             t10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][qa]), x1[o - qa], t10, 0, 0, 0);
                             t11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][qa]), x1[o - qa], t11, 0, 0, 0);
                         }
+                    d10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2][0]), x1[0], d10, 0, 0, 0);
+                    d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.b[j * 2 + 1][0]), x1[0], d11, 0, 0, 0);
                 }
                 d10 += t10; d11 += t11;
             }

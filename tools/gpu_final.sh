@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end evidence on one MI355X: full -m gpu suite (log + parity errors kept), default bench line (fp32 headline + cfg3 block +
-# cpu baseline), rocprofv3 kernel stats of the fp32 and bf16 bench, PMC traffic of the bench step.  usage: tools/gpu_final.sh <tag>
+# cpu baseline), the same fp32 line with the native fp32 MFMA kernels (--fp32-math mfma), rocprofv3 kernel stats of the fp32 and bf16 bench, PMC traffic of the bench step.  usage: tools/gpu_final.sh <tag>
 TAG=${1:-final}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
 rm -f gpurun_out/parity_errors.jsonl
 T0=$(date +%s)
@@ -17,6 +17,9 @@ c = d.get('cfg3')
 if c: print('cfg3:', round(c['value'], 1), round(c['ms_per_step'], 2), {k: round(v['ms_per_step'], 2) for k, v in c['kernels'].items()})
 print('cpu:', d.get('cpu_baseline', {}).get('value'), 'traffic:', d['roofline']['traffic'])
 PY
+timeout 300 python bench.py --fp32-math mfma --no-cfg3 --no-cpu-baseline > $OUT/bench_fp32_mfma.json 2>> $OUT/bench.log
+python -c "
+import json; d = json.load(open('$OUT/bench_fp32_mfma.json')); print('fp32 with native fp32 MFMAs:', round(d['value'], 1), round(d['ms_per_step'], 2), {k: round(v['ms_per_step'], 2) for k, v in d['kernels'].items()})"
 echo "t=$(( $(date +%s) - T0 ))s"
 bash tools/gpu_prof.sh ${TAG}_prof > $OUT/prof.log 2>&1; grep -E "GPU busy|steps in" $OUT/prof.log
 echo "t=$(( $(date +%s) - T0 ))s"

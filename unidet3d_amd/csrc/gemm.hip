@@ -528,146 +528,6 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
     if (sums && n0 + tid < N) partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = csum;
 }
 
-// gemm_tn_k with the fp32 products on the bf16 pipe (u3d_common.h, "bf16x3").  The reduction index is the ROW index of both
-// operands, and an MFMA lane wants 8 consecutive reduction elements in one register vector: the staging thread therefore loads
-// the same four columns of TWO consecutive rows and split3_pair() packs them into one dword per plane (low half: even row), so
-// the LDS tile is [row pair][column] dwords per plane and a fragment is four ds_read_b32 (conflict free: LD = T + 8 puts the two
-// half-waves, 4 row pairs apart, on disjoint banks).  Grid, split placement, partial layout and column sums as in gemm_tn_k.
-template <int T>
-__global__ __launch_bounds__(256) void gemm_tn_x3_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
-                                                    int colsum, int64_t M, int N, int K, int64_t rows_per_split, int S) {
-    const int tiles_n = (N + T - 1) / T, tiles = tiles_n * ((K + T - 1) / T);
-    const int slot = blockIdx.x >> 3, tile = slot % tiles;
-    const int split = (slot / tiles) * 8 + (blockIdx.x & 7);
-    if (split >= S) return;
-    constexpr int LD = T + 8;                   // dwords per row pair
-    constexpr int NF = T / 64;
-    constexpr int TPR = T / 4;                  // staging threads per row pair (float4 of each of its rows)
-    constexpr int RP = 256 / TPR;               // row pairs per stage: 8 (T = 128) / 16 (T = 64)
-    constexpr int KB = RP / 8;                  // 16-deep MFMA blocks per stage
-    constexpr int ROWS = RP * 2;
-    __shared__ __attribute__((aligned(16))) unsigned As[2][3][RP * LD];
-    __shared__ __attribute__((aligned(16))) unsigned Bs[2][3][RP * LD];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
-    const int n0 = (tile % tiles_n) * T, k0 = (tile / tiles_n) * T;
-    const int64_t mlo = (int64_t)split * rows_per_split;
-    const int64_t mhi = min(M, mlo + rows_per_split);
-    const int rows = (int)max((int64_t)0, mhi - mlo);
-    const int sp = tid / TPR, sc4 = tid % TPR;
-    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + mlo * N, (int64_t)rows * N * 4);
-    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + mlo * K, (int64_t)rows * K * 4);
-    const int va = n0 + sc4 * 4 < N ? (2 * sp * N + n0 + sc4 * 4) * 4 : 0x7fffffff;
-    const int vb = k0 + sc4 * 4 < K ? (2 * sp * K + k0 + sc4 * 4) * 4 : 0x7fffffff;
-    const bool ca = va != 0x7fffffff, cb = vb != 0x7fffffff;
-    f32x4 ra[2], rb[2];
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            ra[j] = bload128(rs_a, ca ? va + j * N * 4 : va, t * (ROWS * N * 4));
-            rb[j] = bload128(rs_b, cb ? vb + j * K * 4 : vb, t * (ROWS * K * 4));
-        }
-    };
-    auto lstore = [&](int buf) {
-        cs += ra[0] + ra[1];
-        unsigned w[3][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) split3_pair(ra[0][c], ra[1][c], w[0][c], w[1][c], w[2][c]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&As[buf][q][sp * LD + sc4 * 4]) = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) split3_pair(rb[0][c], rb[1][c], w[0][c], w[1][c], w[2][c]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&Bs[buf][q][sp * LD + sc4 * 4]) = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
-    };
-    auto frag = [&](const unsigned* t, int pair0, int col) {
-        const unsigned* q = t + pair0 * LD + col;
-        return __builtin_bit_cast(bf16x8, u32x4{q[0], q[LD], q[2 * LD], q[3 * LD]});
-    };
-    f32x16 acc[NF][NF];
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-#pragma unroll
-        for (int b = 0; b < NF; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    f32x16 lo[NF][NF];                              // low-order plane products, see gemm_nt_x3_k
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-#pragma unroll
-        for (int b = 0; b < NF; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lo[a][b][r] = 0.f;
-    const int nt = (rows + ROWS - 1) / ROWS;
-    if (nt > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            bf16x8 af[3][NF], bf[3][NF];
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int u = 0; u < NF; ++u) {
-                    af[q][u] = frag(As[buf][q], kb * 8 + kh * 4, wr * (T / 2) + u * 32 + i32);
-                    bf[q][u] = frag(Bs[buf][q], kb * 8 + kh * 4, wc * (T / 2) + u * 32 + i32);
-                }
-#pragma unroll
-            for (int o = 2; o >= 0; --o)
-#pragma unroll
-                for (int qa = 0; qa <= o; ++qa)
-#pragma unroll
-                    for (int a = 0; a < NF; ++a)
-#pragma unroll
-                        for (int b = 0; b < NF; ++b) {
-                            if (o == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], acc[a][b], 0, 0, 0);
-                            else lo[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][a], bf[o - qa][b], lo[a][b], 0, 0, 0);
-                        }
-        }
-        if (t + 1 < nt) lstore(buf ^ 1);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-#pragma unroll
-        for (int b = 0; b < NF; ++b) acc[a][b] += lo[a][b];
-    const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
-    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)split * pstride, (int64_t)N * K * 4);
-#pragma unroll
-    for (int b = 0; b < NF; ++b) {
-        const int k = k0 + wc * (T / 2) + b * 32 + i32;
-        const int vo = k < K ? ((n0 + 4 * kh) * K + k) * 4 : 0x7fffffff;        // rows past N fall off the end of the descriptor
-#pragma unroll
-        for (int a = 0; a < NF; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * (T / 2) + a * 32 + (r & 3) + 8 * (r >> 2);
-                float v = acc[a][b][r];
-                asm volatile("" : "+v"(v));
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, row * K * 4, 0);
-            }
-    }
-    if (colsum && k0 == 0) {                    // column sums of A (the bias gradient): the staging threads' fp32 sums, added over the row pairs
-        float* cs_s = reinterpret_cast<float*>(&As[0][0][0]);          // [RP][T] floats fit in the first plane buffer (LD > T)
-        __syncthreads();
-        *reinterpret_cast<f32x4*>(&cs_s[sp * LD + sc4 * 4]) = cs;
-        __syncthreads();
-        if (tid < T && n0 + tid < N) {
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < RP; ++r) v += cs_s[r * LD + tid];
-            partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = v;
-        }
-    }
-}
-
 // bf16-operand form of gemm_tn_k (weight gradients of the Linear layers under BASELINE configs[2]): A (= dY) and B (= X) are
 // rounded to bf16 while they are staged, the reduction over the M rows runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 // The reduction index is the ROW index of both operands, so a lane's 8 consecutive k values are a COLUMN of the staged
@@ -957,7 +817,6 @@ int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W
 
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) {
     // the fp32 and the bf16 kernel pick their split counts independently (U3D_TN_WGS moves only the former): size for the larger
-    // (the bf16x3 kernel's 64 x 64 tiles never need more splits than the tilings below)
     const int s32 = tn_splits(M, N, K, GT, false), s32b = tn_splits(M, N, K, tn_tile(N, K), false), s16 = tn_splits(M, N, K, GT, true);
     const int smax = s32 > s16 ? (s32 > s32b ? s32 : s32b) : (s16 > s32b ? s16 : s32b);
     return (int64_t)(smax + 8) * ((int64_t)N * K + N) * 4 + 256;       // + 8: the fp32 grid is padded to whole groups of 8 splits
@@ -969,9 +828,12 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     if (N % 4 || K % 4) { set_error("gemm_tn: N=%d, K=%d must be multiples of 4", N, K); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
-    const bool x3 = !bf && fp32_x3();
-    // bf16x3: 64 x 64 tiles only (the low-order accumulator tile doubles the accumulator registers: 128 x 128 would not fit two waves per SIMD)
-    const int T = bf ? GT : (x3 ? 64 : tn_tile(N, K));
+    // The fp32 weight gradients stay on the native fp32 MFMA kernel in both fp32 math modes: a three-plane bf16 form (pair-packed
+    // planes, ds_read_b32 fragments) was built and measured -- 64 x 64 tiles 45 us against 45 us, 128 x 128 tiles 58 against 79 us
+    // but only with all six plane products in one accumulator, i.e. with the truncation bias of the bf16 MFMA (u3d_common.h) in a
+    // sum over 17 k rows; with the low-order products in a tile of their own 128 x 128 no longer fits two waves per SIMD
+    // (268 registers) and 64 x 64 everywhere cost 2.24 ms/step against 1.9 ms for this kernel.  Removed again.
+    const int T = bf ? GT : tn_tile(N, K);
     const int S = tn_splits(M, N, K, T, bf);
     const int64_t rps = ceil_div(ceil_div(M, S), GK) * GK;
     if ((int64_t)(rps + 2 * GK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + 2 * GK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
@@ -981,8 +843,7 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     if (bf) hipLaunchKernelGGL(gemm_tn_bf16_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
     else {
         const unsigned grid = (unsigned)(ceil_div(S, 8) * 8 * ceil_div(N, T) * ceil_div(K, T));       // whole groups of 8 splits
-        if (x3) hipLaunchKernelGGL(gemm_tn_x3_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
-        else if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+        if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
         else hipLaunchKernelGGL(gemm_tn_k<GT>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
     }
     const int64_t n4_main = (int64_t)N * K / 4, n4 = n4_main + (colsum_A ? N / 4 : 0);

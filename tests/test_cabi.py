@@ -69,3 +69,30 @@ def test_index_words_bounds():
     assert lib.u3d_index_words(1, 128, 128, 65) == 128 * 128 * 2
     assert lib.u3d_index_words(0, 128, 128, 128) < 0
     assert lib.u3d_index_words(8, 100_000, 100_000, 4096) < 0 and b'extent too large' in lib.u3d_last_error()
+
+
+def test_fp32_math_switch_is_host_state_and_drives_the_conv_format():
+    """u3d_fp32_math is pure host state (no GPU needed): default = three-plane bf16 products unless U3D_FP32_MATH=mfma, any other
+    argument only queries, and the Python layer picks the sparse-conv entry point / packed-weight layout from it
+    (precision.conv_format; the packed layout belongs to the entry point, so the library does not switch it silently)."""
+    from unidet3d_amd import _lib as L
+    from unidet3d_amd import precision as P
+    lib = L.lib()
+    default = 0 if os.environ.get('U3D_FP32_MATH') == 'mfma' else 1
+    prev = P.get_fp32_math()
+    try:
+        P.set_fp32_math('bf16x3' if default else 'mfma')
+        assert lib.u3d_fp32_math(-1) == default and lib.u3d_fp32_math(7) == default       # queries
+        with P.fp32_math('mfma'):
+            assert lib.u3d_fp32_math(-1) == 0 and P.get_fp32_math() == 'mfma' and P.conv_format() == P.FMT_FP32
+            with P.fp32_math('bf16x3'):
+                assert lib.u3d_fp32_math(-1) == 1 and P.conv_format() == P.FMT_X3
+                with P.operands('bf16'):
+                    assert P.conv_format() == P.FMT_BF16                                   # bf16 operands win over the fp32 math mode
+            assert P.get_fp32_math() == 'mfma'
+        with pytest.raises(ValueError):
+            P.set_fp32_math('tf32')
+    finally:
+        P.set_fp32_math(prev)
+    from unidet3d_amd import sparse
+    assert [sparse._pack_floats(96, f) for f in (0, 1, 2)] == [96, 48, 144]               # fp32 | bf16 | three bf16 planes

@@ -323,9 +323,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
 }
 
 void attn_fwd_x3_launch(const float* qkv, const int32_t* cu, int B, int max_len, int64_t n_total, int H, float scale, float* out, float* lse,
-                        hipStream_t s);
+                        hipStream_t s, int planes);
 void attn_bwd_x3_launch(const float* qkv, const float* out, const float* dout, const float* lse, const int32_t* cu, int B, int max_len,
-                        int64_t n_total, int H, float scale, float* dqkv, float* delta_ws, hipStream_t s);
+                        int64_t n_total, int H, float scale, float* dqkv, float* delta_ws, hipStream_t s, int planes);
 
 }  // namespace u3d
 
@@ -341,7 +341,7 @@ int u3d_attn_varlen_fwd(const float* qkv, const int32_t* cu_seqlens, int B, int 
     ProfScope prof(U3D_K_ATTN_FWD, s, flops_hint);
     if (max_len <= 0) return U3D_OK;
     if (fp32_x3()) {                       // default: fp32 products from three bf16 planes (attn_x3.hip)
-        attn_fwd_x3_launch(qkv, cu_seqlens, B, max_len, n_total, H, scale, out, lse, s);
+        attn_fwd_x3_launch(qkv, cu_seqlens, B, max_len, n_total, H, scale, out, lse, s, 3);
         return check_launch("attn_fwd_x3");
     }
     const int n_tiles = (max_len + 63) / 64;
@@ -358,7 +358,7 @@ int u3d_attn_varlen_bwd(const float* qkv, const float* out, const float* dout, c
     ProfScope prof(U3D_K_ATTN_BWD, s, flops_hint);
     if (max_len <= 0) return U3D_OK;
     if (fp32_x3()) {
-        attn_bwd_x3_launch(qkv, out, dout, lse, cu_seqlens, B, max_len, n_total, H, scale, dqkv, delta_ws, s);
+        attn_bwd_x3_launch(qkv, out, dout, lse, cu_seqlens, B, max_len, n_total, H, scale, dqkv, delta_ws, s, 3);
         return check_launch("attn_bwd_x3");
     }
     hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, out, dout, n_total, H, delta_ws);

@@ -16,6 +16,8 @@
 //       pipe level with the matrix pipe).  Slots are XOR-swizzled by the dim group so that the dword stores of the staging
 //       threads (8 threads x the same slot) spread over the banks; 40-dword columns keep the 16-byte reads conflict-free.
 // The backward kernels use the same two layouts in both orientations; tiles that are read both ways are staged in both.
+// The kernels are templates over the number of planes: NP = 3 is the fp32 path above, NP = 1 the bf16-operand form of
+// BASELINE configs[2] (one bf16 value per operand, rounded to nearest even; u3d_attn_varlen_*_bf16 at the end of the file).
 #include "u3d_common.h"
 
 namespace u3d {
@@ -36,9 +38,10 @@ constexpr int XP = 32 * XPD;             // dwords per pair plane
 // a running sum lose their low bits every time -- a coherent bias (tools/bias_probe.py: -1.2e-8 mean error after 8 blocks, zero
 // for fp32 MFMAs) that reductions over thousands of rows downstream do not average out.  So chains that start from zero (S, dP)
 // run smallest terms first, and the running sums O / dQ / dK / dV keep the low-order products in accumulators of their own.
-__device__ __forceinline__ void mfma_x3_2a(const bf16x8 (&a0)[3], const bf16x8 (&a1)[3], const bf16x8 (&b)[3], f32x4& c0, f32x4& c1) {
+template <int NP>
+__device__ __forceinline__ void mfma_x3_2a(const bf16x8 (&a0)[NP], const bf16x8 (&a1)[NP], const bf16x8 (&b)[NP], f32x4& c0, f32x4& c1) {
 #pragma unroll
-    for (int o = 2; o >= 0; --o)
+    for (int o = NP - 1; o >= 0; --o)
 #pragma unroll
         for (int qa = 0; qa <= o; ++qa) {
             c0 = U3D_MFMA_X(a0[qa], b[o - qa], c0);
@@ -46,11 +49,12 @@ __device__ __forceinline__ void mfma_x3_2a(const bf16x8 (&a0)[3], const bf16x8 (
         }
 }
 // running sums: the h.h product goes to (c0, c1), the five low-order plane products to their own accumulators (l0, l1), joined
-// once at the end of the kernel
-__device__ __forceinline__ void mfma_x3_2b(const bf16x8 (&a)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], f32x4& c0, f32x4& c1,
+// once at the end of the kernel (NP = 1, bf16 operands: the one product goes to (c0, c1))
+template <int NP>
+__device__ __forceinline__ void mfma_x3_2b(const bf16x8 (&a)[NP], const bf16x8 (&b0)[NP], const bf16x8 (&b1)[NP], f32x4& c0, f32x4& c1,
                                            f32x4& l0, f32x4& l1) {
 #pragma unroll
-    for (int o = 2; o >= 1; --o)
+    for (int o = NP - 1; o >= 1; --o)
 #pragma unroll
         for (int qa = 0; qa <= o; ++qa) {
             l0 = U3D_MFMA_X(a[qa], b0[o - qa], l0);
@@ -59,10 +63,35 @@ __device__ __forceinline__ void mfma_x3_2b(const bf16x8 (&a)[3], const bf16x8 (&
     c0 = U3D_MFMA_X(a[0], b0[0], c0);
     c1 = U3D_MFMA_X(a[0], b1[0], c1);
 }
+// one chain pair sharing nothing: s += a . b, d += c . e (S and dP of the backward kernels)
+template <int NP>
+__device__ __forceinline__ void mfma_x3_2c(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], const bf16x8 (&c)[NP], const bf16x8 (&e)[NP], f32x4& s, f32x4& d) {
+#pragma unroll
+    for (int o = NP - 1; o >= 0; --o)
+#pragma unroll
+        for (int qa = 0; qa <= o; ++qa) {
+            s = U3D_MFMA_X(a[qa], b[o - qa], s);
+            d = U3D_MFMA_X(c[qa], e[o - qa], d);
+        }
+}
+
+// NP planes of a pair / of eight values: NP = 3 the exact split (u3d_common.h), NP = 1 one bf16 value rounded to nearest even
+// (bf16 operands, BASELINE configs[2])
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_r;
+template <int NP>
+__device__ __forceinline__ void planes_pair(float a, float b, unsigned (&w)[NP]) {
+    if constexpr (NP == 3) split3_pair(a, b, w[0], w[1], w[2]);
+    else w[0] = __builtin_bit_cast(unsigned, bf16x2_r{(__bf16)a, (__bf16)b});
+}
+template <int NP>
+__device__ __forceinline__ void planes_x8(const f32x4& lo, const f32x4& hi, bf16x8 (&out)[NP]) {
+    if constexpr (NP == 3) split3_x8(lo, hi, out);
+    else out[0] = bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+}
 
 // Stage 64 rows x 32 floats of `base` (rows >= len are zero, values scaled before the split): thread (p = tid >> 3, c = tid & 7)
 // holds dims 4c .. 4c+3 of rows 2p and 2p+1; load_x3 issues the global loads (one tile ahead of their use: the compute phase of
-// the tile before covers their latency), store_x3 splits and writes.  NAT: natural planes nat[3][64][XLD] halves; PAIR: pair planes pr[3][32 dims][XPD]
+// the tile before covers their latency), store_x3 splits and writes.  NAT: natural planes nat[NP][64][XLD] halves; PAIR: pair planes pr[NP][32 dims][XPD]
 // dwords, row pair p = (t, half, g, w) bits 4 | 3 | 2-1 | 0 in slot 16 t + 4 g + 2 half + w, XORed with 4 * (dim >> 2).
 struct StageRegs { f32x4 a, b; };
 __device__ __forceinline__ StageRegs load_x3(const float* __restrict__ base, int ld, int row0, int len, int tid) {
@@ -75,61 +104,65 @@ __device__ __forceinline__ StageRegs load_x3(const float* __restrict__ base, int
     if (r0 + 1 < len) r.b = *reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + 1) * ld + c * 4);
     return r;
 }
-template <bool NAT, bool PAIR>
+template <int NP, bool NAT, bool PAIR>
 __device__ __forceinline__ void store_x3(StageRegs r, float scale, __bf16* nat, unsigned* pr, int tid) {
     const int p = tid >> 3, c = tid & 7;
     const f32x4 a = r.a * scale, b = r.b * scale;
     if constexpr (PAIR) {
-        unsigned w[3][4];
+        unsigned w[4][NP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split3_pair(a[j], b[j], w[0][j], w[1][j], w[2][j]);
+        for (int j = 0; j < 4; ++j) planes_pair<NP>(a[j], b[j], w[j]);
         const int slot = ((p & 16) | ((p & 6) << 1) | ((p & 8) >> 2) | (p & 1)) ^ (4 * c);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pr[q * XP + (4 * c + j) * XPD + slot] = w[q][j];
+            for (int j = 0; j < 4; ++j) pr[q * XP + (4 * c + j) * XPD + slot] = w[j][q];
     }
     if constexpr (NAT) {
-        unsigned wa[3][2], wb[3][2];
+        unsigned wa[2][NP], wb[2][NP];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            split3_pair(a[2 * j], a[2 * j + 1], wa[0][j], wa[1][j], wa[2][j]);
-            split3_pair(b[2 * j], b[2 * j + 1], wb[0][j], wb[1][j], wb[2][j]);
+            planes_pair<NP>(a[2 * j], a[2 * j + 1], wa[j]);
+            planes_pair<NP>(b[2 * j], b[2 * j + 1], wb[j]);
         }
         const int off = (((c >> 1) ^ (p & 3)) * 8) + (c & 1) * 4;          // rows 2p and 2p+1 share (row >> 1) & 3 = p & 3
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p) * XLD + off) = make_uint2(wa[q][0], wa[q][1]);
-            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p + 1) * XLD + off) = make_uint2(wb[q][0], wb[q][1]);
+        for (int q = 0; q < NP; ++q) {
+            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p) * XLD + off) = make_uint2(wa[0][q], wa[1][q]);
+            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p + 1) * XLD + off) = make_uint2(wb[0][q], wb[1][q]);
         }
     }
 }
 
 // own row -> B operand planes: 8 consecutive dims of row `ptr` (nullptr: zeros), scaled
-__device__ __forceinline__ void row_frag_x3(const float* ptr, float scale, bf16x8 (&out)[3]) {
+template <int NP>
+__device__ __forceinline__ void row_frag_x3(const float* ptr, float scale, bf16x8 (&out)[NP]) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
     if (ptr) { a = *reinterpret_cast<const f32x4*>(ptr); b = *reinterpret_cast<const f32x4*>(ptr + 4); }
     a *= scale;
     b *= scale;
-    split3_x8(a, b, out);
+    planes_x8<NP>(a, b, out);
 }
 
 // A operand planes from two C fragments: k = 8g + e <-> row 16 (e >> 2) + 4g + (e & 3) of the 32-row block
-__device__ __forceinline__ void pair_frag_x3(const float (&lo)[4], const float (&hi)[4], bf16x8 (&out)[3]) {
-    split3_x8(f32x4{lo[0], lo[1], lo[2], lo[3]}, f32x4{hi[0], hi[1], hi[2], hi[3]}, out);
+template <int NP>
+__device__ __forceinline__ void pair_frag_x3(const float (&lo)[4], const float (&hi)[4], bf16x8 (&out)[NP]) {
+    planes_x8<NP>(f32x4{lo[0], lo[1], lo[2], lo[3]}, f32x4{hi[0], hi[1], hi[2], hi[3]}, out);
 }
 
 // natural planes: rows 16 kb + i, dims 8g .. 8g+7
-__device__ __forceinline__ void nat_frag_x3(const __bf16* nat, int kb, int i16, int g, bf16x8 (&out)[3]) {
+template <int NP>
+__device__ __forceinline__ void nat_frag_x3(const __bf16* nat, int kb, int i16, int g, bf16x8 (&out)[NP]) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) out[q] = *reinterpret_cast<const bf16x8*>(nat + q * XN + (kb * 16 + i16) * XLD + ((g ^ ((i16 >> 1) & 3)) * 8));
+    for (int q = 0; q < NP; ++q) out[q] = *reinterpret_cast<const bf16x8*>(nat + q * XN + (kb * 16 + i16) * XLD + ((g ^ ((i16 >> 1) & 3)) * 8));
 }
 
 // pair planes: column (dim) `col`, rows {4g..4g+3} and {16+4g..16+4g+3} of the 32-row block t: slots 16 t + 4 g .. + 3
-__device__ __forceinline__ void pair_col_frag_x3(const unsigned* pr, int t, int g, int col, bf16x8 (&out)[3]) {
+template <int NP>
+__device__ __forceinline__ void pair_col_frag_x3(const unsigned* pr, int t, int g, int col, bf16x8 (&out)[NP]) {
     const unsigned* s = pr + col * XPD + ((16 * t + 4 * g) ^ (4 * ((col >> 2) & 7)));
 #pragma unroll
-    for (int q = 0; q < 3; ++q) out[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + q * XP));
+    for (int q = 0; q < NP; ++q) out[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + q * XP));
 }
 
 struct AttnWorkX { int b, h, tile; };
@@ -143,10 +176,11 @@ __device__ __forceinline__ AttnWorkX attn_decode_x(int H, int B, int n_tiles) { 
     return w;
 }
 
+template <int NP>
 __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale,
                                                      float* __restrict__ out, float* __restrict__ lse, int64_t n_total, int B, int n_tiles) {
-    __shared__ __attribute__((aligned(16))) __bf16 Kn[3 * XN];
-    __shared__ __attribute__((aligned(16))) unsigned Vp[3 * XP];
+    __shared__ __attribute__((aligned(16))) __bf16 Kn[NP * XN];
+    __shared__ __attribute__((aligned(16))) unsigned Vp[NP * XP];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
     if (b >= B) return;
@@ -157,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const float* base = qkv + (int64_t)start * ld + h * 32;
     const int qrow = q0 + wave * 16 + i16;
-    bf16x8 qf[3];                                // scores in log2 units: q carries scale * log2(e)
+    bf16x8 qf[NP];                                // scores in log2 units: q carries scale * log2(e)
     row_frag_x3(qrow < len ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
     float m = -INFINITY, l = 0.f;
     f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // h.h | low-order products
@@ -165,8 +199,8 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
     StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        store_x3<true, false>(rk, 1.f, Kn, nullptr, tid);
-        store_x3<false, true>(rv, 1.f, nullptr, Vp, tid);
+        store_x3<NP, true, false>(rk, 1.f, Kn, nullptr, tid);
+        store_x3<NP, false, true>(rv, 1.f, nullptr, Vp, tid);
         if (kt + 1 < ntiles) {
             rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
             rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
@@ -175,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
         float st[4][4];
 #pragma unroll
         for (int kb = 0; kb < 4; kb += 2) {
-            bf16x8 a0[3], a1[3];
+            bf16x8 a0[NP], a1[NP];
             nat_frag_x3(Kn, kb, i16, g, a0);
             nat_frag_x3(Kn, kb + 1, i16, g, a1);
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -222,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            bf16x8 pa[3], v0[3], v1[3];
+            bf16x8 pa[NP], v0[NP], v1[NP];
             pair_frag_x3(st[2 * t], st[2 * t + 1], pa);
             pair_col_frag_x3(Vp, t, g, i16, v0);
             pair_col_frag_x3(Vp, t, g, 16 + i16, v1);
@@ -262,12 +296,13 @@ __global__ __launch_bounds__(256) void attn_delta_x3_k(const float* __restrict__
 }
 
 // dQ: one workgroup per 64-query tile, keys streamed.  K is staged in both layouts (natural for S, pairs for dQ += dS . K).
+template <int NP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                                                         const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
                                                         float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
-    __shared__ __attribute__((aligned(16))) __bf16 Kn[3 * XN];
-    __shared__ __attribute__((aligned(16))) __bf16 Vn[3 * XN];
-    __shared__ __attribute__((aligned(16))) unsigned Kp[3 * XP];
+    __shared__ __attribute__((aligned(16))) __bf16 Kn[NP * XN];
+    __shared__ __attribute__((aligned(16))) __bf16 Vn[NP * XN];
+    __shared__ __attribute__((aligned(16))) unsigned Kp[NP * XP];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
     if (b >= B) return;
@@ -279,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     const float* base = qkv + (int64_t)start * ld + h * 32;
     const int qrow = q0 + wave * 16 + i16;
     const bool qok = qrow < len;
-    bf16x8 qf[3], dof[3];
+    bf16x8 qf[NP], dof[NP];
     row_frag_x3(qok ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
     row_frag_x3(qok ? dout + (int64_t)(start + qrow) * D + h * 32 + g * 8 : nullptr, 1.f, dof);
     // log2 units; rows past the end get +inf so that exp2(s - lse) = 0 masks them without a select per element
@@ -290,8 +325,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        store_x3<true, true>(rk, 1.f, Kn, Kp, tid);
-        store_x3<true, false>(rv, 1.f, Vn, nullptr, tid);
+        store_x3<NP, true, true>(rk, 1.f, Kn, Kp, tid);
+        store_x3<NP, true, false>(rv, 1.f, Vn, nullptr, tid);
         if (kt + 1 < ntiles) {
             rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
             rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
@@ -301,17 +336,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
         float ds[4][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            bf16x8 ak[3], av[3];
+            bf16x8 ak[NP], av[NP];
             nat_frag_x3(Kn, kb, i16, g, ak);
             nat_frag_x3(Vn, kb, i16, g, av);
             f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = s4;
-#pragma unroll
-            for (int o = 2; o >= 0; --o)
-#pragma unroll
-                for (int qa = 0; qa <= o; ++qa) {
-                    s4 = U3D_MFMA_X(ak[qa], qf[o - qa], s4);
-                    dp4 = U3D_MFMA_X(av[qa], dof[o - qa], dp4);
-                }
+            mfma_x3_2c<NP>(ak, qf, av, dof, s4, dp4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f(s4[r] - lse_q);
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            bf16x8 da[3], k0[3], k1[3];
+            bf16x8 da[NP], k0[NP], k1[NP];
             pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
             pair_col_frag_x3(Kp, t, g, i16, k0);
             pair_col_frag_x3(Kp, t, g, 16 + i16, k1);
@@ -342,13 +371,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
 }
 
 // dK, dV: one workgroup per 64-key tile, queries streamed.  Q and dO are staged in both layouts.
+template <int NP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                                                          const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
                                                          float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
-    __shared__ __attribute__((aligned(16))) __bf16 Qn[3 * XN];
-    __shared__ __attribute__((aligned(16))) __bf16 On[3 * XN];
-    __shared__ __attribute__((aligned(16))) unsigned Qp[3 * XP];
-    __shared__ __attribute__((aligned(16))) unsigned Op[3 * XP];
+    __shared__ __attribute__((aligned(16))) __bf16 Qn[NP * XN];
+    __shared__ __attribute__((aligned(16))) __bf16 On[NP * XN];
+    __shared__ __attribute__((aligned(16))) unsigned Qp[NP * XP];
+    __shared__ __attribute__((aligned(16))) unsigned Op[NP * XP];
     __shared__ float lse_s[64], del_s[64];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
@@ -361,7 +391,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
     const float* base = qkv + (int64_t)start * ld + h * 32;
     const float* dobase = dout + (int64_t)start * D + h * 32;
     const int krow = k0 + wave * 16 + i16;
-    bf16x8 kf[3], vf[3];
+    bf16x8 kf[NP], vf[NP];
     row_frag_x3(krow < len ? base + (int64_t)krow * ld + D + g * 8 : nullptr, 1.f, kf);
     row_frag_x3(krow < len ? base + (int64_t)krow * ld + 2 * D + g * 8 : nullptr, 1.f, vf);
     f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -370,8 +400,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
     StageRegs rq = load_x3(base, ld, 0, len, tid), ro = load_x3(dobase, D, 0, len, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
-        store_x3<true, true>(rq, scale * X_LOG2E, Qn, Qp, tid);        // log2 units; dK is rescaled by ln 2 at the end
-        store_x3<true, true>(ro, 1.f, On, Op, tid);
+        store_x3<NP, true, true>(rq, scale * X_LOG2E, Qn, Qp, tid);        // log2 units; dK is rescaled by ln 2 at the end
+        store_x3<NP, true, true>(ro, 1.f, On, Op, tid);
         if (qt + 1 < ntiles) {
             rq = load_x3(base, ld, qt * 64 + 64, len, tid);
             ro = load_x3(dobase, D, qt * 64 + 64, len, tid);
@@ -385,17 +415,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
         float p[4][4], ds[4][4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
-            bf16x8 aq[3], ao[3];
+            bf16x8 aq[NP], ao[NP];
             nat_frag_x3(Qn, qb, i16, g, aq);
             nat_frag_x3(On, qb, i16, g, ao);
             f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp4 = s4;
-#pragma unroll
-            for (int o = 2; o >= 0; --o)
-#pragma unroll
-                for (int qa = 0; qa <= o; ++qa) {
-                    s4 = U3D_MFMA_X(aq[qa], kf[o - qa], s4);
-                    dp4 = U3D_MFMA_X(ao[qa], vf[o - qa], dp4);
-                }
+            mfma_x3_2c<NP>(aq, kf, ao, vf, s4, dp4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qq = qb * 16 + g * 4 + r;
@@ -405,7 +429,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            bf16x8 pa[3], da[3], f0[3], f1[3];
+            bf16x8 pa[NP], da[NP], f0[NP], f1[NP];
             pair_frag_x3(p[2 * t], p[2 * t + 1], pa);
             pair_col_frag_x3(Op, t, g, i16, f0);
             pair_col_frag_x3(Op, t, g, 16 + i16, f1);
@@ -433,19 +457,57 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
 
 // launchers, called from attn.hip's entry points when fp32_x3() (arguments already validated there)
 void attn_fwd_x3_launch(const float* qkv, const int32_t* cu, int B, int max_len, int64_t n_total, int H, float scale, float* out, float* lse,
-                        hipStream_t s) {
+                        hipStream_t s, int planes) {
     const int n_tiles = (max_len + 63) / 64;
     const unsigned grid = (unsigned)(((H * B + 7) / 8) * 8 * n_tiles);
-    hipLaunchKernelGGL(attn_fwd_x3_k, dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
+    if (planes == 1) hipLaunchKernelGGL(attn_fwd_x3_k<1>, dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
+    else hipLaunchKernelGGL(attn_fwd_x3_k<3>, dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
 }
 
 void attn_bwd_x3_launch(const float* qkv, const float* out, const float* dout, const float* lse, const int32_t* cu, int B, int max_len,
-                        int64_t n_total, int H, float scale, float* dqkv, float* delta_ws, hipStream_t s) {
+                        int64_t n_total, int H, float scale, float* dqkv, float* delta_ws, hipStream_t s, int planes) {
     hipLaunchKernelGGL(attn_delta_x3_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, out, dout, n_total, H, delta_ws);
     const int n_tiles = (max_len + 63) / 64;
     const dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * n_tiles));
-    hipLaunchKernelGGL(attn_bwd_dq_x3_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
-    hipLaunchKernelGGL(attn_bwd_dkv_x3_k, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+    if (planes == 1) {
+        hipLaunchKernelGGL(attn_bwd_dq_x3_k<1>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL(attn_bwd_dkv_x3_k<1>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_x3_k<3>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL(attn_bwd_dkv_x3_k<3>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+    }
 }
 
 }  // namespace u3d
+
+using namespace u3d;
+
+extern "C" {
+
+// bf16-operand form (BASELINE configs[2]; the reference's `--amp` run through nn.MultiheadAttention, tools/train.py:86-99): the
+// same kernels with ONE plane per operand, rounded to nearest even where the three-plane form splits; qkv / out / gradients stay
+// fp32 in HBM, accumulation and softmax stay fp32.
+int u3d_attn_varlen_fwd_bf16(const float* qkv, const int32_t* cu_seqlens, int B, int max_len, int64_t n_total, int H, int hd,
+                             float scale, float* out, float* lse, double flops_hint, u3d_stream_t stream) {
+    if (!qkv || !cu_seqlens || !out || !lse || B <= 0 || H <= 0 || n_total <= 0) return U3D_EINVAL;
+    if (hd != 32) { set_error("attn: head_dim %d unsupported (32 only)", hd); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_ATTN_FWD, s, flops_hint);
+    if (max_len <= 0) return U3D_OK;
+    attn_fwd_x3_launch(qkv, cu_seqlens, B, max_len, n_total, H, scale, out, lse, s, 1);
+    return check_launch("attn_fwd_bf16");
+}
+
+int u3d_attn_varlen_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, const int32_t* cu_seqlens,
+                             int B, int max_len, int64_t n_total, int H, int hd, float scale, float* dqkv, float* delta_ws,
+                             double flops_hint, u3d_stream_t stream) {
+    if (!qkv || !out || !dout || !lse || !cu_seqlens || !dqkv || !delta_ws || B <= 0 || H <= 0 || n_total <= 0) return U3D_EINVAL;
+    if (hd != 32) { set_error("attn: head_dim %d unsupported (32 only)", hd); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_ATTN_BWD, s, flops_hint);
+    if (max_len <= 0) return U3D_OK;
+    attn_bwd_x3_launch(qkv, out, dout, lse, cu_seqlens, B, max_len, n_total, H, scale, dqkv, delta_ws, s, 1);
+    return check_launch("attn_bwd_bf16");
+}
+
+}  // extern "C"

@@ -4,7 +4,7 @@
 // u3d_attn_varlen_fwd / _bwd (reference: nn.MultiheadAttention inside unidet3d/encoder.py:19-21,55-61; oracle/model.py);
 // U3D_FP32_MATH=mfma selects the native fp32 MFMA kernels of attn.hip.
 //
-// Shapes as in attn_bf16.hip: lane (i = lane & 15, g = lane >> 4) holds the 8 reduction elements k = 8g .. 8g+7 of row i (A) /
+// v_mfma_f32_16x16x32_bf16: lane (i = lane & 15, g = lane >> 4) holds the 8 reduction elements k = 8g .. 8g+7 of row i (A) /
 // column i (B); head_dim = 32 is one instruction's reduction depth.
 //   S^T (16 keys x 16 queries) = K_tile . Q^T       A = K rows, natural [key][dim] planes in LDS (one 16-byte read per plane),
 //                                                   B = own Q rows, split once into registers

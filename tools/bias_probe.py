@@ -20,7 +20,6 @@ for K in (32, 256, 2048):
     print(line + f'  torch: mean {e.mean():+.3e} rms {e.pow(2).mean().sqrt():.3e}', flush=True)
 
 # sparse convolution, all-positive features and weights
-import numpy as np
 from unidet3d_amd import ops, sparse
 from unidet3d_amd.synthetic import make_scene
 vb = ops.voxelize([torch.from_numpy(make_scene(i, n_points=30000).points).to(dev) for i in range(2)], 0.04, 128)

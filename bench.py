@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--fp32-math', default=None, choices=['bf16x3', 'mfma'],
                     help="how the fp32 path forms its products: 'bf16x3' (library default) = three exact bf16 planes per operand, six bf16 "
                          "MFMAs per product, fp32-level error; 'mfma' = native v_mfma_f32_* (round 1-2 headline kernels)")
+    ap.add_argument('--no-mfma-line', action='store_true',
+                    help='skip the `fp32_native_mfma` block (the same fp32 workload on the native fp32 MFMA kernels) appended to the default line')
     ap.add_argument('--no-cfg3', action='store_true', help='skip the cfg3 block (bf16 operands, 16 scenes/GPU) appended to the fp32 line')
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--voxel-size', type=float, default=0.02)
@@ -187,7 +189,7 @@ def _pmc_traffic(bf: bool):
     return None, (f'{len(files)} PMC file(s) under profiles/ were measured on a different spconv.hip: not reported' if files else None)
 
 
-def measure(args, dtype: str, batch: int, rank: int, world: int, dev):
+def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=None):
     """W untimed + K timed steps of one configuration (model, optimizer, scenes built here); returns the fields of the JSON line
     that describe it.  Collective when world > 1 (every rank calls it with the same arguments)."""
     from unidet3d_amd import _lib as L
@@ -199,8 +201,8 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev):
     from unidet3d_amd.synthetic import make_scene
 
     precision.set_operand_dtype(dtype)
-    if getattr(args, 'fp32_math', None):
-        precision.set_fp32_math(args.fp32_math)
+    if fp32_math or getattr(args, 'fp32_math', None):
+        precision.set_fp32_math(fp32_math or args.fp32_math)
     x3 = dtype == 'fp32' and precision.get_fp32_math() == 'bf16x3'
     torch.manual_seed(0)
     model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)
@@ -380,6 +382,13 @@ def main():
 
     head_batch = args.batch if args.batch is not None else (16 if args.dtype == 'bf16' else 8)
     head = measure(args, args.dtype, head_batch, rank, world, dev)
+    native = None
+    if args.dtype == 'fp32' and head['config'].get('fp32_math') == 'bf16x3' and not args.no_mfma_line:
+        # the same workload, steps and protocol on the native fp32 MFMA kernels: the headline forms its fp32 products from bf16 pieces
+        #  -- a reader who wants the number of the plain fp32 matrix instructions finds it in the same line
+        native = measure(args, 'fp32', head_batch, rank, world, dev, fp32_math='mfma')
+        from unidet3d_amd import precision as _P
+        _P.set_fp32_math('bf16x3')
     cfg3 = None
     if args.dtype == 'fp32' and not args.no_cfg3:
         # BASELINE.json configs[2] right behind the headline, same process, same protocol (W warm-up + K timed steps)
@@ -390,6 +399,12 @@ def main():
                'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': head['dtype'], 'data': 'synthetic', 'config': head['config'], 'roofline': head['roofline'],
                'kernels': head['kernels'], 'step_roofline': head['step_roofline']}
+        if native is not None:
+            out['fp32_native_mfma'] = dict(note='same workload / steps / protocol with U3D_FP32_MATH=mfma (v_mfma_f32_* instead of six bf16 MFMAs per '
+                                                'product), measured right after the headline in the same process',
+                                           value=native['value'], unit=native['unit'], ms_per_step=native['ms_per_step'],
+                                           roofline=native['roofline'], kernels=native['kernels'],
+                                           warmup_losses=native['config']['warmup_losses'])
         if cfg3 is not None:
             out['cfg3'] = dict(note='BASELINE.json configs[2] measured after the headline in the same process: bf16 MFMA operands, 16 scenes/GPU; '
                                     'families priced against the bf16 dense MFMA peak where their operands are bf16', **cfg3)

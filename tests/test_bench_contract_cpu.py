@@ -17,7 +17,7 @@ def test_defaults_are_one_gpu_and_a_run_of_minutes(monkeypatch):
     a = bench.parse()
     assert bench.METRIC == json.load(open(os.path.join(ROOT, 'BASELINE.json')))['metric']
     assert a.gpus == 1 and 1 <= a.steps <= 50 and a.warmup >= 1 and a.dtype == 'fp32' and a.points == 100_000
-    assert not a.no_prefetch and not a.no_optimizer and not a.no_cpu_baseline and not a.no_cfg3 and a.optimizer == 'adamw'
+    assert not a.no_prefetch and not a.no_optimizer and not a.no_cpu_baseline and not a.no_cfg3 and not a.no_mfma_line and a.optimizer == 'adamw'
 
 
 def test_gpus_n_turns_itself_into_a_torchrun_launch(monkeypatch):
@@ -77,3 +77,10 @@ def test_kept_bench_lines_follow_the_contract():
     assert c3['dtype'] == 'bf16' and c3['config']['global_batch'] == 16 and 'cfg3' in c3['config']['workload']
     assert abs(c3['value'] - 16 / c3['ms_per_step'] * 1e3) < 1e-6 * c3['value'] and c3['roofline']['peak'] == 2500.0
     assert 'median of' in main['cpu_baseline']['sample'] and 'warm-up' in main['cpu_baseline']['sample']      # SURVEY 8(d) protocol
+    # the headline forms its fp32 products from three bf16 planes per operand and says so; the same workload on the
+    # native fp32 MFMA kernels is a block of the same line
+    assert main['config']['fp32_math'] == 'bf16x3' and 'math' in main['roofline'] and main['roofline']['instruction_peak'] > main['roofline']['peak']
+    nm = main['fp32_native_mfma']
+    assert nm['value'] > 0 and abs(nm['value'] - 8 / nm['ms_per_step'] * 1e3) < 1e-6 * nm['value']
+    assert nm['roofline']['peak'] == 157.3 and 'math' not in nm['roofline']
+    assert nm['warmup_losses'][0] == main['config']['warmup_losses'][0]          # same initial weights and scenes

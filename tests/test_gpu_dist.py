@@ -95,7 +95,7 @@ def test_bench_gpus_2_launches_itself():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
-                          '--points', '20000', '--no-cpu-baseline', '--no-cfg3'], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+                          '--points', '20000', '--no-cpu-baseline', '--no-cfg3', '--no-mfma-line'], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, res.stdout[-2000:]

@@ -4,8 +4,8 @@
 # (MI355X_MICROARCH.md, HBM section) -> doubled below; WRITE_SIZE is used as reported (uncalibrated).
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${PMC_TAG:-pmc_bench}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line > /dev/null 2>&1
 cd $R
 python - "$OUT" <<'PY'
 import csv, sys, glob, json, collections

@@ -382,15 +382,18 @@ def main():
 
     head_batch = args.batch if args.batch is not None else (16 if args.dtype == 'bf16' else 8)
     head = measure(args, args.dtype, head_batch, rank, world, dev)
+    # The two extra blocks below belong to the single-GPU line only: at N > 1 every further configuration builds a second model,
+    # gradient bucket and communicator inside the same job -- measured with 2 gloo ranks: an ~11 s one-time stall lands somewhere in
+    # the second configuration's first steps (3.7 s/step "timed") -- and the scaling runs need the headline only.
     native = None
-    if args.dtype == 'fp32' and head['config'].get('fp32_math') == 'bf16x3' and not args.no_mfma_line:
+    if world == 1 and args.dtype == 'fp32' and head['config'].get('fp32_math') == 'bf16x3' and not args.no_mfma_line:
         # the same workload, steps and protocol on the native fp32 MFMA kernels: the headline forms its fp32 products from bf16 pieces
         #  -- a reader who wants the number of the plain fp32 matrix instructions finds it in the same line
         native = measure(args, 'fp32', head_batch, rank, world, dev, fp32_math='mfma')
         from unidet3d_amd import precision as _P
         _P.set_fp32_math('bf16x3')
     cfg3 = None
-    if args.dtype == 'fp32' and not args.no_cfg3:
+    if world == 1 and args.dtype == 'fp32' and not args.no_cfg3:
         # BASELINE.json configs[2] right behind the headline, same process, same protocol (W warm-up + K timed steps)
         cfg3 = measure(args, 'bf16', 16, rank, world, dev)
 

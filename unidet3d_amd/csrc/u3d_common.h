@@ -90,6 +90,10 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsig
 }
 // eight fp32 values -> the three bf16x8 planes
 __device__ __forceinline__ void split3_x8(const f32x4& lo, const f32x4& hi, bf16x8_t (&out)[3]) {
+#ifdef U3D_SPLIT_ABL       // timing ablation (tools/build_variant.sh <file> -DU3D_SPLIT_ABL): operands without the split arithmetic, WRONG results
+    out[0] = __builtin_bit_cast(bf16x8_t, lo); out[1] = __builtin_bit_cast(bf16x8_t, hi); out[2] = out[0];
+    return;
+#endif
     unsigned w[3][4];
     split3_pair(lo[0], lo[1], w[0][0], w[1][0], w[2][0]);
     split3_pair(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);

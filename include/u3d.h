@@ -33,6 +33,9 @@ typedef void* u3d_stream_t; /* hipStream_t */
 #define U3D_ELAUNCH (-2)  /* HIP launch error (hipGetLastError != success) */
 #define U3D_EUNSUPPORTED (-3) /* channel combination not instantiated */
 
+/* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
+ * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
+#define U3D_ABI_VERSION 104
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -42,6 +45,15 @@ const char* u3d_last_error(void);
  *   0 (env U3D_FP32_MATH=mfma): the native v_mfma_f32_* instructions.
  * Returns the previous mode; any other argument only queries.  Process-wide, not thread-safe against running launches. */
 int u3d_fp32_math(int mode);
+
+/* Which output-stationary sparse-convolution kernel serves u3d_spconv_gmm_bf16 / _x3:
+ *   1 (default; env U3D_GMM_WG unset or != 0): workgroup tiles -- four waves share 4 x tile_rows dst rows, the packed weights of
+ *     an offset are staged once per workgroup in LDS and the offset's pairs are dealt evenly to the waves (csrc/spconv_wg.hip);
+ *   0: wave-private tiles, every item reads its weight fragments through the vector-memory path (csrc/spconv.hip; also what
+ *     u3d_spconv_gmm -- native fp32 MFMAs -- and launches with bn_partial always use).
+ * Same arguments, same tile_starts, bit-identical pair arithmetic; results differ only in fp32 summation order across offsets
+ * of one row (none: both accumulate offsets in ascending order).  Returns the previous mode; other arguments only query. */
+int u3d_conv_kernel(int mode);
 
 /* ---- kernel timing (HIP events on the launch stream; used by bench.py's roofline) ---- */
 enum { U3D_K_CONV_FWD = 0, U3D_K_CONV_WGRAD = 1, U3D_K_BN = 2, U3D_K_POOL = 3, U3D_K_ATTN_FWD = 4,

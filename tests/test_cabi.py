@@ -26,7 +26,32 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/u3d.h but not exported'
     lib.u3d_version.restype = ctypes.c_int
-    assert lib.u3d_version() >= 100
+    from unidet3d_amd import _lib
+    hdr = int(re.search(r'#define\s+U3D_ABI_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 'u3d.h')).read()).group(1))
+    assert lib.u3d_version() == hdr == _lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """a library built against another argument list must not load silently."""
+    from unidet3d_amd import _lib
+    _lib.lib()
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    import pytest
+    with pytest.raises(_lib.U3DError, match='ABI version'):
+        _lib.lib()
+
+
+def test_conv_kernel_switch_is_host_state():
+    from unidet3d_amd import _lib
+    l = _lib.lib()
+    prev = l.u3d_conv_kernel(-1)
+    try:
+        assert prev in (0, 1)
+        assert l.u3d_conv_kernel(0) == prev and l.u3d_conv_kernel(-1) == 0 and l.u3d_conv_kernel(5) == 0
+        assert l.u3d_conv_kernel(1) == 0 and l.u3d_conv_kernel(-1) == 1
+    finally:
+        l.u3d_conv_kernel(prev)
 
 
 def test_ctypes_table_mirrors_header():

@@ -104,12 +104,13 @@ def _level_geometry(n_points=12_000, vs=0.05):
     return vb, oc, oshape
 
 
-@pytest.fixture(params=['bf16x3', 'mfma'])
+@pytest.fixture(params=['bf16x3', 'bf16x3-wavetile', 'mfma'])
 def math_mode(request):
     """both ways of forming fp32 products (precision.fp32_math): three exact bf16 planes per operand on the bf16 matrix pipe
-    (the default) and the native fp32 MFMAs"""
+    (the default; sparse convolutions through the workgroup-tile kernel and, '-wavetile', the wave-tile kernel) and the
+    native fp32 MFMAs"""
     from unidet3d_amd import precision as P
-    with P.fp32_math(request.param):
+    with P.fp32_math(request.param.split('-')[0]), P.conv_kernel('wave' if request.param.endswith('wavetile') else 'workgroup'):
         yield request.param
 
 
@@ -138,6 +139,51 @@ def test_subm_conv_fwd_bwd(cin, cout, math_mode):
         assert _rel(xg.grad, xo.grad) < 1e-4
     assert _rel(wg.grad, wo.grad) < 1e-4
     assert _rel(ag.grad, ao.grad) < 1e-6
+
+
+@pytest.mark.parametrize('operands', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('tile_rows', [0, 64])
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (64, 64), (96, 96), (128, 160), (256, 256)])
+def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_rows, operands):
+    """The workgroup-tile kernel (weights of an offset through LDS, an offset's pairs dealt evenly to four waves) performs the
+    same MFMAs on the same operands in the same order per dst row as the wave-tile kernel: forward (+ residual addend) and
+    input gradient must be IDENTICAL, for SubM (27 offsets) and strided / inverse (8 offsets) rulebooks, at both tile heights
+    and with offset groups (the small levels)."""
+    import os
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    vb, oc, oshape = _level_geometry()
+    n = vb.coords.shape[0]
+    g = torch.Generator().manual_seed(cin * 31 + cout)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    c2, shape2, ix2, rb2 = sparse.build_down_rulebook(vb.coords, 2, vb.spatial_shape)
+    n2 = c2.shape[0]
+    x = torch.randn(n, cin, generator=g).to(_dev())
+    w3 = (torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1).to(_dev())
+    w2 = (torch.randn(cout, 2, 2, 2, cin, generator=g) * 0.1).to(_dev())
+    wi = (torch.randn(cin, 2, 2, 2, cout, generator=g) * 0.1).to(_dev())
+    add = torch.randn(n, cout, generator=g).to(_dev())
+    go, go2 = torch.randn(n, cout, generator=g).to(_dev()), torch.randn(n2, cout, generator=g).to(_dev())
+    prev = os.environ.get('U3D_GMM_R')
+    if tile_rows:
+        os.environ['U3D_GMM_R'] = str(tile_rows)
+    out = {}
+    try:
+        for kind in ('wave', 'workgroup'):
+            with P.conv_kernel(kind), (P.operands('bf16') if operands == 'bf16' else P.fp32_math('bf16x3')):
+                xg = x.clone().requires_grad_()
+                y = sparse.sparse_conv(xg, w3, rb, 'fwd', add); y.backward(go)
+                xd = x.clone().requires_grad_()
+                yd = sparse.sparse_conv(xd, w2, rb2, 'fwd'); yd.backward(go2)
+                xu = go2.clone().requires_grad_()
+                yu = sparse.sparse_conv(xu, wi, rb2, 'inv'); yu.backward(x)
+                out[kind] = [y.detach(), xg.grad, yd.detach(), xd.grad, yu.detach(), xu.grad]
+    finally:
+        if tile_rows:
+            os.environ.pop('U3D_GMM_R') if prev is None else os.environ.__setitem__('U3D_GMM_R', prev)
+    for name, a, b in zip(('subm fwd', 'subm dgrad', 'down fwd', 'down dgrad', 'inverse fwd', 'inverse dgrad'), out['wave'], out['workgroup']):
+        assert torch.isfinite(b).all(), name
+        assert torch.equal(a, b), f'{name}: max |diff| {float((a - b).abs().max())}'
 
 
 def _l2(a, b):

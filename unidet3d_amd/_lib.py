@@ -21,6 +21,7 @@ PROTOTYPES = {
     'u3d_version': (_i32, []),
     'u3d_last_error': (C.c_char_p, []),
     'u3d_fp32_math': (_i32, [_i32]),
+    'u3d_conv_kernel': (_i32, [_i32]),
     'u3d_prof_enable': (_i32, [_i32, _i32]),
     'u3d_prof_collect': (_i32, [_i32, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64)]),
     'u3d_vox_scene_stats': (_i32, [_vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp, _vp, _vp]),
@@ -99,6 +100,8 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
+ABI_VERSION = 104         # include/u3d.h U3D_ABI_VERSION this table was written against
+
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 
 _lib = None
@@ -120,6 +123,10 @@ def lib():
             f = getattr(l, name)
             f.restype = res
             f.argtypes = args
+        v = l.u3d_version()
+        if v != ABI_VERSION:
+            raise U3DError(f'{LIB_PATH} has ABI version {v}, this package expects {ABI_VERSION}: rebuild it '
+                           '(`python -m unidet3d_amd.csrc.build`); a stale library would misread the arguments')
         _lib = l
     return _lib
 

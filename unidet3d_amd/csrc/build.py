@@ -6,14 +6,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ['misc.hip', 'voxelize.hip', 'rulebook.hip', 'spconv.hip', 'bn.hip', 'pool.hip', 'attn.hip', 'attn_x3.hip', 'gemm.hip', 'norm.hip', 'postproc.hip', 'criterion.hip', 'hashidx.hip']
+SOURCES = ['misc.hip', 'voxelize.hip', 'rulebook.hip', 'spconv.hip', 'spconv_wg.hip', 'bn.hip', 'pool.hip', 'attn.hip', 'attn_x3.hip', 'gemm.hip', 'norm.hip', 'postproc.hip', 'criterion.hip', 'hashidx.hip']
 LIB = os.path.join(HERE, 'libu3d_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-value',
          '-I', os.path.join(ROOT, 'include'), '-I', HERE]
 
 
 # per-file code generation options
-EXTRA = {'spconv.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],     # MFMA results are consumed by VALU/LDS right away
+EXTRA = {'spconv.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
+         'spconv_wg.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],     # MFMA results are consumed by VALU/LDS right away
          'attn_x3.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
          'postproc.hip': ['-ffp-contract=off']}                     # bit-exact against the oracle's operation order
 
@@ -28,7 +29,7 @@ def _hipcc():
 def _stale(src, obj):
     if not os.path.exists(obj):
         return True
-    deps = [src, os.path.join(HERE, 'u3d_common.h'), os.path.join(ROOT, 'include', 'u3d.h'), __file__]
+    deps = [src, os.path.join(HERE, 'u3d_common.h'), os.path.join(HERE, 'spconv_gmm.h'), os.path.join(ROOT, 'include', 'u3d.h'), __file__]
     return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 
 

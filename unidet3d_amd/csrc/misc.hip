@@ -1,5 +1,6 @@
 // Error reporting, per-class event timing, device-wide exclusive scan (wave-64 shuffle scan).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -12,6 +13,7 @@ namespace u3d {
 static thread_local char g_err[512] = "";
 
 int g_fp32_math = -1;
+int g_conv_kernel = -1;
 bool fp32_x3() {
     if (g_fp32_math < 0) {
         const char* e = getenv("U3D_FP32_MATH");
@@ -167,7 +169,16 @@ int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hip
 
 extern "C" {
 
-int u3d_version(void) { return 100; }
+int u3d_version(void) { return U3D_ABI_VERSION; }
+int u3d_conv_kernel(int mode) {
+    if (u3d::g_conv_kernel < 0) {
+        const char* e = getenv("U3D_GMM_WG");
+        u3d::g_conv_kernel = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    const int prev = u3d::g_conv_kernel;
+    if (mode == 0 || mode == 1) u3d::g_conv_kernel = mode;
+    return prev;
+}
 int u3d_fp32_math(int mode) {
     const int prev = u3d::fp32_x3() ? 1 : 0;
     if (mode == 0 || mode == 1) u3d::g_fp32_math = mode;

@@ -22,45 +22,10 @@
 #include <stdlib.h>
 
 #include "u3d_common.h"
+#include "spconv_gmm.h"
 
 namespace u3d {
 
-
-struct GmmParams {
-    const float* src;
-    const float* w;
-    const int32_t* gather;
-    const int32_t* scatter;
-    const int32_t* ts;
-    const float* addend;
-    float* out;          // dst, or the partial buffer [G][n_dst][Cd] when G > 1
-    float* stats;        // nullable (G == 1 only): per-tile column sums of dst for the batch norm behind this convolution,
-                         // float [n_sub][2][Cd] = sum x | sum x^2 over the tile's rows
-    int K;
-    int64_t cap;
-    int Cs, Cd;
-    int64_t n_dst;
-    int64_t n_src;
-    int64_t n_sub;
-    int n_slices;
-    int G;
-    int kper;
-};
-
-constexpr int GMM_CDS = 32;            // output columns per wave
-// Accumulator tile of a wave in LDS: R rows x 32 floats.  Default layout (round 3): 128-byte rows, the eight 16-byte quads of
-// row r stored at quad ^ (r & 7) -- the XOR spreads the random-row 16-byte accesses of the MFMA read-modify-write over the
-// banks like the padded 160-byte rows of rounds 1-2 did, without their 25 % padding, and the scratch row for lanes past the
-// end of a range aliases the head of the staging image (dead at that point of a unit) instead of being a 65th row:
-// 10 KB per wave instead of 12.4 -> FOUR workgroups (16 waves) per CU instead of three for the 64-row kernels.
-// -DU3D_GMM_ALD40 builds the old layout (A/B measurements).
-#ifdef U3D_GMM_ALD40
-constexpr bool GMM_SWZ = false;
-constexpr int GMM_ALD = 40;
-#else
-constexpr bool GMM_SWZ = true;
-constexpr int GMM_ALD = 32;
-#endif
 // Timing ablations (tools/build_variant.sh ... -DU3D_GMM_ABL=n; results are WRONG by construction, never shipped):
 //   bit 0 (1) = no MFMAs (operands kept alive), bit 1 (2) = no accumulator read-modify-write in LDS, 4 = every gather hits rows 0..63,
 //   bit 3 (8) = no LDS staging transposition, bit 4 (16) = no index shuffles, bit 5 (32) = weights loaded once
@@ -1077,7 +1042,12 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
 #define U3D_GMM_CASE(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64>(p, s) : launch_gmm<cs, 32>(p, s);
 #define U3D_GMM_CASE_BF(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64, 1>(p, s) : launch_gmm<cs, 32, 1>(p, s);
 #define U3D_GMM_CASE_X3(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64, 2>(p, s) : launch_gmm<cs, 32, 2>(p, s);
-    if (pr == 1) {
+    // bf16 / three-plane operands: the workgroup-tile kernel (spconv_wg.hip, weights of an offset shared through LDS) unless the
+    // launch asks for per-tile statistics (wave-tile epilogue only) or u3d_conv_kernel(0) / U3D_GMM_WG=0 selected the wave-tile kernel
+    const bool use_wg = u3d_conv_kernel(-1) == 1;
+    if (pr && use_wg && !bn_partial && gmm_wg_supported(cs16, R, pr)) {
+        rc = launch_gmm_wg(p, cs16, R, pr, s);
+    } else if (pr == 1) {
         U3D_GMM_CASE_BF(2) U3D_GMM_CASE_BF(4) U3D_GMM_CASE_BF(6) U3D_GMM_CASE_BF(8) U3D_GMM_CASE_BF(10) U3D_GMM_CASE_BF(12) U3D_GMM_CASE_BF(16)
     } else if (pr == 2) {
         U3D_GMM_CASE_X3(2) U3D_GMM_CASE_X3(4) U3D_GMM_CASE_X3(6) U3D_GMM_CASE_X3(8) U3D_GMM_CASE_X3(10) U3D_GMM_CASE_X3(12) U3D_GMM_CASE_X3(16)

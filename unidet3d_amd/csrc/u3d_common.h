@@ -66,6 +66,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64
 // issue time, with the error of an fp32 FMA chain (tests/test_gpu_kernels.py / test_gpu_model.py measure both modes against
 // fp64, per kernel and end to end).  U3D_FP32_MATH=mfma selects the native fp32 MFMA kernels instead.
 extern int g_fp32_math;
+extern int g_conv_kernel;      // 1: workgroup-tile sparse convolution (spconv_wg.hip), 0: wave tiles (u3d_conv_kernel)
 bool fp32_x3();
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;

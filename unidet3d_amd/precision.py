@@ -76,6 +76,28 @@ def fp32_math(mode: str):
         set_fp32_math(prev)
 
 
+_CONV_KERNEL = {'wave': 0, 'workgroup': 1}
+
+
+def set_conv_kernel(kind: str) -> str:
+    """'workgroup' (default: four waves share a row tile and the LDS copy of an offset's weights, csrc/spconv_wg.hip) | 'wave'
+    (wave-private tiles, csrc/spconv.hip) for the bf16 / three-plane sparse convolutions (include/u3d.h: u3d_conv_kernel;
+    env U3D_GMM_WG).  Returns the previous kind.  Process-wide; A/B measurements and tests."""
+    from . import _lib as L
+    if kind not in _CONV_KERNEL:
+        raise ValueError("conv kernel must be 'workgroup' or 'wave'")
+    return 'workgroup' if L.lib().u3d_conv_kernel(_CONV_KERNEL[kind]) == 1 else 'wave'
+
+
+@contextlib.contextmanager
+def conv_kernel(kind: str):
+    prev = set_conv_kernel(kind)
+    try:
+        yield
+    finally:
+        set_conv_kernel(prev)
+
+
 FMT_FP32, FMT_BF16, FMT_X3 = 0, 1, 2
 
 

@@ -171,22 +171,38 @@ def log(msg: str):
 FAMILY_NAMES = ('conv_gmm', 'conv_wgrad', 'attn_fwd', 'attn_bwd', 'gemm')
 
 
-def _pmc_traffic(bf: bool):
-    """HBM bytes per spconv_gmm_k launch from the newest committed PMC pass of this command whose spconv.hip hash matches the
-    kernel timed here (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950)."""
+# sources the timed sparse-convolution kernels are built from: a PMC file is only quoted when it was taken on exactly these
+PMC_SOURCES = ('spconv.hip', 'spconv_wg.hip', 'spconv_gmm.h', 'u3d_common.h')
+
+
+def csrc_hashes(names=None):
+    """sha256/16 of kernel sources (default: every .hip / .h under unidet3d_amd/csrc) -- the stamp tools/pmc_bench.sh writes into a
+    PMC summary and ``_pmc_traffic`` checks before quoting it."""
     import glob
     import hashlib
+    d = os.path.join(ROOT, 'unidet3d_amd', 'csrc')
+    if names is None:
+        names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h')))
+    return {n: hashlib.sha256(open(os.path.join(d, n), 'rb').read()).hexdigest()[:16] for n in names}
+
+
+def _pmc_traffic(bf: bool):
+    """HBM bytes per sparse-convolution (forward / input-gradient) launch from the newest committed PMC pass of this command whose
+    source hashes match the kernels timed here (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    FETCH x2 on gfx950).  A file taken on other sources is refused, not quoted."""
+    import glob
     if bf:
         return None, None
-    sha = hashlib.sha256(open(os.path.join(ROOT, 'unidet3d_amd', 'csrc', 'spconv.hip'), 'rb').read()).hexdigest()[:16]
+    want = csrc_hashes(PMC_SOURCES)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_traffic.json')), reverse=True)
     for f in files:
         rec = json.load(open(f))
-        if rec.get('_meta', {}).get('spconv_hip_sha16') == sha and '_spconv_gmm_k_all' in rec:
-            return (rec['_spconv_gmm_k_all']['hbm_MB_per_launch'] * 1e6,
+        have = rec.get('_meta', {}).get('csrc_sha16', {})
+        if all(have.get(n) == h for n, h in want.items()) and '_spconv_gmm_all' in rec:
+            return (rec['_spconv_gmm_all']['hbm_MB_per_launch'] * 1e6,
                     f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command at commit "
-                    f"{rec['_meta'].get('git_head', '?')}; spconv.hip sha256/16 {sha} matches the kernel timed here)")
-    return None, (f'{len(files)} PMC file(s) under profiles/ were measured on a different spconv.hip: not reported' if files else None)
+                    f"{rec['_meta'].get('git_head', '?')}; sha256/16 of {', '.join(PMC_SOURCES)} match the kernels timed here)")
+    return None, (f'{len(files)} PMC file(s) under profiles/ were measured on different kernel sources: not reported' if files else None)
 
 
 def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=None):
@@ -301,9 +317,10 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
     # decoder's NT GEMMs and attention; weight gradients keep fp32 operands below 64x64 channels
     peak = {k: (PEAK_BF16_MFMA_TFLOPS if bf and k in ('conv_gmm', 'attn_fwd', 'attn_bwd') else PEAK_F32_MFMA_TFLOPS) for k in prof}
     # fp32 math from three bf16 planes: the instructions that run are bf16 MFMAs, six per fp32-equivalent product, so the hardware
-    # ceiling of those kernels is the bf16 dense peak / 6; `frac` stays priced against the dtype's own (fp32) MFMA peak so that it is
-    # comparable across rounds and modes, the second fraction is reported next to it (weight gradients below 160 channels and the
-    # 16-channel input convolution stay on fp32 MFMAs)
+    # ceiling of those kernels is the bf16 dense peak / 6.  The roofline block's `frac` is priced against THAT ceiling (a correct
+    # kernel can never exceed 1 there); the fraction of the dtype's own fp32 MFMA peak -- the figure rounds 1-3 quoted, comparable
+    # across modes -- rides along as `frac_of_dtype_peak` (weight gradients below 160 channels and the 16-channel input convolution
+    # stay on fp32 MFMAs)
     x3_ceiling = PEAK_BF16_MFMA_TFLOPS / 6.0
     kernels = {}
     for k, v in prof.items():
@@ -337,11 +354,11 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
                    'global_batch': batch * world, 'points_per_scene': args.points,
                    'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val, 'warmup_losses': warm_losses},
         'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
-                     'bound': 'mfma', 'achieved': ach, 'peak': peak['conv_gmm'], 'unit': 'TFLOP/s',
-                     'frac': ach / peak['conv_gmm'],
-                     **({'math': 'bf16x3: six v_mfma_f32_16x16x32_bf16 per fp32-equivalent product; peak is the fp32 dense MFMA peak (the dtype\'s), '
-                                 'instruction_peak the ceiling of the instructions that run (bf16 dense peak / 6)',
-                         'instruction_peak': x3_ceiling, 'frac_of_instruction_peak': ach / x3_ceiling} if x3 else {}),
+                     'bound': 'mfma', 'achieved': ach, 'peak': x3_ceiling if x3 else peak['conv_gmm'], 'unit': 'TFLOP/s',
+                     'frac': ach / (x3_ceiling if x3 else peak['conv_gmm']),
+                     **({'math': 'bf16x3: six v_mfma_f32_16x16x32_bf16 per fp32-equivalent product; peak = the ceiling of the instructions that '
+                                 'run (bf16 dense MFMA peak / 6); dtype_peak = the fp32 dense MFMA peak (what rounds 1-3 priced frac against)',
+                         'dtype_peak': peak['conv_gmm'], 'frac_of_dtype_peak': ach / peak['conv_gmm']} if x3 else {}),
                      'traffic': traffic, 'traffic_unit': 'bytes/launch (HBM, PMC)',
                      'traffic_source': traffic_src,
                      'algorithmic_bytes_per_launch': g['bytes'] / max(g['launches'], 1),

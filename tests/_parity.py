@@ -180,11 +180,22 @@ def oracle_fp64_grads(orac, run):
     """Parameter gradients of the SAME oracle in float64 -- the ground truth the fp32 gradients of both the product and the
     fp32 oracle are measured against.  ``run(model)`` must return the oracle_forward dict."""
     import copy
+    global _LAST_FP64_MASKS
     o64 = copy.deepcopy(orac).double().train()
     o64.zero_grad()
-    O = run(o64)
+    _LAST_FP64_MASKS, O = oracle_relu_masks(o64, run)       # the fp64 run's own ReLU decisions: compare() counts the product's flips
     O['loss'].backward()
     return {k: p.grad for k, p in o64.named_parameters() if p.grad is not None}
+
+
+_LAST_FP64_MASKS = None
+
+
+def count_relu_flips(masks64, masks_prod):
+    """BatchNorm+ReLU units on which the product's forward and the fp64 oracle's own forward decide differently."""
+    if not masks64 or not masks_prod or set(masks64) != set(masks_prod):
+        return None
+    return int(sum(int((masks64[k].cpu() != masks_prod[k].cpu()).sum()) for k in masks64))
 
 
 def oracle_perturbed_grads(orac, run, rel_sigma=2e-7, seed=1):
@@ -300,6 +311,7 @@ def compare(name, P, O, prod, orac, g64=None, gpert=None, g64m=None, grad_tol=1e
         err['vs_fp64'] = v
         err['flat_backbone'] = flat_gradient_stats(gsets, g64, bb)
         err['flat_decoder'] = flat_gradient_stats(gsets, g64, dd)
+        err['relu_flips_vs_fp64'] = count_relu_flips(_LAST_FP64_MASKS, P.get('relu_masks'))
     if g64m is not None:
         # THE gradient assertion: fp64 oracle on the product's own activation pattern (oracle_fp64_grads_same_activation_pattern)
         pp = dict(prod.named_parameters())
@@ -319,6 +331,15 @@ def compare(name, P, O, prod, orac, g64=None, gpert=None, g64m=None, grad_tol=1e
     assert err['grad_decoder_max'] < 1e-3, err              # well-conditioned part: the north-star tolerance applies as is
     if g64 is not None:
         assert err['vs_fp64']['product_decoder_max'] < 1e-3, err['vs_fp64']
+        # Against the fp64 oracle's OWN decisions: the decoder side has no decisions to flip, so its flat gradient is
+        # held to the cosine / directional-derivative bounds always; the backbone side whenever the product's forward took every
+        # BatchNorm+ReLU decision the way the fp64 run did (flip count 0) -- otherwise the count is in the log next to the errors
+        fd = err['flat_decoder']['product']
+        assert fd['cos'] >= COS_MIN and max(fd['dir_rel']) <= DIR_TOL, err['flat_decoder']
+        if err['relu_flips_vs_fp64'] == 0 and not SOFT:
+            fb = err['flat_backbone']['product']
+            assert fb['cos'] >= COS_MIN and max(fb['dir_rel']) <= max(DIR_TOL, grad_tol), err['flat_backbone']
+            assert err['vs_fp64']['product_backbone_max'] < grad_tol, err['vs_fp64']
     if g64m is not None and not SOFT:
         m = err['same_activation_pattern']
         # every parameter gradient, backbone included, at the north-star tolerance -- no additive floor, no multiple of a CPU run

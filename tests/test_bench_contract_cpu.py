@@ -47,9 +47,32 @@ def test_gpus_n_turns_itself_into_a_torchrun_launch(monkeypatch):
     assert not seen
 
 
+def test_pmc_traffic_is_refused_on_other_kernel_sources(tmp_path, monkeypatch):
+    """a PMC summary is quoted only when the hashes of the conv kernels' sources match the tree; the roofline block of
+    a three-plane line prices `frac` against the instruction ceiling and keeps the fp32-peak figure beside it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.csrc_hashes()
+    assert set(bench.PMC_SOURCES) <= set(h) and all(len(v) == 16 for v in h.values())
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(bench, 'csrc_hashes', lambda names=None: {n: h[n] for n in (names or h)})
+    rec = {'_spconv_gmm_all': {'hbm_MB_per_launch': 12.5}, '_meta': {'csrc_sha16': dict(h), 'git_head': 'abc'}}
+    (prof / 'round9_pmc_traffic.json').write_text(json.dumps(rec))
+    t, src = bench._pmc_traffic(False)
+    assert t == 12.5e6 and 'round9_pmc_traffic.json' in src
+    rec['_meta']['csrc_sha16']['spconv_wg.hip'] = '0' * 16
+    (prof / 'round9_pmc_traffic.json').write_text(json.dumps(rec))
+    t, src = bench._pmc_traffic(False)
+    assert t is None and 'different kernel sources' in src
+    assert bench._pmc_traffic(True) == (None, None)
+
+
 def test_kept_bench_lines_follow_the_contract():
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round2_final_bench_*.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'round3_bench_*.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round2_final_bench_*.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'round3_bench_*.json')) +
+                   glob.glob(os.path.join(ROOT, 'profiles', 'round4_bench_*.json')))
     assert files, 'no bench line kept under profiles/'
     for f in files:
         d = json.load(open(f))
@@ -65,7 +88,12 @@ def test_kept_bench_lines_follow_the_contract():
         for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
             assert k in r, (f, k)
         assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-        assert d['dtype'] in ('f32', 'bf16') and r['peak'] == (157.3 if d['dtype'] == 'f32' else 2500.0)
+        if 'round4' in os.path.basename(f) and d['config'].get('fp32_math') == 'bf16x3':
+            # round 4 on: a three-plane line prices frac against the instruction ceiling, the fp32-peak figure rides along
+            assert abs(r['peak'] - 2500.0 / 6) < 1e-9 and r['dtype_peak'] == 157.3 and abs(r['frac_of_dtype_peak'] - r['achieved'] / 157.3) < 1e-9
+            assert 0 < r['frac'] < 1 and r['frac_of_dtype_peak'] > r['frac']
+        else:
+            assert d['dtype'] in ('f32', 'bf16') and r['peak'] == (157.3 if d['dtype'] == 'f32' else 2500.0)
         if 'cpu_baseline' in d and d['cpu_baseline']:
             c = d['cpu_baseline']
             assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']

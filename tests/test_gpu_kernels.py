@@ -181,9 +181,17 @@ def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_r
     finally:
         if tile_rows:
             os.environ.pop('U3D_GMM_R') if prev is None else os.environ.__setitem__('U3D_GMM_R', prev)
-    for name, a, b in zip(('subm fwd', 'subm dgrad', 'down fwd', 'down dgrad', 'inverse fwd', 'inverse dgrad'), out['wave'], out['workgroup']):
+    # one difference in summation ORDER: at 32-row tiles the wave-tile kernel takes 64 source channels per unit where the count
+    # allows (low-order plane products of 64 channels summed before they join the running row), the workgroup-tile kernel always
+    # 32 -- there the comparison is to fp32 rounding instead of bit-for-bit
+    exact = operands == 'bf16' or tile_rows == 64
+    for i, (name, a, b) in enumerate(zip(('subm fwd', 'subm dgrad', 'down fwd', 'down dgrad', 'inverse fwd', 'inverse dgrad'), out['wave'], out['workgroup'])):
         assert torch.isfinite(b).all(), name
-        assert torch.equal(a, b), f'{name}: max |diff| {float((a - b).abs().max())}'
+        cs = cin if i in (0, 2, 5) else cout          # source channels of that launch
+        if exact or cs % 64:
+            assert torch.equal(a, b), f'{name}: max |diff| {float((a - b).abs().max())}'
+        else:
+            assert float((a - b).abs().max()) <= 4e-6 * float(a.abs().max()), name
 
 
 def _l2(a, b):

@@ -105,6 +105,30 @@ def test_decoder_joint_datasets_rotated_head_and_empty_scene_on_gpu():
         assert _rel(r['bboxes'][i], G[f'B.box{i}']) < 1e-3
 
 
+def test_mixed_batch_heading_decode_sends_no_nan_through_yaw_free_rows():
+    """in a mixed batch the packed 7-dof decode runs on every row; a yaw-free scene whose raw heading columns are exactly
+    (0, 0) must not turn the zero gradient torch.where sends back into 0 * inf = nan in out_bboxes.linear (the reference never
+    evaluates those columns for such scenes).  Heading rows keep their own values: their boxes equal the single-dataset decode."""
+    from unidet3d_amd.encoder import UniDet3DEncoder
+    cfg = dict(num_layers=1, datasets_classes=[CLASSES, CLASSES_B], in_channels=32, d_model=256, num_heads=8,
+               hidden_dim=1024, dropout=0.0, activation_fn='gelu', datasets=['scannet', 's3dis'], angles=[False, True])
+    m = fill_state_dict(UniDet3DEncoder(**cfg), tag0=700).to(DEV)
+    with torch.no_grad():
+        m.out_norm.bias.zero_()
+        m.out_bboxes.linear.bias[6:8].zero_()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.cat((torch.randn(40, 256, generator=g), torch.zeros(24, 256))).to(DEV)        # rows 40..63: LayerNorm -> 0 -> raw heading (0, 0)
+    centers = torch.randn(64, 3, generator=g).to(DEV)
+    cls, boxes, (cls_all, box_p) = m._forward_head(feats, [40, 24], None, centers, ['s3dis', 'scannet'])
+    assert box_p.shape == (64, 7) and boxes[0].shape == (40, 7) and boxes[1].shape == (24, 6)
+    assert torch.equal(box_p[:40], boxes[0]) and torch.equal(box_p[40:, :6], boxes[1]) and float(box_p[40:, 6].abs().max()) == 0.0
+    (box_p.sum() + cls_all.sum()).backward()
+    for name, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), name
+    assert m.out_bboxes.linear.weight.grad is not None and float(m.out_bboxes.linear.weight.grad[6:8].abs().max()) > 0     # heading rows still train
+
+
 # ---------------------------------------------------------------------------- end to end vs the oracle
 def _build_pair(num_layers=6):
     import unidet3d_amd  # noqa: F401

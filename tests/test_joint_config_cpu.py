@@ -78,8 +78,12 @@ def test_prefetch_is_a_no_op_off_gpu_and_tensor_walk_finds_nested_tensors():
     found = list(_tensors_of(dict(a=[t1, (Box(t2),)], s=Slotted(t1, Slotted(t2, None)), deep=deep, f=t1), cuda_only=False))
     assert len(found) == 3 and {id(t) for t in found} == {id(t1), id(t2), id(t3)}
     import pytest
-    with pytest.raises(TypeError):                      # an object the walk cannot look into must not be skipped silently
-        list(_tensors_of([object()], cuda_only=False))
+    # an object the walk cannot look into (no __dict__ / __slots__, not a container) is an opaque leaf: one warning per type,
+    # the tensors next to it are still found (a datetime / Enum / Path in a batch must not stop training)
+    import datetime
+    with pytest.warns(UserWarning, match='opaque leaf'):
+        got = list(_tensors_of([object(), datetime.date(2024, 1, 1), t1], cuda_only=False))
+    assert len(got) == 1 and got[0] is t1
     model = build_model(scannet_model_cfg(voxel_size=0.05))
     model.prefetch(dict(points=[torch.zeros(10, 6)]), [])
     assert model._prefetched is None

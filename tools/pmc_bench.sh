@@ -24,12 +24,14 @@ for k, v in sorted(res.items(), key=lambda kv: -kv[1]['fetch_kb']):
     n = max(v['n'], 1)
     summ[k] = dict(dispatches=n, fetch_MB_per_launch_corrected=2.0 * v['fetch_kb'] * 1024 / n / 1e6,
                    write_MB_per_launch=v['write_kb'] * 1024 / n / 1e6)
-gm = [v for k, v in res.items() if 'spconv_gmm_k' in k]
+gm = [v for k, v in res.items() if 'spconv_gmm' in k]          # wave-tile and workgroup-tile forward / input-gradient kernels
 n = sum(v['n'] for v in gm)
-summ['_spconv_gmm_k_all'] = dict(dispatches=n, hbm_MB_per_launch=(2.0 * sum(v['fetch_kb'] for v in gm) + sum(v['write_kb'] for v in gm)) * 1024 / max(n, 1) / 1e6)
-import hashlib, os
+summ['_spconv_gmm_all'] = dict(dispatches=n, hbm_MB_per_launch=(2.0 * sum(v['fetch_kb'] for v in gm) + sum(v['write_kb'] for v in gm)) * 1024 / max(n, 1) / 1e6)
+import os
 root = os.environ.get('GRAFT_REPO_ROOT', '.')
-summ['_meta'] = dict(spconv_hip_sha16=hashlib.sha256(open(f'{root}/unidet3d_amd/csrc/spconv.hip', 'rb').read()).hexdigest()[:16],
+sys.path.insert(0, root)
+import bench
+summ['_meta'] = dict(csrc_sha16=bench.csrc_hashes(),        # every kernel source this pass covers; bench.py refuses the file on a mismatch
                      command='python bench.py --steps 2 --warmup 1 --no-cpu-baseline under rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes)',
                      correction='FETCH_SIZE x 2 (gfx950 wide coalesced streams, MI355X_MICROARCH.md), WRITE_SIZE as reported; KB -> bytes x 1024')
 json.dump(summ, open(f'{out}/summary.json', 'w'), indent=1)

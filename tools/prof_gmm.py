@@ -38,10 +38,12 @@ def timed(f):
     return ms / max(cnt, 1) * 1e3
 
 
-total = {'wave': 0.0, 'workgroup': 0.0}
+KINDS = os.environ.get('PROF_KINDS', 'wave,workgroup').split(',')
+MAXLV = int(os.environ.get('PROF_MAXLV', '5'))
+total = {k: 0.0 for k in KINDS}
 ctx = P.operands('bf16') if operands == 'bf16' else P.fp32_math('bf16x3')
 with ctx:
-    for lv, c, rb in levels:
+    for lv, c, rb in levels[:MAXLV]:
         n = c.shape[0]
         C = 32 * lv
         for cs, cd in ((C, C), (2 * C, C)) if lv < 5 else ((C, C),):
@@ -51,12 +53,13 @@ with ctx:
             gf = 2.0 * pairs * cs * cd / 1e9
             row = f'level {lv} n={n:7d} {cs:3d}->{cd:3d} pairs/voxel {pairs / n:5.2f} {gf:6.2f} GF:'
             ys = {}
-            for kind in ('wave', 'workgroup'):
+            for kind in KINDS:
                 with P.conv_kernel(kind):
                     us = timed(lambda: sparse.sparse_conv(x, w, rb))
                     ys[kind] = sparse.sparse_conv(x, w, rb)
                 total[kind] += us
                 row += f'  {kind} {us:7.1f} us ({gf / us * 1e-3:6.1f} TF/s)'
-            row += '  equal' if torch.equal(ys['wave'], ys['workgroup']) else f'  DIFF {float((ys["wave"] - ys["workgroup"]).abs().max()):.3e}'
+            if len(KINDS) == 2:
+                row += '  equal' if torch.equal(ys['wave'], ys['workgroup']) else f'  DIFF {float((ys["wave"] - ys["workgroup"]).abs().max()):.3e}'
             print(row, flush=True)
 print('sum of shapes:', {k: round(v, 1) for k, v in total.items()}, flush=True)

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void hash_coords_k(const int64_t* __restrict__
 
 static size_t sort_ws(int64_t n) {
     size_t a = 0, b = 0;
-    hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const int64_t*)nullptr, (int64_t*)nullptr, (int)n);
+    hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const int64_t*)nullptr, (int64_t*)nullptr, (int)n, 0, 63);      // the bit range the sort below uses
     hipcub::DeviceSelect::Unique(nullptr, b, (const int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr, (int)n);
     return (a > b ? a : b) + 256;
 }

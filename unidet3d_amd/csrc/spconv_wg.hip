@@ -17,14 +17,33 @@
 
 #include "spconv_gmm.h"
 
+// Timing ablations (tools/build_variant.sh <out.so> spconv_wg.hip -DU3D_WGK_ABL=<mask>; results are WRONG by construction, never
+// shipped): 1 no MFMAs (operands kept alive), 2 no split arithmetic, 4 no barriers, 8 no row gathers, 16 every gather hits rows
+// 0..63, 32 no accumulator read-modify-write, 64 LDS padded to two workgroups per CU, 128 no weight-fragment reads, 256 no staging
+// transposition, 512 no index loads
+#ifndef U3D_WGK_ABL
+#define U3D_WGK_ABL 0
+#endif
+
 namespace u3d {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ f32x4 wg_mfma(const f32x4& a, const bf16x8& b, const f32x4& c) {
+    if constexpr ((U3D_WGK_ABL & 1) != 0) {
+        f32x4 r = c;
+        asm volatile("" : "+v"(r) : "v"(a), "v"(b));
+        return r;
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
+    }
+}
 
 // float index of (row r, 16-byte quad c4) in the accumulator tile: 128-byte rows, quad stored at c4 ^ (r & 7)
 __device__ __forceinline__ int wg_acc_idx(int r, int c4) { return r * 32 + ((c4 ^ (r & 7)) << 2); }
 
 __device__ __forceinline__ void wg_barrier() {      // LDS traffic of this wave done, then the workgroup barrier; vmcnt is NOT drained
+    if constexpr ((U3D_WGK_ABL & 4) != 0) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -37,7 +56,9 @@ constexpr int wg_slot_bytes(int cs16, int pr) { return (cs16 / 2) * (pr == 2 ? 6
 constexpr int wg_fixed_bytes(int r) { return (wg_acc_floats(r) + 4 * WG_STAGE_FLOATS) * 4; }
 // two weight slots (one barrier per offset) where three workgroups per CU still fit, otherwise one slot (two barriers)
 constexpr int wg_nslot(int cs16, int r, int pr) { return 3 * (wg_fixed_bytes(r) + 2 * wg_slot_bytes(cs16, pr)) <= 160 * 1024 ? 2 : 1; }
-constexpr int wg_lds_bytes(int cs16, int r, int pr) { return wg_fixed_bytes(r) + wg_nslot(cs16, r, pr) * wg_slot_bytes(cs16, pr); }
+constexpr int wg_lds_bytes(int cs16, int r, int pr) {
+    return wg_fixed_bytes(r) + wg_nslot(cs16, r, pr) * wg_slot_bytes(cs16, pr) + ((U3D_WGK_ABL & 64) ? 26 * 1024 : 0);
+}
 
 struct WgItem {
     int k, base, e;      // wave-uniform; when !valid the fields still name a real item (addresses stay legal)
@@ -112,6 +133,13 @@ struct GmmWgWave {
     __device__ __forceinline__ void load_idx(const WgItem& it, int (&g)[NI], int (&s_)[NCH]) const {
         const int soff_k = (int)(it.k * cap) * 4;
         const int vg = cg + it.base * 4, vs = cs_ + it.base * 4;
+        if constexpr ((U3D_WGK_ABL & 512) != 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) g[i] = (vg + i * 32 + soff_k) & 0xffff;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) s_[c] = row0 + ((vs + c * 64) >> 2 & (TR - 1));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) g[i] = bload32(rs_g, vg + i * 32, soff_k);
 #pragma unroll
@@ -119,8 +147,13 @@ struct GmmWgWave {
     }
     __device__ __forceinline__ void issue(Buf& buf, const int (&g)[NI], int u) const {
         const int lp16 = (lane & 7) * 16;
+        if constexpr ((U3D_WGK_ABL & 8) != 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) buf.a[i] = bload128(rs_src, (int)__umul24(g[i], cs4) + lp16, u * 128);
+            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(buf.a[i]) : "v"(g[i]));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) buf.a[i] = bload128(rs_src, (int)__umul24((U3D_WGK_ABL & 16) ? (g[i] & 63) : g[i], cs4) + lp16, u * 128);
     }
     static __device__ __forceinline__ bf16x8 cvt8(const f32x4& lo, const f32x4& hi) {
         return bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
@@ -129,6 +162,11 @@ struct GmmWgWave {
     // rows of one 16-pair chunk: registers -> swizzled LDS image -> fragments (in-order LDS queue of one wave: no barrier)
     template <int C>
     __device__ __forceinline__ Frag frags(const Buf& buf) const {
+        if constexpr ((U3D_WGK_ABL & 256) != 0) {
+            Frag f;
+            f.v[0] = buf.a[C * 2]; f.v[1] = buf.a[C * 2 + 1];
+            return f;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(stage + wr_off + i * 256) = buf.a[C * 2 + i];
         Frag f;
@@ -223,7 +261,9 @@ struct GmmWgWave {
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
-        if constexpr (U == 0) {                // accumulator rows of the item -> C operands
+        if constexpr (U == 0 && (U3D_WGK_ABL & 32) != 0) {
+            d00 = f32x4{0.f, 0.f, 0.f, 0.f}; d01 = d00; d10 = d00; d11 = d00;
+        } else if constexpr (U == 0) {                // accumulator rows of the item -> C operands
             d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
             d01 = *reinterpret_cast<const f32x4*>(accq + (soff0 ^ 64));
             if (two) {
@@ -238,7 +278,10 @@ struct GmmWgWave {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) wf[nb][q] = *reinterpret_cast<const f32x4*>(wslot + wrd + U * WB + (nb * NPL + q) * 1024);
+            for (int q = 0; q < NPL; ++q) {
+                if constexpr ((U3D_WGK_ABL & 128) != 0) asm volatile("" : "=v"(wf[nb][q]));
+                else wf[nb][q] = *reinterpret_cast<const f32x4*>(wslot + wrd + U * WB + (nb * NPL + q) * 1024);
+            }
         WgItem it2;
         int g2[NI], s2[NCH], n0 = 0, n1 = 0;
         if constexpr (U == NJB - 1) {
@@ -260,11 +303,11 @@ struct GmmWgWave {
             for (int o = 2; o >= 1; --o)
 #pragma unroll
                 for (int qa = 0; qa <= o; ++qa) {
-                    t00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][qa]), x0[o - qa], t00, 0, 0, 0);
-                    t01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][qa]), x0[o - qa], t01, 0, 0, 0);
+                    t00 = wg_mfma(wf[0][qa], x0[o - qa], t00);
+                    t01 = wg_mfma(wf[1][qa], x0[o - qa], t01);
                 }
-            d00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][0]), x0[0], d00, 0, 0, 0);
-            d01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][0]), x0[0], d01, 0, 0, 0);
+            d00 = wg_mfma(wf[0][0], x0[0], d00);
+            d01 = wg_mfma(wf[1][0], x0[0], d01);
             if (two) {
                 bf16x8 x1[3];
                 split3_x8(f1.v[0], f1.v[1], x1);
@@ -272,30 +315,33 @@ struct GmmWgWave {
                 for (int o = 2; o >= 1; --o)
 #pragma unroll
                     for (int qa = 0; qa <= o; ++qa) {
-                        t10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][qa]), x1[o - qa], t10, 0, 0, 0);
-                        t11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][qa]), x1[o - qa], t11, 0, 0, 0);
+                        t10 = wg_mfma(wf[0][qa], x1[o - qa], t10);
+                        t11 = wg_mfma(wf[1][qa], x1[o - qa], t11);
                     }
-                d10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][0]), x1[0], d10, 0, 0, 0);
-                d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][0]), x1[0], d11, 0, 0, 0);
+                d10 = wg_mfma(wf[0][0], x1[0], d10);
+                d11 = wg_mfma(wf[1][0], x1[0], d11);
                 d10 += t10; d11 += t11;
             }
             d00 += t00; d01 += t01;
         } else {
             const bf16x8 x0 = cvt8(f0.v[0], f0.v[1]);
-            d00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][0]), x0, d00, 0, 0, 0);
-            d01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][0]), x0, d01, 0, 0, 0);
+            d00 = wg_mfma(wf[0][0], x0, d00);
+            d01 = wg_mfma(wf[1][0], x0, d01);
             if (two) {
                 const bf16x8 x1 = cvt8(f1.v[0], f1.v[1]);
-                d10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][0]), x1, d10, 0, 0, 0);
-                d11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][0]), x1, d11, 0, 0, 0);
+                d10 = wg_mfma(wf[0][0], x1, d10);
+                d11 = wg_mfma(wf[1][0], x1, d11);
             }
         }
+        if constexpr (U == NJB - 1 && (U3D_WGK_ABL & 32) != 0) asm volatile("" :: "v"(d00), "v"(d01), "v"(d10), "v"(d11));
         if constexpr (U == NJB - 1) {
+            if constexpr ((U3D_WGK_ABL & 32) == 0) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
             *reinterpret_cast<f32x4*>(accq + (soff0 ^ 64)) = d01;
             if (two) {
                 *reinterpret_cast<f32x4*>(accq + soff1) = d10;
                 *reinterpret_cast<f32x4*>(accq + (soff1 ^ 64)) = d11;
+            }
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) { g_cur[i] = ix1_g[i]; ix1_g[i] = g2[i]; }

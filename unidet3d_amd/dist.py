@@ -17,6 +17,27 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE = False
+
+
+def force_collectives(on: bool = True) -> bool:
+    """Issue every collective of the data-parallel path even when the process group has ONE rank (SyncBatchNorm sums, gradient
+    buckets, the buckets' own communicator).  A single-GPU box can then drive the exact RCCL call sequence of an N-GPU run --
+    communicator creation, fp64 / fp32 all-reduces, stream hand-over -- with results that must equal the non-distributed step bit
+    for bit (tests/test_gpu_dist.py).  Returns the previous setting."""
+    global _FORCE
+    prev, _FORCE = _FORCE, bool(on)
+    return prev
+
+
+def collectives_on(group=None) -> bool:
+    """True when the data-parallel collectives are to be issued: a process group with more than one rank, or any initialised group
+    under ``force_collectives()``."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return _FORCE or dist.get_world_size(group) > 1
+
+
 class FlatGradBucket:
     """One flat fp32 buffer for all parameter gradients.
 
@@ -71,7 +92,7 @@ class FlatGradBucket:
 
     def allreduce_mean(self, group=None):
         """Sum over ranks / world size (DDP semantics).  No-op without a process group."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if collectives_on(group):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
 
@@ -82,7 +103,7 @@ class FlatGradBucket:
         all-reduce is launched asynchronously.  Use with ``clear_grads()`` before and ``finish()`` after backward.
         Assumes every parameter receives at most one gradient per backward (true for this model); ``finish()`` raises
         if a second accumulation hit a bucket that was already launched."""
-        if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if group is None and collectives_on():
             # a communicator of its own: the (blocking) SyncBatchNorm all-reduces of the backbone's backward would otherwise
             # queue behind a 16 MB bucket on the shared one.  Collective call: every rank reaches enable_overlap().
             group = dist.new_group()
@@ -136,7 +157,7 @@ class FlatGradBucket:
         if src:
             torch._foreach_copy_(dst, src)
         b['launched'] = True
-        if self._world() > 1:
+        if collectives_on(self.group):
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=not sync)
 
     def finish(self):
@@ -152,7 +173,7 @@ class FlatGradBucket:
                 raise RuntimeError('FlatGradBucket: a parameter received a second gradient after its bucket was launched; '
                                    'use pack() + allreduce_mean() for graphs that reuse parameters')
         w = self._world()
-        if w > 1:
+        if w > 1 or collectives_on(self.group):
             self.flat.div_(w)
         for b in self.buckets:
             b.update(pending=b['hi'] - b['lo'], launched=False, dirty=False, work=None)
@@ -172,12 +193,13 @@ class FlatGradBucket:
         return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params)
 
 
-def init_from_env(backend: str = 'nccl'):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank)."""
+def init_from_env(backend: str = 'nccl', force: bool = False):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank).  ``force``: create the
+    process group even for WORLD_SIZE = 1 (see ``force_collectives``)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         kw = {}
@@ -188,6 +210,6 @@ def init_from_env(backend: str = 'nccl'):
 
 
 def broadcast_params(module: torch.nn.Module, src: int = 0):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_on():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src)

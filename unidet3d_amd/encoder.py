@@ -218,7 +218,16 @@ class UniDet3DEncoder(nn.Module):
         b6 = _bbox_pred_to_bbox(centers_packed, box_all[:, :6])
         idxs = [self.datasets.index(name) for name in datasets_names]
         any_yaw = any(self.angles[i] for i in idxs)
-        b7 = _bbox_pred_to_bbox(centers_packed, box_all) if any_yaw else None
+        b7 = yaw_rows = None
+        if any_yaw:
+            # The reference never evaluates the heading columns of a yaw-free dataset's scenes (encoder.py:186-199).  The packed decode
+            # runs on every row, so those rows get a harmless heading (0, 1) BEFORE exp(sqrt(a^2 + b^2)) / atan2: with their own
+            # values -- a = b = 0 exactly, or an overflowing exp -- the zero gradient torch.where sends back would meet inf / nan
+            # factors in sqrt's and exp's backward (0 * inf = nan in out_bboxes.linear's gradient).  Heading rows are untouched.
+            flags = L.h2d([bool(self.angles[i]) for i in idxs], torch.bool, feats.device)
+            yaw_rows = torch.repeat_interleave(flags, L.h2d(list(sizes), torch.int64, feats.device), output_size=int(sum(sizes)))[:, None]
+            safe = torch.where(yaw_rows, box_all[:, 6:8], box_all.new_tensor([0.0, 1.0]))
+            b7 = _bbox_pred_to_bbox(centers_packed, torch.cat((box_all[:, :6], safe), dim=1))
         cls_preds, boxes = [], []
         for c, p6, p7, raw, idx in zip(cls_all.split(sizes), b6.split(sizes), b7.split(sizes) if any_yaw else [None] * len(sizes),
                                        box_all.split(sizes), idxs):
@@ -228,8 +237,6 @@ class UniDet3DEncoder(nn.Module):
             else:
                 boxes.append(p7 if self.angles[idx] else p6)
         if any_yaw:      # [M, 7] for the criterion kernel: heading rows from b7, the others from b6 with a zero heading column
-            flags = L.h2d([bool(self.angles[i]) for i in idxs], torch.bool, feats.device)
-            yaw_rows = torch.repeat_interleave(flags, L.h2d(list(sizes), torch.int64, feats.device), output_size=int(sum(sizes)))[:, None]
             box_p = torch.where(yaw_rows, b7, torch.nn.functional.pad(b6, (0, 1)))
         else:
             box_p = b6

@@ -81,8 +81,11 @@ class OccupancyIndex:
         slots = L.lib().u3d_hash_index_slots(n)
         ukeys = torch.empty(n, dtype=torch.int64, device=dev)
         n_dev = torch.empty(1, dtype=torch.int32, device=dev)
-        keys = torch.empty(slots, dtype=torch.int64, device=dev)
         vals = torch.empty(slots, dtype=torch.int32, device=dev)
+        if n == 0:                 # an empty level / point set: a table of free slots, zero rows (the C entry points take n > 0 only)
+            keys = torch.full((slots,), -1, dtype=torch.int64, device=dev)
+            return OccupancyIndex(keys, vals, B, shape, slots, ukeys, n_dev.zero_())
+        keys = torch.empty(slots, dtype=torch.int64, device=dev)
         w = L.ws(L.lib().u3d_hash_index_ws_bytes(n), dev)
         L.call('u3d_hash_index_build', L.ptr(cells), n, L.ptr(ukeys), L.ptr(n_dev), L.ptr(keys), L.ptr(vals), slots, L.ptr(w), L.stream())
         return OccupancyIndex(keys, vals, B, shape, slots, ukeys, n_dev)
@@ -108,6 +111,8 @@ class OccupancyIndex:
         shape = [int(s) for s in shape]
         if OccupancyIndex.wants_hash(B, shape):
             cells = torch.empty(coords.shape[0], dtype=torch.int64, device=coords.device)
+            if coords.shape[0] == 0:
+                return OccupancyIndex.from_cells(cells, B, shape)
             L.call('u3d_cells_of_coords', L.ptr(coords), coords.shape[0], shift, B, *shape, L.ptr(cells), L.stream())
             return OccupancyIndex.from_cells(cells, B, shape)
         ix = OccupancyIndex.alloc(B, shape, coords.device)
@@ -207,7 +212,8 @@ class WeightPacks:
     refreshed by ONE launch (u3d_weight_pack_batch) instead of one pack launch in front of each of the ~90 convolution launches
     of a step.
 
-    Validity contract: in TRAINING mode every ``refresh()`` repacks (one launch per step -- what a changed weight costs anyway),
+    Validity contract: in TRAINING mode -- and in eval mode while any convolution weight carries a ``.grad`` (fine-tuning with
+    frozen batch norm) -- every ``refresh()`` repacks (one launch per step -- what a changed weight costs anyway),
     and the first eval-mode ``refresh()`` after a training-mode one repacks too, so no optimizer can leave a stale pack behind.
     Otherwise (eval mode) a pack is reused while ``(data_ptr, Tensor._version)`` of every weight is unchanged.  ``_version`` is
     bumped by torch's for-loop / foreach optimizers, ``load_state_dict`` and in-place ops on the parameter, but NOT by
@@ -243,9 +249,12 @@ class WeightPacks:
         bf = P.conv_format()           # 0 fp32 fragments, 1 bf16, 2 three bf16 planes (precision.conv_format)
         dev = self.convs[0].weight.device
         state = (bf, str(dev), tuple((m.weight.data_ptr(), m.weight._version) for m in self.convs))
-        if state == self.state and not self.root.training and not self.dirty:
+        # a root kept in eval() (frozen batch norm) while an optimizer steps it: a weight that carries a gradient can change
+        # behind _version's back (fused AdamW), so such a model repacks every time, exactly like training mode
+        tuned = any(m.weight.grad is not None for m in self.convs)
+        if state == self.state and not self.root.training and not self.dirty and not tuned:
             return
-        self.dirty = bool(self.root.training)
+        self.dirty = bool(self.root.training or tuned)
         rebuild = self.state is None or self.state[0] != bf or self.state[1] != str(dev) or \
             [a for a, _ in self.state[2]] != [a for a, _ in state[2]]
         if rebuild:
@@ -418,7 +427,8 @@ def sparse_conv(src, weight, rb, mode='fwd', addend=None, stats_out=None):
 # batch norm (+ReLU)
 # ----------------------------------------------------------------------------------------
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    from .dist import collectives_on          # > 1 rank, or any initialised group under dist.force_collectives()
+    return collectives_on()
 
 
 def allreduce_bn_sums(sums: torch.Tensor, group=None):

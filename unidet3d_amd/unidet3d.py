@@ -15,6 +15,8 @@ from __future__ import annotations
 import contextlib
 from typing import List, Optional
 
+import warnings
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -26,10 +28,15 @@ from .sparse import SparseBatchNorm, SparseConvTensor, SparseSequential, SubMCon
 from .structures import DepthInstance3DBoxes, InstanceData_
 
 
+_OPAQUE_SEEN = set()
+
+
 def _tensors_of(obj, cuda_only: bool = True):
     """Every CUDA tensor reachable from ``obj`` through lists / tuples / sets / dicts and object attributes (``__dict__`` and
     ``__slots__``), to any depth.  The walk exists to ``record_stream`` tensors that cross from the side stream to the main one:
-    a tensor it missed could be recycled by the caching allocator while still in use, so an object it cannot look into raises."""
+    a tensor it missed could be recycled by the caching allocator while still in use.  Objects without ``__dict__`` / ``__slots__``
+    that are not containers (datetime, Decimal, Enum members, Path, C-extension handles ...) cannot hold tensors the walk could
+    reach: they are skipped as opaque leaves, with one warning per type."""
     seen, stack = set(), [obj]
     while stack:
         o = stack.pop()
@@ -57,9 +64,10 @@ def _tensors_of(obj, cuda_only: bool = True):
                     found = True
                     if name not in ('__dict__', '__weakref__') and hasattr(o, name):
                         stack.append(getattr(o, name))
-            if not found and not callable(o):
-                raise TypeError(f'prefetch: cannot look for tensors inside a {type(o).__name__}; hand batches over as '
-                                'lists / dicts / attribute objects')
+            if not found and not callable(o) and type(o) not in _OPAQUE_SEEN:
+                _OPAQUE_SEEN.add(type(o))
+                warnings.warn(f'prefetch: treating {type(o).__module__}.{type(o).__name__} as an opaque leaf (no __dict__ / __slots__ to '
+                              'look for tensors in); hand tensors over in lists / dicts / attribute objects', stacklevel=2)
 
 
 @MODELS.register_module()

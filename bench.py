@@ -41,6 +41,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5'],
+                    help="workload: cfg2 = BASELINE.json configs[1] (the metric's configuration; default; the line also carries cfg3); "
+                         "cfg4 = configs[3]'s per-GPU share: the six-dataset joint model, 8 mixed scenes of 100k / 180k / 200k points by "
+                         "dataset; cfg5 = configs[4]'s per-GPU share: ONE S3DIS-shape room of 1 M points.  cfg4 / cfg5 print the same "
+                         "line shape (value in scenes/s of THAT workload) and never stand in for the headline")
     ap.add_argument('--batch', type=int, default=None, help='scenes per GPU (cfg2: 8; cfg3 = --dtype bf16: 16)')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
                     help="MFMA operand precision of the HEADLINE: fp32 = BASELINE configs[1] (default), bf16 = configs[2] "
@@ -169,6 +174,9 @@ def log(msg: str):
 
 
 FAMILY_NAMES = ('conv_gmm', 'conv_wgrad', 'attn_fwd', 'attn_bwd', 'gemm')
+# bench.py --config cfg4: (dataset, points) of the 8 scenes of one GPU's batch of the joint six-dataset config
+CFG4_SCENES = [('scannet', 100_000), ('arkitscenes', 100_000), ('s3dis', 200_000), ('multiscan', 100_000), ('3rscan', 100_000),
+               ('scannetpp', 180_000), ('scannet', 100_000), ('arkitscenes', 100_000)]
 
 
 # sources the timed sparse-convolution kernels are built from: a PMC file is only quoted when it was taken on exactly these
@@ -221,7 +229,12 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
         precision.set_fp32_math(fp32_math or args.fp32_math)
     x3 = dtype == 'fp32' and precision.get_fp32_math() == 'bf16x3'
     torch.manual_seed(0)
-    model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)
+    wl = getattr(args, 'config', 'cfg2')
+    if wl == 'cfg4':
+        from unidet3d_amd.config import joint_model_cfg
+        model = build_model(joint_model_cfg()).to(dev)
+    else:
+        model = build_model(scannet_model_cfg(voxel_size=args.voxel_size)).to(dev)
     model.train()
     broadcast_params(model)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -234,9 +247,21 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
     else:
         opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)      # configs/unidet3d_1xb8_scannet.py:712
 
-    log(f'rank {rank}/{world}: [{dtype}] model built, generating {batch} scenes')
-    scenes = [make_scene(rank * batch + i, n_points=args.points) for i in range(batch)]
-    inputs, samples = make_batch_inputs(scenes, dev)                              # resident in HBM before timing
+    log(f'rank {rank}/{world}: [{dtype}] model built, generating {batch} scenes ({wl})')
+    if wl == 'cfg4':
+        # 100k - 200k points per scene by dataset; the scene's surface grows with its point count so that the
+        # voxel density stays ScanNet's (S3DIS rooms and ScanNet++ laser scans are the large ones)
+        from unidet3d_amd.config import joint_model_cfg
+        from unidet3d_amd.data import make_joint_batch
+        specs = [(n, p, p / 100_000) for n, p in CFG4_SCENES][:batch]
+        scenes, _names, _gtb, inputs, samples = make_joint_batch(joint_model_cfg(), specs, dev, seed0=200 + rank * batch)
+    elif wl == 'cfg5':
+        scenes = [make_scene(500 + rank * batch + i, n_points=1_000_000, area_scale=10.0, n_furniture=40) for i in range(batch)]
+        inputs, samples = make_batch_inputs(scenes, dev)
+    else:
+        scenes = [make_scene(rank * batch + i, n_points=args.points) for i in range(batch)]
+        inputs, samples = make_batch_inputs(scenes, dev)                          # resident in HBM before timing
+    n_points_total = int(sum(len(sc.points) for sc in scenes))
 
     inflight = collections.deque()
 
@@ -342,8 +367,13 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
         'unit': 'scenes/s',
         'ms_per_step': dt / args.steps * 1e3,
         'dtype': 'bf16' if bf else 'f32',
-        'config': {'workload': f'{"cfg3" if bf else "cfg2"}: {batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
-                               f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, '
+        'config': {'workload': ((f'cfg4 (BASELINE.json configs[3], one GPU\'s share): {batch} mixed synthetic scenes/GPU over the six datasets '
+                                 f'({", ".join(f"{n} {p // 1000}k" for n, p in CFG4_SCENES[:batch])} pts), 0.02 m voxels, the joint '
+                                 'unidet3d_1xb8_scannet_s3dis_multiscan_3rscan_scannetpp_arkitscenes model (7-dof head, rotated DIoU), ') if wl == 'cfg4' else
+                                (f'cfg5 (BASELINE.json configs[4], one GPU\'s share): {batch} synthetic S3DIS-shape room/GPU x 1M pts, '
+                                 f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, ') if wl == 'cfg5' else
+                                f'{"cfg3" if bf else "cfg2"}: {batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
+                                f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, ')
                                + ('bf16 MFMA operands (sparse conv fwd/dgrad/wgrad, Linear fwd/dX/dW, attention), fp32 accumulate/BN/softmax/optimizer; '
                                   if bf else ('fp32 (products from three exact bf16 planes per operand on the bf16 matrix pipe, fp32 accumulation, '
                                               'fp32-level error; --fp32-math mfma = native fp32 MFMAs); ' if x3 else 'fp32 (native fp32 MFMAs); ')) +
@@ -351,7 +381,8 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
                                + ('' if args.no_prefetch else "; each step's voxelise+rulebook part is queued on a side stream during "
                                   "the previous step's backward"),
                    'front_prefetch': not args.no_prefetch, 'fp32_math': ('bf16x3' if x3 else 'mfma') if not bf else None,
-                   'global_batch': batch * world, 'points_per_scene': args.points,
+                   'global_batch': batch * world, 'points_per_scene': args.points if wl == 'cfg2' else n_points_total // max(batch, 1),
+                   'points_per_gpu': n_points_total,
                    'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val, 'warmup_losses': warm_losses},
         'roofline': {'kernel': 'spconv_gmm_k (sparse conv forward + input-gradient, all levels)',
                      'bound': 'mfma', 'achieved': ach, 'peak': x3_ceiling if x3 else peak['conv_gmm'], 'unit': 'TFLOP/s',
@@ -397,7 +428,9 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     dev = torch.device('cuda', local_dev)
 
-    head_batch = args.batch if args.batch is not None else (16 if args.dtype == 'bf16' else 8)
+    head_batch = args.batch if args.batch is not None else (1 if args.config == 'cfg5' else (16 if args.dtype == 'bf16' else 8))
+    if args.config != 'cfg2':      # the extra blocks (native MFMAs, cfg3, CPU baseline) belong to the headline line
+        args.no_mfma_line = args.no_cfg3 = args.no_cpu_baseline = True
     head = measure(args, args.dtype, head_batch, rank, world, dev)
     # The two extra blocks below belong to the single-GPU line only: at N > 1 every further configuration builds a second model,
     # gradient bucket and communicator inside the same job -- measured with 2 gloo ranks: an ~11 s one-time stall lands somewhere in

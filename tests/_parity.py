@@ -47,17 +47,8 @@ def build_pair(cfg, tag0=3000, scale=0.06):
 
 
 def scene_boxes(sc):
-    """Axis-aligned GT boxes (centre, size) [n_inst, 6] of a synthetic scene in its ORIGINAL frame (what a dataset with
-    box annotations stores); instances without points are dropped together with their labels."""
-    xyz = sc.points[:, :3]
-    boxes, keep = [], []
-    for j in range(len(sc.labels)):
-        m = sc.instance_mask == j
-        if m.any():
-            lo, hi = xyz[m].min(0), xyz[m].max(0)
-            boxes.append(np.concatenate(((lo + hi) / 2, hi - lo)))
-            keep.append(j)
-    return np.stack(boxes).astype(np.float32), np.asarray(keep)
+    from unidet3d_amd.data import scene_boxes as _sb
+    return _sb(sc)
 
 
 def oracle_forward(orac, scenes, names, crit_cfg=None, det_cfg=None, gt_boxes=None, train_topk=6):

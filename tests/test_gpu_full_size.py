@@ -170,35 +170,10 @@ JOINT_SCENES = [('scannet', 40_000), ('arkitscenes', 30_000), ('s3dis', 50_000),
                 ('scannetpp', 40_000), ('scannet', 30_000), ('arkitscenes', 35_000)]
 
 
-def _joint_batch(cfg):
-    """Synthetic mixed batch following each dataset's annotation style (configs/...arkitscenes.py:36-43): ScanNet / S3DIS carry
-    instance masks (bbox_by_mask), the others boxes (ARKitScenes with a heading) and get their masks by distance."""
-    from unidet3d_amd.data import make_batch_inputs
-    from unidet3d_amd.structures import DepthInstance3DBoxes
-    from unidet3d_amd.synthetic import make_scene
-    dec = cfg['decoder']
-    scenes, names, gt_boxes = [], [], []
-    rng = np.random.default_rng(4)
-    for i, (name, n_pts) in enumerate(JOINT_SCENES):
-        d = dec['datasets'].index(name)
-        sc = make_scene(200 + i, n_points=n_pts, n_classes=len(dec['datasets_classes'][d]), dataset=name)
-        scenes.append(sc); names.append(name)
-        if cfg['bbox_by_mask'][d]:
-            gt_boxes.append(None)
-        else:
-            b, keep = PA.scene_boxes(sc)
-            if dec['angles'][d]:
-                b = np.concatenate((b, rng.uniform(-0.6, 0.6, (len(b), 1)).astype(np.float32)), 1)
-            gt_boxes.append((b, sc.labels[keep]))
-    inputs, samples = make_batch_inputs(scenes, DEV)
-    for ds, gb in zip(samples, gt_boxes):
-        if gb is not None:
-            b, lab = gb
-            ds.gt_instances_3d.labels_3d = torch.from_numpy(lab).to(DEV)
-            ds.gt_instances_3d.sp_masks = ds.gt_instances_3d.sp_masks[:len(lab)]        # replaced by get_targets in loss()
-            ds.gt_instances_3d.bboxes_3d = DepthInstance3DBoxes(torch.from_numpy(b), with_yaw=b.shape[1] == 7, box_dim=b.shape[1],
-                                                                origin=(0.5, 0.5, 0.5)).to(DEV)
-    return scenes, names, gt_boxes, inputs, samples
+def _joint_batch(cfg, specs=None):
+    """Synthetic mixed batch following each dataset's annotation style (unidet3d_amd.data.make_joint_batch)."""
+    from unidet3d_amd.data import make_joint_batch
+    return make_joint_batch(cfg, specs or JOINT_SCENES, DEV)
 
 
 def test_cfg4_joint_config_mixed_batch_vs_oracle():
@@ -228,6 +203,75 @@ def test_cfg4_joint_config_mixed_batch_vs_oracle():
         assert PA.rel(ds.gt_instances_3d.sp_centers, O['centers'][i]) < 1e-5
         assert PA.rel(ds.gt_instances_3d.bboxes_3d.gravity_center, O['insts'][i].bboxes_3d.gravity_center) < 1e-5
     PA.compare('cfg4_joint_mixed_batch', P, O, prod, orac, g64, None, g64m)
+
+
+def test_cfg4_stated_point_counts_properties():
+    """BASELINE.md's cfg4 workload at its STATED sizes (bench.py --config cfg4: 8 mixed scenes of 100 k / 180 k /
+    200 k points, ~1 M points per GPU) -- too large for the CPU oracle's full forward/backward in test time, so size-independent
+    properties: voxel coordinates and the level-1 / level-2 rulebooks bit-exact against the oracle's builders, ONE fused criterion
+    call, finite loss and gradients for every parameter that the oracle-sized cfg4 run also trains, 7-dof boxes for ARKitScenes
+    only, and the step repeats bit-identically."""
+    import collections
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from unidet3d_amd import _lib as L
+    from unidet3d_amd import sparse
+    from unidet3d_amd.config import build_model, joint_model_cfg
+    from unidet3d_amd.data import make_joint_batch
+    from _detw import fill_state_dict
+    cfg = joint_model_cfg()
+    specs = [(n, p, p / 100_000) for n, p in bench.CFG4_SCENES]
+    assert sorted({p for _, p in bench.CFG4_SCENES}) == [100_000, 180_000, 200_000]
+    prod = fill_state_dict(build_model(cfg), tag0=5000, scale=0.06).to(DEV).train()
+    scenes, names, gt_boxes, inputs, samples = make_joint_batch(cfg, specs, DEV)
+    calls, orig_call = collections.Counter(), L.call
+    L.call = lambda name, *a: (calls.update([name]), orig_call(name, *a))[1]
+    try:
+        P = PA.product_forward(prod, inputs, samples)
+    finally:
+        L.call = orig_call
+    assert calls['u3d_criterion_packed'] == 1, calls
+    loss = P['loss']
+    assert torch.isfinite(loss)
+    loss.backward()
+    n_grad = 0
+    for k, p in prod.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+            n_grad += 1
+    assert n_grad >= 200
+    for i, name in enumerate(names):
+        assert P['out']['bboxes'][i].shape[1] == (7 if name == 'arkitscenes' else 6), name
+    # integer work against the oracle's builders at this size
+    pts_cpu = [torch.from_numpy(s.points) for s in scenes]
+    oc, _, oinv, oshape = so.voxelize(pts_cpu, cfg['voxel_size'], cfg['min_spatial_shape'])
+    vb = prod._vb
+    assert torch.equal(vb.coords.cpu(), oc) and torch.equal(vb.inverse.cpu(), oinv)
+    coords, shape, index = vb.coords, vb.spatial_shape, vb.index
+    n_pairs = []
+    for level in range(2):
+        got = sparse.build_subm_rulebook(coords, index).lists()
+        want = so.build_subm_rulebook(oc, oshape)
+        for k, ((gi, go), (oi, oo)) in enumerate(zip(got, want)):
+            assert np.array_equal(gi, oi) and np.array_equal(go, oo), f'level {level} offset {k}'
+        n_pairs.append(sum(len(a) for a, _ in want))
+        oc2, oshape2, opairs = so.build_down_rulebook(oc, oshape)
+        c2, shape2, ix2, rb2 = sparse.build_down_rulebook(coords, len(scenes), shape)
+        assert torch.equal(c2.cpu(), oc2)
+        for k, ((gi, go), (oi, oo)) in enumerate(zip(rb2.lists(), opairs)):
+            assert np.array_equal(gi, oi) and np.array_equal(go, oo), f'level {level} down offset {k}'
+        coords, shape, index, oc, oshape = c2, shape2, ix2, oc2, oshape2
+    # the same step again on fresh weights: every kernel on this path is deterministic (fixed-order reductions, no float atomics)
+    prod2 = fill_state_dict(build_model(cfg), tag0=5000, scale=0.06).to(DEV).train()
+    loss2 = prod2.loss(inputs, samples)['det_loss']
+    loss2.backward()
+    assert torch.equal(loss2.detach(), loss.detach())
+    g1 = dict(prod.named_parameters())
+    worst = max(float((p.grad - g1[k].grad).abs().max()) for k, p in prod2.named_parameters() if p.grad is not None)
+    PA.log_errors('cfg4_stated_point_counts', dict(points=int(sum(len(s.points) for s in scenes)), n_voxels_l1=int(vb.coords.shape[0]),
+                                                   subm_pairs=n_pairs, loss=float(loss), repeat_max_abs_diff=worst, criterion_calls=1))
+    assert worst == 0.0, worst
 
 
 @pytest.mark.parametrize('name', ['s3dis', 'arkitscenes', '3rscan'])

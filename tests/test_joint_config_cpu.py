@@ -14,6 +14,15 @@ CFG = '/root/reference/configs/unidet3d_1xb8_scannet_s3dis_multiscan_3rscan_scan
 pytestmark = pytest.mark.skipif(not os.path.exists(CFG), reason='reference configs are only available in the build container')
 
 
+def test_packaged_joint_config_is_the_reference_fixture():
+    """unidet3d_amd.config.joint_model_cfg() (what bench.py --config cfg4 builds) is the dict tools/gen_golden_reference.py wrote
+    from the reference's joint config."""
+    import json
+    from unidet3d_amd.config import joint_model_cfg
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_joint_model_cfg.json')))
+    assert joint_model_cfg() == ref
+
+
 def test_joint_config_builds_and_flags_arrive():
     cfg = load_model_cfg(CFG)
     m = build_model(cfg)

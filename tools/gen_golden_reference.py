@@ -366,6 +366,8 @@ def gen_joint_cfg():
     path = os.path.join(RS.REF_ROOT, 'configs', 'unidet3d_1xb8_scannet_s3dis_multiscan_3rscan_scannetpp_arkitscenes.py')
     exec(compile(open(path).read(), path, 'exec'), ns)
     json.dump(ns['model'], open(os.path.join(GOLD, 'ref_joint_model_cfg.json'), 'w'), indent=0, sort_keys=True)
+    # the package's own copy (unidet3d_amd.config.joint_model_cfg: bench.py --config cfg4 runs without tests/)
+    json.dump(ns['model'], open(os.path.join(HERE, '..', 'unidet3d_amd', 'configs', 'joint_model_cfg.json'), 'w'), indent=0, sort_keys=True)
     print('joint model cfg: datasets', ns['model']['decoder']['datasets'])
 
 

@@ -36,6 +36,16 @@ def scannet_model_cfg(num_channels: int = 32, voxel_size: float = 0.02) -> dict:
         test_cfg=dict(low_sp_thr=0.18, up_sp_thr=0.81, topk_insts=1000, score_thr=0, iou_thr=[0.5]))
 
 
+def joint_model_cfg() -> dict:
+    """The ``model=dict(...)`` of configs/unidet3d_1xb8_scannet_s3dis_multiscan_3rscan_scannetpp_arkitscenes.py (six datasets, one
+    7-dof head): its values as data (configs/joint_model_cfg.json, written from the reference config by
+    tools/gen_golden_reference.py; tests/test_joint_config_cpu.py pins it against tests/golden/ref_joint_model_cfg.json)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs', 'joint_model_cfg.json')) as f:
+        return json.load(f)
+
+
 def build_model(cfg: dict):
     from .registry import MODELS
     return MODELS.build(dict(cfg))

@@ -38,3 +38,53 @@ def make_batch_inputs(scenes: List[Scene], device):
         ds.n_superpoints = int(sc.superpoints.max()) + 1
         samples.append(ds)
     return dict(points=pts), samples
+
+
+def scene_boxes(sc: Scene):
+    """Axis-aligned GT boxes (centre, size) [n_inst, 6] of a synthetic scene in its ORIGINAL frame (what a dataset with box
+    annotations stores); instances without points are dropped together with their labels (second return: the kept indices)."""
+    xyz = sc.points[:, :3]
+    boxes, keep = [], []
+    for j in range(len(sc.labels)):
+        m = sc.instance_mask == j
+        if m.any():
+            lo, hi = xyz[m].min(0), xyz[m].max(0)
+            boxes.append(np.concatenate(((lo + hi) / 2, hi - lo)))
+            keep.append(j)
+    return np.stack(boxes).astype(np.float32), np.asarray(keep)
+
+
+def make_joint_batch(cfg: dict, scene_specs, device, seed0: int = 200, yaw_seed: int = 4):
+    """Synthetic MIXED batch for the joint six-dataset config (BASELINE.json configs[3]), one scene per ``(dataset name, n_points)``
+    or ``(dataset name, n_points, area_scale)`` entry of ``scene_specs``, following each dataset's annotation style
+    (configs/unidet3d_1xb8_scannet_s3dis_multiscan_3rscan_scannetpp_arkitscenes.py:36-43): ScanNet / S3DIS carry instance masks
+    (bbox_by_mask), the others boxes -- ARKitScenes with a heading -- and get their masks by distance in ``loss``.
+    -> (scenes, dataset names, gt_boxes per scene (None or (boxes, labels)), batch_inputs_dict, batch_data_samples)."""
+    from .structures import DepthInstance3DBoxes
+    from .synthetic import make_scene
+    dec = cfg['decoder']
+    scenes, names, gt_boxes = [], [], []
+    rng = np.random.default_rng(yaw_seed)
+    for i, spec in enumerate(scene_specs):
+        name, n_pts = spec[0], spec[1]
+        d = dec['datasets'].index(name)
+        sc = make_scene(seed0 + i, n_points=n_pts, n_classes=len(dec['datasets_classes'][d]), dataset=name,
+                        **(dict(area_scale=float(spec[2])) if len(spec) > 2 else {}))
+        scenes.append(sc)
+        names.append(name)
+        if cfg['bbox_by_mask'][d]:
+            gt_boxes.append(None)
+        else:
+            b, keep = scene_boxes(sc)
+            if dec['angles'][d]:
+                b = np.concatenate((b, rng.uniform(-0.6, 0.6, (len(b), 1)).astype(np.float32)), 1)
+            gt_boxes.append((b, sc.labels[keep]))
+    inputs, samples = make_batch_inputs(scenes, device)
+    for ds, gb in zip(samples, gt_boxes):
+        if gb is not None:
+            b, lab = gb
+            ds.gt_instances_3d.labels_3d = torch.from_numpy(lab).to(device)
+            ds.gt_instances_3d.sp_masks = ds.gt_instances_3d.sp_masks[:len(lab)]        # replaced by get_targets in loss()
+            ds.gt_instances_3d.bboxes_3d = DepthInstance3DBoxes(torch.from_numpy(b), with_yaw=b.shape[1] == 7, box_dim=b.shape[1],
+                                                                origin=(0.5, 0.5, 0.5)).to(device)
+    return scenes, names, gt_boxes, inputs, samples

@@ -142,13 +142,14 @@ def test_subm_conv_fwd_bwd(cin, cout, math_mode):
 
 
 @pytest.mark.parametrize('operands', ['bf16x3', 'bf16'])
-@pytest.mark.parametrize('tile_rows', [0, 64])
+@pytest.mark.parametrize('tile_rows', [32, 64])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (64, 64), (96, 96), (128, 160), (256, 256)])
 def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_rows, operands):
     """The workgroup-tile kernel (weights of an offset through LDS, an offset's pairs dealt evenly to four waves) performs the
     same MFMAs on the same operands in the same order per dst row as the wave-tile kernel: forward (+ residual addend) and
     input gradient must be IDENTICAL, for SubM (27 offsets) and strided / inverse (8 offsets) rulebooks, at both tile heights
-    and with offset groups (the small levels)."""
+    (U3D_GMM_R / U3D_GMM_G pin the plan: this small geometry would otherwise split the offsets over groups, which the
+    workgroup-tile kernel is not used for)."""
     import os
     from unidet3d_amd import precision as P
     from unidet3d_amd import sparse
@@ -164,9 +165,8 @@ def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_r
     wi = (torch.randn(cin, 2, 2, 2, cout, generator=g) * 0.1).to(_dev())
     add = torch.randn(n, cout, generator=g).to(_dev())
     go, go2 = torch.randn(n, cout, generator=g).to(_dev()), torch.randn(n2, cout, generator=g).to(_dev())
-    prev = os.environ.get('U3D_GMM_R')
-    if tile_rows:
-        os.environ['U3D_GMM_R'] = str(tile_rows)
+    prev, prev_g = os.environ.get('U3D_GMM_R'), os.environ.get('U3D_GMM_G')
+    os.environ['U3D_GMM_R'], os.environ['U3D_GMM_G'] = str(tile_rows), '1'
     out = {}
     try:
         for kind in ('wave', 'workgroup'):
@@ -179,8 +179,8 @@ def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_r
                 yu = sparse.sparse_conv(xu, wi, rb2, 'inv'); yu.backward(x)
                 out[kind] = [y.detach(), xg.grad, yd.detach(), xd.grad, yu.detach(), xu.grad]
     finally:
-        if tile_rows:
-            os.environ.pop('U3D_GMM_R') if prev is None else os.environ.__setitem__('U3D_GMM_R', prev)
+        os.environ.pop('U3D_GMM_R') if prev is None else os.environ.__setitem__('U3D_GMM_R', prev)
+        os.environ.pop('U3D_GMM_G') if prev_g is None else os.environ.__setitem__('U3D_GMM_G', prev_g)
     # one difference in summation ORDER: at 32-row tiles the wave-tile kernel takes 64 source channels per unit where the count
     # allows (low-order plane products of 64 channels summed before they join the running row), the workgroup-tile kernel always
     # 32 -- there the comparison is to fp32 rounding instead of bit-for-bit

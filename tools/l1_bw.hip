@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ buf, float* 
         for (int u = 0; u < 8; ++u) {
             long idx;
             if (mode == 0) idx = (base + u * 64 + lane) % span16;
-            else idx = (base + (long)(lane & 15) * 8 * 37 + (u & 1) * 4 + (lane >> 4) + (u >> 1) * 8 * 1021) % span16;   // 128-B rows, scattered
+            else if (mode == 1) idx = (base + (long)(lane & 15) * 8 * 37 + (u & 1) * 4 + (lane >> 4) + (u >> 1) * 8 * 1021) % span16;   // 128-B rows, scattered
+            else idx = (base + (long)((lane >> 3) + (u & 1) * 8) * 8 * 37 + (lane & 7) + (u >> 1) * 8 * 1021) % span16;   // mode 2: 8 COMPLETE 128-B rows per instruction
             v[u] = buf[idx];
         }
 #pragma unroll
@@ -40,6 +41,9 @@ int main() {
         {"gather 16 rows x 64 B, 16 KB footprint", 16l << 10, 1, 0},
         {"gather 16 rows x 64 B, 16 MB footprint", 16l << 20, 1, 4099},
         {"gather 16 rows x 64 B, 200 MB footprint", 200l << 20, 1, 65537},
+        {"gather 8 rows x 128 B, 16 KB footprint", 16l << 10, 2, 0},
+        {"gather 8 rows x 128 B, 16 MB footprint", 16l << 20, 2, 4099},
+        {"gather 8 rows x 128 B, 200 MB footprint", 200l << 20, 2, 65537},
     };
     for (auto& c : cases)
         for (int wgs : {1024, 4096}) {

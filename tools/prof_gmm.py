@@ -40,10 +40,11 @@ def timed(f):
 
 KINDS = os.environ.get('PROF_KINDS', 'wave,workgroup').split(',')
 MAXLV = int(os.environ.get('PROF_MAXLV', '5'))
+MINLV = int(os.environ.get('PROF_MINLV', '1'))
 total = {k: 0.0 for k in KINDS}
 ctx = P.operands('bf16') if operands == 'bf16' else P.fp32_math('bf16x3')
 with ctx:
-    for lv, c, rb in levels[:MAXLV]:
+    for lv, c, rb in levels[MINLV - 1:MAXLV]:
         n = c.shape[0]
         C = 32 * lv
         for cs, cd in ((C, C), (2 * C, C)) if lv < 5 else ((C, C),):

@@ -499,15 +499,21 @@ __global__ __launch_bounds__(256) void gmm_reduce_k(const float* __restrict__ pa
     }
 }
 
-// rows per wave-tile and offset groups: aim at >= 2 waves per SIMD on 256 CUs x 4 SIMDs
+// rows per wave-tile and offset groups.  Measured on MI355X at the cfg2 level sizes (tools/prof_gmm.py sweep, round 4,
+// profiles/round4_gmm_plan_sweep.txt): 64-row tiles win at every level once a level that cannot fill the chip with them
+// (fewer than 2048 wave tiles) splits its 27 offsets over NINE groups instead of going to 32-row tiles and three groups
+// (level 3, 192 -> 96 channels: 126 us against 161; level 4, 256 -> 128: 69 against 80); strided / inverse convolutions
+// (8 offsets, no groups) keep 32-row tiles there for the parallelism.
 static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
     const int slices = Cd / GMM_CDS;
     const int64_t want = 2048;
     int r = 64, g = 1;
-    if (ceil_div(n_dst, 64) * slices < want) r = 32;
-    const int64_t waves = ceil_div(n_dst, r) * slices;
-    if (waves < want && K >= 27) g = waves * 3 >= want ? 3 : 9;
-    if (const char* e = getenv("U3D_GMM_R")) r = atoi(e) == 32 ? 32 : 64;      // experiment knob (tools/prof_conv.py)
+    if (ceil_div(n_dst, 64) * slices < want) {
+        if (K >= 27) g = 9;
+        else r = 32;
+    }
+    if (const char* e = getenv("U3D_GMM_R")) r = atoi(e) == 32 ? 32 : 64;      // experiment knobs (tools/prof_gmm.py)
+    if (const char* e = getenv("U3D_GMM_G")) { const int v = atoi(e); if ((v == 1 || v == 3 || v == 9) && K >= 27) g = v; }
     *R = r;
     *G = g;
 }
@@ -1044,8 +1050,10 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
 #define U3D_GMM_CASE_X3(cs) if (cs16 == cs) rc = (R == 64) ? launch_gmm<cs, 64, 2>(p, s) : launch_gmm<cs, 32, 2>(p, s);
     // bf16 / three-plane operands: the workgroup-tile kernel (spconv_wg.hip, weights of an offset shared through LDS) unless the
     // launch asks for per-tile statistics (wave-tile epilogue only) or u3d_conv_kernel(0) / U3D_GMM_WG=0 selected the wave-tile kernel
+    // (offset groups -- the small levels -- stay on the wave-tile kernel: there the workgroup form measured level or behind)
     const bool use_wg = u3d_conv_kernel(-1) == 1;
-    if (pr && use_wg && !bn_partial && gmm_wg_supported(cs16, R, pr)) {
+    // bf16 operands from fp32 rows (pr = 1): the wave-tile kernel measured ahead (level 1, 32 -> 32: 78 us against 88)
+    if (pr == 2 && use_wg && !bn_partial && G == 1 && gmm_wg_supported(cs16, R, pr)) {
         rc = launch_gmm_wg(p, cs16, R, pr, s);
     } else if (pr == 1) {
         U3D_GMM_CASE_BF(2) U3D_GMM_CASE_BF(4) U3D_GMM_CASE_BF(6) U3D_GMM_CASE_BF(8) U3D_GMM_CASE_BF(10) U3D_GMM_CASE_BF(12) U3D_GMM_CASE_BF(16)

@@ -48,7 +48,8 @@ int u3d_fp32_math(int mode);
 
 /* Which output-stationary sparse-convolution kernel serves u3d_spconv_gmm_bf16 / _x3:
  *   1 (default; env U3D_GMM_WG unset or != 0): workgroup tiles -- four waves share 4 x tile_rows dst rows, the packed weights of
- *     an offset are staged once per workgroup in LDS and the offset's pairs are dealt evenly to the waves (csrc/spconv_wg.hip);
+ *     an offset are staged once per workgroup in LDS and the offset's pairs are dealt evenly to the waves (csrc/spconv_wg.hip) --
+ *     where they measured ahead: the three-plane entry point at k_groups = 1; 2: wherever that kernel is instantiated (tests, A/B);
  *   0: wave-private tiles, every item reads its weight fragments through the vector-memory path (csrc/spconv.hip; also what
  *     u3d_spconv_gmm -- native fp32 MFMAs -- and launches with bn_partial always use).
  * Same arguments, same tile_starts, bit-identical pair arithmetic; results differ only in fp32 summation order across offsets

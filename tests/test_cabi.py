@@ -50,6 +50,7 @@ def test_conv_kernel_switch_is_host_state():
         assert prev in (0, 1)
         assert l.u3d_conv_kernel(0) == prev and l.u3d_conv_kernel(-1) == 0 and l.u3d_conv_kernel(5) == 0
         assert l.u3d_conv_kernel(1) == 0 and l.u3d_conv_kernel(-1) == 1
+        assert l.u3d_conv_kernel(2) == 1 and l.u3d_conv_kernel(-1) == 2
     finally:
         l.u3d_conv_kernel(prev)
 
@@ -71,7 +72,9 @@ def test_pure_size_queries_run_without_gpu():
     assert l.u3d_index_words(2, 128, 130, 65) == 2 * 128 * 130 * 2
     R, G = ctypes.c_int(0), ctypes.c_int(0)
     assert l.u3d_spconv_plan(32, 32, 27, 400000, ctypes.byref(R), ctypes.byref(G)) == 0 and (R.value, G.value) == (64, 1)
-    assert l.u3d_spconv_plan(160, 160, 27, 1400, ctypes.byref(R), ctypes.byref(G)) == 0 and R.value == 32 and G.value > 1
+    # a level that cannot fill the chip: 27 offsets -> 64-row tiles, nine offset groups; 8 offsets (strided / inverse) -> 32-row tiles
+    assert l.u3d_spconv_plan(160, 160, 27, 1400, ctypes.byref(R), ctypes.byref(G)) == 0 and (R.value, G.value) == (64, 9)
+    assert l.u3d_spconv_plan(128, 160, 8, 1400, ctypes.byref(R), ctypes.byref(G)) == 0 and (R.value, G.value) == (32, 1)
     assert l.u3d_spconv_plan(24, 32, 27, 1000, ctypes.byref(R), ctypes.byref(G)) < 0     # unsupported channel count is refused
     assert l.u3d_subm_rulebook_ws_bytes(1000) >= 2 * 27 * 4 * 4      # block counts + bases of 4 blocks (no dense neighbour matrix since round 3)
     assert l.u3d_down_rulebook_ws_bytes(1000) >= 8 * 1000 * 4

@@ -169,7 +169,7 @@ def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_r
     os.environ['U3D_GMM_R'], os.environ['U3D_GMM_G'] = str(tile_rows), '1'
     out = {}
     try:
-        for kind in ('wave', 'workgroup'):
+        for kind in ('wave', 'workgroup-all'):
             with P.conv_kernel(kind), (P.operands('bf16') if operands == 'bf16' else P.fp32_math('bf16x3')):
                 xg = x.clone().requires_grad_()
                 y = sparse.sparse_conv(xg, w3, rb, 'fwd', add); y.backward(go)
@@ -185,7 +185,7 @@ def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_r
     # allows (low-order plane products of 64 channels summed before they join the running row), the workgroup-tile kernel always
     # 32 -- there the comparison is to fp32 rounding instead of bit-for-bit
     exact = operands == 'bf16' or tile_rows == 64
-    for i, (name, a, b) in enumerate(zip(('subm fwd', 'subm dgrad', 'down fwd', 'down dgrad', 'inverse fwd', 'inverse dgrad'), out['wave'], out['workgroup'])):
+    for i, (name, a, b) in enumerate(zip(('subm fwd', 'subm dgrad', 'down fwd', 'down dgrad', 'inverse fwd', 'inverse dgrad'), out['wave'], out['workgroup-all'])):
         assert torch.isfinite(b).all(), name
         cs = cin if i in (0, 2, 5) else cout          # source channels of that launch
         if exact or cs % 64:

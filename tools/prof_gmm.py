@@ -55,7 +55,7 @@ with ctx:
             row = f'level {lv} n={n:7d} {cs:3d}->{cd:3d} pairs/voxel {pairs / n:5.2f} {gf:6.2f} GF:'
             ys = {}
             for kind in KINDS:
-                with P.conv_kernel(kind):
+                with P.conv_kernel('workgroup-all' if kind == 'workgroup' else kind):
                     us = timed(lambda: sparse.sparse_conv(x, w, rb))
                     ys[kind] = sparse.sparse_conv(x, w, rb)
                 total[kind] += us

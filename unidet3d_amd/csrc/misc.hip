@@ -176,7 +176,7 @@ int u3d_conv_kernel(int mode) {
         u3d::g_conv_kernel = (e && atoi(e) == 0) ? 0 : 1;
     }
     const int prev = u3d::g_conv_kernel;
-    if (mode == 0 || mode == 1) u3d::g_conv_kernel = mode;
+    if (mode == 0 || mode == 1 || mode == 2) u3d::g_conv_kernel = mode;
     return prev;
 }
 int u3d_fp32_math(int mode) {

@@ -1051,9 +1051,10 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
     // bf16 / three-plane operands: the workgroup-tile kernel (spconv_wg.hip, weights of an offset shared through LDS) unless the
     // launch asks for per-tile statistics (wave-tile epilogue only) or u3d_conv_kernel(0) / U3D_GMM_WG=0 selected the wave-tile kernel
     // (offset groups -- the small levels -- stay on the wave-tile kernel: there the workgroup form measured level or behind)
-    const bool use_wg = u3d_conv_kernel(-1) == 1;
-    // bf16 operands from fp32 rows (pr = 1): the wave-tile kernel measured ahead (level 1, 32 -> 32: 78 us against 88)
-    if (pr == 2 && use_wg && !bn_partial && G == 1 && gmm_wg_supported(cs16, R, pr)) {
+    // bf16 operands from fp32 rows (pr = 1): the wave-tile kernel measured ahead (level 1, 32 -> 32: 78 us against 88);
+    // u3d_conv_kernel(2) takes the workgroup form wherever it is instantiated (tests, A/B runs)
+    const int ck = u3d_conv_kernel(-1);
+    if (pr && (ck == 2 || (ck == 1 && pr == 2 && G == 1)) && !bn_partial && gmm_wg_supported(cs16, R, pr)) {
         rc = launch_gmm_wg(p, cs16, R, pr, s);
     } else if (pr == 1) {
         U3D_GMM_CASE_BF(2) U3D_GMM_CASE_BF(4) U3D_GMM_CASE_BF(6) U3D_GMM_CASE_BF(8) U3D_GMM_CASE_BF(10) U3D_GMM_CASE_BF(12) U3D_GMM_CASE_BF(16)

@@ -76,17 +76,18 @@ def fp32_math(mode: str):
         set_fp32_math(prev)
 
 
-_CONV_KERNEL = {'wave': 0, 'workgroup': 1}
+_CONV_KERNEL = {'wave': 0, 'workgroup': 1, 'workgroup-all': 2}
 
 
 def set_conv_kernel(kind: str) -> str:
-    """'workgroup' (default: four waves share a row tile and the LDS copy of an offset's weights, csrc/spconv_wg.hip) | 'wave'
+    """'workgroup' (default: four waves share a row tile and the LDS copy of an offset's weights, csrc/spconv_wg.hip, where that
+    measured ahead: three-plane products, single offset group) | 'workgroup-all' (wherever the kernel is instantiated) | 'wave'
     (wave-private tiles, csrc/spconv.hip) for the bf16 / three-plane sparse convolutions (include/u3d.h: u3d_conv_kernel;
     env U3D_GMM_WG).  Returns the previous kind.  Process-wide; A/B measurements and tests."""
     from . import _lib as L
     if kind not in _CONV_KERNEL:
-        raise ValueError("conv kernel must be 'workgroup' or 'wave'")
-    return 'workgroup' if L.lib().u3d_conv_kernel(_CONV_KERNEL[kind]) == 1 else 'wave'
+        raise ValueError("conv kernel must be 'workgroup', 'workgroup-all' or 'wave'")
+    return {0: 'wave', 1: 'workgroup', 2: 'workgroup-all'}[L.lib().u3d_conv_kernel(_CONV_KERNEL[kind])]
 
 
 @contextlib.contextmanager

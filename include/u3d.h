@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 104
+#define U3D_ABI_VERSION 105
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -175,6 +175,15 @@ int u3d_spconv_gmm_bf16(const float* src, int64_t n_src, const void* w_rows_bf16
                         const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
                         int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream);
 int u3d_weight_pack_bf16(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream);
+/* bf16 SOURCE ROWS (BASELINE configs[2] with bf16 copies of the gathered activations in HBM): src_bf16 is the shadow a
+ * batch-norm call wrote next to its fp32 output (u3d_bn_apply / u3d_bn_bwd_apply, y_bf16 / dx_bf16): [n_src][Cs] bf16, rounded to
+ * nearest even, each 32-channel group in MFMA fragment order (16 bytes at byte 16 q = channels 4q..4q+3, 16+4q..16+4q+3).  A lane
+ * loads its fragment straight from the row: half the gathered bytes, no LDS transposition, no rounding arithmetic.  Weights from
+ * u3d_weight_pack_bf16 (the same pack as u3d_spconv_gmm_bf16); dst / addend fp32, fp32 accumulation; results are bit-identical to
+ * u3d_spconv_gmm_bf16 on the fp32 tensor the shadow was rounded from.  Always the workgroup-tile kernel (csrc/spconv_wg.hip). */
+int u3d_spconv_gmm_bf16a(const void* src_bf16, int64_t n_src, const void* w_rows_bf16, const int32_t* gather, const int32_t* scatter,
+                         const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                         int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream);
 /* fp32 products on the bf16 matrix pipe (see u3d_fp32_math): same arguments and results at fp32-level error; the gathered rows are
  * split exactly into three bf16 planes as the MFMA operand is formed, the weights come pre-split from u3d_weight_pack_x3
  * (Cd*K*Cs*6 bytes: three consecutive 1 KB plane blocks per (32-channel group, 16-column block) of the bf16 form's order), a
@@ -234,7 +243,9 @@ int64_t u3d_bn_ws_bytes(int C);
 int u3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, int C, float* mean, float* invstd,
                     float* scale, float* shift, int64_t* num_batches_tracked, u3d_stream_t stream);
-int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y,
+/* y_bf16 (nullable, [n][C] bf16, C % 32 == 0): a copy of y rounded to nearest even, fragment order inside each 32-channel group
+ * (see u3d_spconv_gmm_bf16a), written in the same pass -- the source rows of u3d_spconv_gmm_bf16a. */
+int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y, void* y_bf16,
                  u3d_stream_t stream);
 /* backward of y = relu(x*scale+shift): sums[0..C) = sum dy', sums[C..2C) = sum dy'*xhat  (dy' = dy*[y>0]);
  * sums[2C] is left untouched (the caller keeps the forward row count there). */
@@ -244,19 +255,20 @@ int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const f
  * count <= 0: read from sums[2C]. */
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd,
                      const float* scale, const float* shift, int relu, const double* sums, double count,
-                     int64_t n, int C, float* dx, float* dgamma, float* dbeta, const float* addend /* nullable [n][C]: added to dx (a second gradient of x, e.g. the residual identity branch) */,
+                     int64_t n, int C, float* dx, void* dx_bf16 /* nullable [n][C] bf16: dx rounded to nearest even (as y_bf16 of u3d_bn_apply) */,
+                     float* dgamma, float* dbeta, const float* addend /* nullable [n][C]: added to dx (a second gradient of x, e.g. the residual identity branch) */,
                      u3d_stream_t stream);
 
 /* Single-call forms for the non-distributed case: forward = statistics -> sum + finalize -> apply; backward = bwd_stats -> sum ->
  * bwd_apply.  st float [4C] = mean, invstd, scale, shift (saved for backward); sums double [2C+1]; partial / n_tiles as in
  * u3d_bn_stats. */
 int u3d_bn_forward(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const float* gamma, const float* beta, float eps,
-                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st,
-                   double* sums, void* ws, u3d_stream_t stream);
+                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, void* y_bf16 /* nullable */,
+                   float* st, double* sums, void* ws, u3d_stream_t stream);
 /* fwd_sums: the forward call's sums vector (its entry [2C] is the row count the backward divides by) */
 int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n,
-                    int C, float* dx, float* dgamma, float* dbeta, const float* addend /* nullable, as in u3d_bn_bwd_apply */, void* ws,
-                    u3d_stream_t stream);
+                    int C, float* dx, void* dx_bf16 /* nullable */, float* dgamma, float* dbeta, const float* addend /* nullable, as in u3d_bn_bwd_apply */,
+                    void* ws, u3d_stream_t stream);
 
 /* =====================================================================================
  * K11/K12  superpoint pooling -- replaces x.features[inverse_mapping] + torch_scatter.scatter_mean

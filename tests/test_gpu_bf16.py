@@ -169,6 +169,123 @@ def test_strided_and_inverse_conv_bf16():
     assert _rel(outs['bf16'][1], outs['fp32'][1]) < 3e-3      # y itself differs in the last bits before it is rounded again
 
 
+# ---------------------------------------------------------------------------- bf16 rows in HBM (round 4: VERDICT r3 item 3)
+@pytest.mark.parametrize('tile_rows,groups', [(64, 1), (32, 1), (64, 9)])
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (64, 64), (96, 96), (128, 160), (256, 256)])
+def test_conv_on_bf16_rows_equals_conv_rounding_fp32_rows_bit_for_bit(cin, cout, tile_rows, groups):
+    """u3d_spconv_gmm_bf16a gathers bf16 rows (the shadow a batch norm wrote: the fp32 tensor rounded to nearest even) as MFMA
+    fragments; u3d_spconv_gmm_bf16 gathers the fp32 rows and rounds them as it forms the operand.  Same operands, same MFMAs in
+    the same order per dst row: forward (+ addend), input gradient, strided and inverse rulebooks, with and without offset
+    groups -- identical bits."""
+    import os
+    from unidet3d_amd import ops, sparse, precision as P
+    from unidet3d_amd.synthetic import make_scene
+    scenes = [make_scene(21 + i, n_points=12_000) for i in range(2)]
+    vb = ops.voxelize([torch.from_numpy(s.points).to(DEV) for s in scenes], 0.05, 128)
+    n = vb.coords.shape[0]
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    c2, shape2, ix2, rb2 = sparse.build_down_rulebook(vb.coords, 2, vb.spatial_shape)
+    n2 = c2.shape[0]
+    g = torch.Generator().manual_seed(cin * 31 + cout)
+    x = torch.randn(n, cin, generator=g).to(DEV)
+    w3 = (torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1).to(DEV)
+    w2 = (torch.randn(cout, 2, 2, 2, cin, generator=g) * 0.1).to(DEV)
+    wi = (torch.randn(cin, 2, 2, 2, cout, generator=g) * 0.1).to(DEV)
+    add = torch.randn(n, cout, generator=g).to(DEV)
+    go, go2 = torch.randn(n, cout, generator=g).to(DEV), torch.randn(n2, cout, generator=g).to(DEV)
+    env = {k: os.environ.get(k) for k in ('U3D_GMM_R', 'U3D_GMM_G')}
+    os.environ['U3D_GMM_R'], os.environ['U3D_GMM_G'] = str(tile_rows), str(groups)
+    out = {}
+    try:
+        for rows in (False, True):
+            with P.operands('bf16'), P.bf16_rows_mode(rows):
+                sparse.SHADOW_STATS.update(hit=0, miss=0)
+
+                def shadowed(t):            # what a batch-norm kernel does: the bf16 copy next to the fp32 tensor
+                    t = t.clone()
+                    if rows:
+                        sparse.attach_shadow(t, sparse.to_shadow(t))
+                    return t
+                xg = shadowed(x).requires_grad_()
+                y = sparse.sparse_conv(xg, w3, rb, 'fwd', add); y.backward(shadowed(go))
+                xd = shadowed(x).requires_grad_()
+                yd = sparse.sparse_conv(xd, w2, rb2, 'fwd'); yd.backward(shadowed(go2))
+                xu = shadowed(go2).requires_grad_()
+                yu = sparse.sparse_conv(xu, wi, rb2, 'inv'); yu.backward(shadowed(x))
+                out[rows] = [y.detach(), xg.grad, yd.detach(), xd.grad, yu.detach(), xu.grad]
+                if rows:
+                    assert sparse.SHADOW_STATS['hit'] == 6 and sparse.SHADOW_STATS['miss'] == 0, sparse.SHADOW_STATS
+    finally:
+        for k, v in env.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for name, a, b in zip(('subm fwd', 'subm dgrad', 'down fwd', 'down dgrad', 'inverse fwd', 'inverse dgrad'), out[False], out[True]):
+        assert torch.isfinite(b).all(), name
+        assert torch.equal(a, b), f'{name}: max |diff| {float((a - b).abs().max())}'
+
+
+def test_batch_norm_writes_bf16_shadows_of_its_output_and_of_the_gradient_it_returns():
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    g = torch.Generator().manual_seed(3)
+    bn = sparse.SparseBatchNorm(64, sync=False).to(DEV).train()
+    x = (torch.randn(5000, 64, generator=g) * 3 + 1).to(DEV).requires_grad_()
+    x._u3d_from_conv = True
+    go = torch.randn(5000, 64, generator=g).to(DEV)
+    with P.operands('bf16'), P.bf16_rows_mode(True):
+        y = bn(x, relu=True)
+        ys = sparse.shadow_of(y)
+        assert ys is not None and ys.dtype == torch.bfloat16 and torch.equal(ys, sparse.to_shadow(y))
+        seen = {}
+        x.register_hook(lambda gr: seen.update(shadow=sparse.shadow_of(gr), grad=gr.detach().clone()))
+        y.backward(go)
+    assert seen['shadow'] is not None and torch.equal(seen['shadow'], sparse.to_shadow(seen['grad']))
+    with P.operands('bf16'), P.bf16_rows_mode(False):
+        bn2 = sparse.SparseBatchNorm(64, sync=False).to(DEV).train()
+        x2 = x.detach().clone().requires_grad_()
+        y2 = bn2(x2, relu=True)
+        assert sparse.shadow_of(y2) is None and torch.equal(y2, y)
+        y2.backward(go)
+    assert torch.equal(x2.grad, x.grad)
+    with P.operands('fp32'):
+        assert sparse.shadow_of(bn(x.detach(), relu=True)) is None             # fp32 operands: no shadows anywhere
+
+
+def test_training_step_with_bf16_rows_is_bit_identical_to_rounding_fp32_rows():
+    """The whole cfg3-style step (bf16 operands) with bf16 shadows of every batch-norm output / returned gradient gathered by the
+    sparse convolutions, against the same step gathering fp32 rows: loss and EVERY parameter gradient identical, and the shadows
+    are really used (forward + input-gradient launches of every 3x3x3 / strided / inverse convolution behind a batch norm)."""
+    import copy
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _detw import fill_state_dict
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    from unidet3d_amd.config import build_model, scannet_model_cfg
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = scannet_model_cfg(voxel_size=0.05)
+    cfg['decoder']['num_layers'] = 2
+    base = fill_state_dict(build_model(cfg), tag0=3300, scale=0.06)
+    inputs, samples = make_batch_inputs([make_scene(140 + i, n_points=10_000) for i in range(2)], DEV)
+    res = {}
+    for rows in (False, True):
+        model = copy.deepcopy(base).to(DEV).train()
+        sparse.SHADOW_STATS.update(hit=0, miss=0)
+        with P.operands('bf16'), P.bf16_rows_mode(rows):
+            loss = model.loss(inputs, copy.deepcopy(samples))['det_loss']
+            loss.backward()
+        res[rows] = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                     dict(sparse.SHADOW_STATS))
+    assert torch.equal(res[True][0], res[False][0])
+    for n, gr in res[False][1].items():
+        assert torch.equal(gr, res[True][1][n]), n
+    st = res[True][2]
+    print('shadow use:', st)
+    assert st['hit'] >= 80 and st['miss'] <= 4, st            # 45 convolutions: forward + input gradient; the 16-channel input conv has neither
+    assert res[False][2]['hit'] == 0
+
+
 # ---------------------------------------------------------------------------- the whole step in bf16-operand mode
 def test_training_step_bf16_operands_stays_close_to_fp32():
     """BASELINE configs[2] end to end on a small batch: the same model and scenes with fp32 and with bf16 MFMA operands.  The

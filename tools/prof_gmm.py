@@ -1,6 +1,6 @@
 """A/B of the two output-stationary sparse-convolution kernels (wave tiles / workgroup tiles) at cfg2 geometry
 (8 scenes x 100k pts, 2 cm): forward launches of every (level, Cs -> Cd) shape of the U-Net, HIP-event time per launch.
-usage: python tools/prof_gmm.py [iters] [operands: x3|bf16]"""
+usage: python tools/prof_gmm.py [iters] [operands: x3|bf16|bf16rows]"""
 import os
 import sys
 
@@ -42,13 +42,15 @@ KINDS = os.environ.get('PROF_KINDS', 'wave,workgroup').split(',')
 MAXLV = int(os.environ.get('PROF_MAXLV', '5'))
 MINLV = int(os.environ.get('PROF_MINLV', '1'))
 total = {k: 0.0 for k in KINDS}
-ctx = P.operands('bf16') if operands == 'bf16' else P.fp32_math('bf16x3')
+ctx = P.operands('bf16') if operands.startswith('bf16') else P.fp32_math('bf16x3')
 with ctx:
     for lv, c, rb in levels[MINLV - 1:MAXLV]:
         n = c.shape[0]
         C = 32 * lv
         for cs, cd in ((C, C), (2 * C, C)) if lv < 5 else ((C, C),):
             x = torch.randn(n, cs, device=dev)
+            if operands == 'bf16rows':          # the shadow a batch norm would have written: the conv gathers bf16 rows
+                sparse.attach_shadow(x, sparse.to_shadow(x))
             w = torch.randn(cd, 3, 3, 3, cs, device=dev) * 0.05
             pairs = rb.total_pairs
             gf = 2.0 * pairs * cs * cd / 1e9

@@ -46,6 +46,7 @@ PROTOTYPES = {
     'u3d_tile_starts': (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp]),
     'u3d_spconv_gmm': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
     'u3d_spconv_gmm_bf16': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
+    'u3d_spconv_gmm_bf16a': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _f64, _vp]),
     'u3d_weight_pack_batch': (_i32, [_vp, _i32, _i64, _vp]),
     'u3d_weight_pack_bf16': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_spconv_gmm_x3': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
@@ -66,12 +67,12 @@ PROTOTYPES = {
     'u3d_weight_transpose': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     'u3d_bn_stats': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'u3d_bn_ws_bytes': (_i64, [_i32]),
-    'u3d_bn_forward': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
-    'u3d_bn_backward': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_forward': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_backward': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_bn_finalize': (_i32, [_vp, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'u3d_bn_apply': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    'u3d_bn_apply': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'u3d_bn_bwd_stats': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
-    'u3d_bn_bwd_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_bn_bwd_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     'u3d_csr_build_ws_bytes': (_i64, [_i64, _i64]),
     'u3d_gather_i64_to_i32': (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -100,7 +101,7 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 104         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 105         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

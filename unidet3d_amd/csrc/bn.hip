@@ -204,8 +204,21 @@ __global__ void bn_finalize_k(const double* __restrict__ sums, double count, con
     }
 }
 
+// A bf16 SHADOW of an output ([n][C] bf16, rounded to nearest even, C % 32 == 0) can be written next to the fp32 tensor: the
+// sparse convolutions that gather these rows with bf16 MFMA operands (BASELINE configs[2]) round every row to exactly these values
+// each time they gather it -- from the shadow they read half the bytes, already in MFMA fragment shape (spconv_wg.hip PR = 3).
+// Inside each 32-channel group the shadow is in FRAGMENT ORDER: the 16 bytes at byte 16 q hold channels 4q .. 4q+3 and
+// 16 + 4q .. 16 + 4q + 3 -- the eight reduction elements lane group q of v_mfma_f32_16x16x32_bf16 takes in the fp32-row kernels
+// (spconv.hip: k = 8q + e <-> channel 16 (e >> 2) + 4q + (e & 3)), so both kinds of kernel multiply the same operands in the same
+// k slots, share the packed weights, and return identical bits.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+__device__ __forceinline__ void store_shadow(__bf16* dst, int64_t row, int c4, int C4, const float4& o) {
+    const int g32 = c4 >> 3, half = (c4 >> 2) & 1, q = c4 & 3;          // channels 4 c4 .. 4 c4 + 3 = group g32, 16-channel half, quad q
+    reinterpret_cast<bf16x4_t*>(dst)[row * C4 + g32 * 8 + q * 2 + half] = bf16x4_t{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+}
+
 __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, int relu, int64_t n4, int C4, float* y) {
+                                                  const float* __restrict__ shift, int relu, int64_t n4, int C4, float* y, __bf16* yb) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -214,6 +227,7 @@ __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, c
         float4 o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = o;
+        if (yb) store_shadow(yb, i / C4, c4, C4, o);
     }
 }
 
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                       const double* __restrict__ sums, double inv_count, int64_t n4, int C,
                                                       float* dx, float* dgamma, float* dbeta, const double* __restrict__ count_src,
-                                                      const float* __restrict__ addend) {
+                                                      const float* __restrict__ addend, __bf16* dxb) {
     const int C4 = C >> 2;
     if (!(inv_count > 0.0)) inv_count = 1.0 / (count_src ? count_src[0] : sums[2 * C]);
     if (blockIdx.x == 0 && dgamma) {
@@ -260,10 +274,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
             o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
         }
         reinterpret_cast<float4*>(dx)[i] = o;
+        if (dxb) store_shadow(dxb, i / C4, c4, C4, o);
     }
 }
 
 static bool bn_ok(int64_t n, int C) { return n > 0 && C >= 4 && C <= 256 && C % 4 == 0; }
+static bool shadow_ok(const void* sh, int C) { return !sh || C % 32 == 0; }
 static unsigned ew_grid(int64_t n4) {
     int64_t g = ceil_div(n4, 256);
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -330,13 +346,13 @@ int u3d_bn_finalize(const double* sums, double count, const float* gamma, const 
     return check_launch("bn_finalize");
 }
 
-int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y,
+int u3d_bn_apply(const float* x, const float* scale, const float* shift, int relu, int64_t n, int C, float* y, void* y_bf16,
                  u3d_stream_t stream) {
-    if (!x || !scale || !shift || !y || !bn_ok(n, C)) return U3D_EINVAL;
+    if (!x || !scale || !shift || !y || !bn_ok(n, C) || !shadow_ok(y_bf16, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(U3D_K_BN, s, (double)n * C * 8);
+    ProfScope prof(U3D_K_BN, s, (double)n * C * (y_bf16 ? 10 : 8));
     const int64_t n4 = n * (C / 4);
-    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, scale, shift, relu, n4, C / 4, y);
+    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, scale, shift, relu, n4, C / 4, y, (__bf16*)y_bf16);
     return check_launch("bn_apply");
 }
 
@@ -352,20 +368,20 @@ int u3d_bn_bwd_stats(const float* x, const float* dy, const float* mean, const f
 }
 
 int u3d_bn_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd, const float* scale,
-                     const float* shift, int relu, const double* sums, double count, int64_t n, int C, float* dx,
+                     const float* shift, int relu, const double* sums, double count, int64_t n, int C, float* dx, void* dx_bf16,
                      float* dgamma, float* dbeta, const float* addend, u3d_stream_t stream) {
-    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !dx || !bn_ok(n, C)) return U3D_EINVAL;
+    if (!x || !dy || !mean || !invstd || !scale || !shift || !sums || !dx || !bn_ok(n, C) || !shadow_ok(dx_bf16, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
     const int64_t n4 = n * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, mean, invstd, scale, shift, relu, sums,
-                       1.0 / count, n4, C, dx, dgamma, dbeta, (const double*)nullptr, addend);
+                       1.0 / count, n4, C, dx, dgamma, dbeta, (const double*)nullptr, addend, (__bf16*)dx_bf16);
     return check_launch("bn_bwd_apply");
 }
 
 int u3d_bn_forward(const float* x, int64_t n, int C, const float* partial, int64_t n_tiles, const float* gamma, const float* beta, float eps,
-                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, float* st,
-                   double* sums, void* ws, u3d_stream_t stream) {
+                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int relu, float* y, void* y_bf16,
+                   float* st, double* sums, void* ws, u3d_stream_t stream) {
     // statistics (per-workgroup partial rows) -> bn_sum_k (sums them and finalizes the layer) -> apply
     if (!x || !sums || !ws || !gamma || !beta || !st || !y || !bn_ok(n, C)) return U3D_EINVAL;
     BnFin f = bn_fin(sums, (double)n, 1);
@@ -373,21 +389,22 @@ int u3d_bn_forward(const float* x, int64_t n, int C, const float* partial, int64
     f.st = st; f.nbt = num_batches_tracked;
     int rc = bn_stats_launch(x, n, C, partial, n_tiles, f, ws, (hipStream_t)stream);
     if (rc) return rc;
-    return u3d_bn_apply(x, st + 2 * C, st + 3 * C, relu, n, C, y, stream);
+    return u3d_bn_apply(x, st + 2 * C, st + 3 * C, relu, n, C, y, y_bf16, stream);
 }
 
 int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, const double* fwd_sums, double* sums, int64_t n, int C,
-                    float* dx, float* dgamma, float* dbeta, const float* addend, void* ws, u3d_stream_t stream) {
+                    float* dx, void* dx_bf16, float* dgamma, float* dbeta, const float* addend, void* ws, u3d_stream_t stream) {
     // sums[0..2C) are overwritten; sums[2C] (the row count) is taken from the forward pass's vector
     if (!fwd_sums) return U3D_EINVAL;
     int rc = u3d_bn_bwd_stats(x, dy, st, st + C, st + 2 * C, st + 3 * C, relu, n, C, sums, ws, stream);
     if (rc) return rc;
-    if (!dx) return U3D_EINVAL;
+    if (!dx || !shadow_ok(dx_bf16, C)) return U3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;       // the row count is read from the forward pass's vector (no copy launch)
     ProfScope prof(U3D_K_BN, s, (double)n * C * 12);
     const int64_t n4 = n * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(n4)), dim3(256), 0, s, x, dy, (const float*)st, (const float*)(st + C), (const float*)(st + 2 * C),
-                       (const float*)(st + 3 * C), relu, (const double*)sums, -1.0, n4, C, dx, dgamma, dbeta, fwd_sums + 2 * C, addend);
+                       (const float*)(st + 3 * C), relu, (const double*)sums, -1.0, n4, C, dx, dgamma, dbeta, fwd_sums + 2 * C, addend,
+                       (__bf16*)dx_bf16);
     return check_launch("bn_backward");
 }
 

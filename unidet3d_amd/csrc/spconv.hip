@@ -1021,9 +1021,10 @@ int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k
 static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
                            const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
                            int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream, int pr) {
-    if (pr && Cs % 32) { set_error("spconv_gmm_%s: Cs=%d must be a multiple of 32", pr == 1 ? "bf16" : "x3", Cs); return U3D_EUNSUPPORTED; }
+    if (pr && Cs % 32) { set_error("spconv_gmm_%s: Cs=%d must be a multiple of 32", pr == 1 ? "bf16" : (pr == 2 ? "x3" : "bf16a"), Cs); return U3D_EUNSUPPORTED; }
     if (!src || !w_rows || !gather || !scatter || !tile_starts || !dst || K <= 0 || K > 32 || n_dst <= 0 || n_src <= 0 || cap <= 0) return U3D_EINVAL;
     // the kernel addresses through 32-bit buffer offsets and multiplies row indices with v_mul_u32_u24
+    if (pr == 3 && bn_partial) { set_error("spconv_gmm_bf16a: per-tile statistics are not produced by this kernel"); return U3D_EUNSUPPORTED; }
     if (n_src >= (1 << 24) || n_dst >= (1 << 24) || n_src * Cs * 4 >= 0x7fffffffLL || (int64_t)K * cap * 4 >= 0x7fffffffLL) {
         set_error("spconv_gmm: %lld source rows x %d channels / %lld pairs per offset exceed the kernel's 32-bit addressing",
                   (long long)n_src, Cs, (long long)cap);
@@ -1054,7 +1055,7 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
     // bf16 operands from fp32 rows (pr = 1): the wave-tile kernel measured ahead (level 1, 32 -> 32: 78 us against 88);
     // u3d_conv_kernel(2) takes the workgroup form wherever it is instantiated (tests, A/B runs)
     const int ck = u3d_conv_kernel(-1);
-    if (pr && (ck == 2 || (ck == 1 && pr == 2 && G == 1)) && !bn_partial && gmm_wg_supported(cs16, R, pr)) {
+    if (pr == 3 || (pr && (ck == 2 || (ck == 1 && pr == 2 && G == 1)) && !bn_partial && gmm_wg_supported(cs16, R, pr))) {
         rc = launch_gmm_wg(p, cs16, R, pr, s);
     } else if (pr == 1) {
         U3D_GMM_CASE_BF(2) U3D_GMM_CASE_BF(4) U3D_GMM_CASE_BF(6) U3D_GMM_CASE_BF(8) U3D_GMM_CASE_BF(10) U3D_GMM_CASE_BF(12) U3D_GMM_CASE_BF(16)
@@ -1096,6 +1097,13 @@ int u3d_spconv_gmm_x3(const float* src, int64_t n_src, const void* w_rows_x3, co
                       int k_groups, const float* addend, float* dst, void* ws, float* bn_partial, double flops_hint, u3d_stream_t stream) {
     return spconv_gmm_impl(src, n_src, (const float*)w_rows_x3, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows, k_groups,
                            addend, dst, ws, bn_partial, flops_hint, stream, 2);
+}
+
+int u3d_spconv_gmm_bf16a(const void* src_bf16, int64_t n_src, const void* w_rows_bf16, const int32_t* gather, const int32_t* scatter,
+                         const int32_t* tile_starts, int K, int64_t cap, int Cs, int Cd, int64_t n_dst, int tile_rows,
+                         int k_groups, const float* addend, float* dst, void* ws, double flops_hint, u3d_stream_t stream) {
+    return spconv_gmm_impl((const float*)src_bf16, n_src, (const float*)w_rows_bf16, gather, scatter, tile_starts, K, cap, Cs, Cd, n_dst, tile_rows,
+                           k_groups, addend, dst, ws, nullptr, flops_hint, stream, 3);
 }
 
 int u3d_weight_pack_x3(const float* w, void* wp, int Cd, int K, int Cs, int transposed, u3d_stream_t stream) {

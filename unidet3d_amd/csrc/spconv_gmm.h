@@ -41,7 +41,7 @@ constexpr bool GMM_SWZ = true;
 constexpr int GMM_ALD = 32;
 #endif
 
-// workgroup-tile kernel (spconv_wg.hip): pr = 1 bf16 operands, 2 three bf16 planes; p.n_sub counts R-row tiles
+// workgroup-tile kernel (spconv_wg.hip): pr = 1 bf16 operands, 2 three bf16 planes, 3 bf16 source rows (p.src points at bf16 [n_src][Cs]); p.n_sub counts R-row tiles
 int launch_gmm_wg(const GmmParams& p, int cs16, int R, int pr, hipStream_t s);
 bool gmm_wg_supported(int cs16, int R, int pr);
 

@@ -17,33 +17,18 @@
 
 #include "spconv_gmm.h"
 
-// Timing ablations (tools/build_variant.sh <out.so> spconv_wg.hip -DU3D_WGK_ABL=<mask>; results are WRONG by construction, never
-// shipped): 1 no MFMAs (operands kept alive), 2 no split arithmetic, 4 no barriers, 8 no row gathers, 16 every gather hits rows
-// 0..63, 32 no accumulator read-modify-write, 64 LDS padded to two workgroups per CU, 128 no weight-fragment reads, 256 no staging
-// transposition, 512 no index loads
-#ifndef U3D_WGK_ABL
-#define U3D_WGK_ABL 0
-#endif
-
 namespace u3d {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 __device__ __forceinline__ f32x4 wg_mfma(const f32x4& a, const bf16x8& b, const f32x4& c) {
-    if constexpr ((U3D_WGK_ABL & 1) != 0) {
-        f32x4 r = c;
-        asm volatile("" : "+v"(r) : "v"(a), "v"(b));
-        return r;
-    } else {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
-    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
 }
 
 // float index of (row r, 16-byte quad c4) in the accumulator tile: 128-byte rows, quad stored at c4 ^ (r & 7)
 __device__ __forceinline__ int wg_acc_idx(int r, int c4) { return r * 32 + ((c4 ^ (r & 7)) << 2); }
 
 __device__ __forceinline__ void wg_barrier() {      // LDS traffic of this wave done, then the workgroup barrier; vmcnt is NOT drained
-    if constexpr ((U3D_WGK_ABL & 4) != 0) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -51,13 +36,16 @@ __device__ __forceinline__ void wg_barrier() {      // LDS traffic of this wave 
 
 // LDS of a workgroup: accumulator tile (4R rows + one scratch row per wave) | 4 staging images (16 rows x 128 B) | weight slot(s)
 constexpr int wg_acc_floats(int r) { return (4 * r + 4) * 32; }
-constexpr int WG_STAGE_FLOATS = 16 * 8 * 4;
+constexpr int wg_stage_floats(int pr) { return pr == 3 ? 0 : 16 * 8 * 4; }      // bf16 rows arrive as MFMA fragments: no staging image
 constexpr int wg_slot_bytes(int cs16, int pr) { return (cs16 / 2) * (pr == 2 ? 6144 : 2048); }
-constexpr int wg_fixed_bytes(int r) { return (wg_acc_floats(r) + 4 * WG_STAGE_FLOATS) * 4; }
-// two weight slots (one barrier per offset) where three workgroups per CU still fit, otherwise one slot (two barriers)
-constexpr int wg_nslot(int cs16, int r, int pr) { return 3 * (wg_fixed_bytes(r) + 2 * wg_slot_bytes(cs16, pr)) <= 160 * 1024 ? 2 : 1; }
+constexpr int wg_fixed_bytes(int r, int pr) { return (wg_acc_floats(r) + 4 * wg_stage_floats(pr)) * 4; }
+constexpr int wg_per_cu(int bytes) { return 160 * 1024 / bytes > 4 ? 4 : 160 * 1024 / bytes; }      // workgroups per CU by LDS (beyond 4 nothing is gained)
+// two weight slots (one barrier per offset) unless the second slot costs a workgroup per CU (then one slot, two barriers)
+constexpr int wg_nslot(int cs16, int r, int pr) {
+    return wg_per_cu(wg_fixed_bytes(r, pr) + 2 * wg_slot_bytes(cs16, pr)) >= wg_per_cu(wg_fixed_bytes(r, pr) + wg_slot_bytes(cs16, pr)) ? 2 : 1;
+}
 constexpr int wg_lds_bytes(int cs16, int r, int pr) {
-    return wg_fixed_bytes(r) + wg_nslot(cs16, r, pr) * wg_slot_bytes(cs16, pr) + ((U3D_WGK_ABL & 64) ? 26 * 1024 : 0);
+    return wg_fixed_bytes(r, pr) + wg_nslot(cs16, r, pr) * wg_slot_bytes(cs16, pr);
 }
 
 struct WgItem {
@@ -66,14 +54,19 @@ struct WgItem {
 };
 
 // PR = 1: bf16 operands (rows rounded as the operand is formed, weights pre-rounded); PR = 2: three exact bf16 planes per operand.
+// PR = 3: the source rows are ALREADY bf16 in HBM (the shadow copy a batch-norm kernel wrote next to its fp32 output, [n][Cs] bf16):
+// lane (pair i16, lane group q) loads its MFMA fragment -- 16 bytes at byte 16 q of the unit's 64, which the shadow's fragment
+// order (bn.hip store_shadow) fills with channels 4q .. 4q+3 and 16+4q .. 16+4q+3 -- straight from the row: no staging image, no LDS
+// transposition, no rounding arithmetic, half the gathered bytes.  Same operands in the same k slots as PR = 1, the same packed
+// weights (u3d_weight_pack_bf16): bit-identical results.
 // A unit is one 32-channel group of the source channels (JB = 2 in spconv_gmm_k's terms).
 template <int CS16, int R, int PR>
 struct GmmWgWave {
-    static constexpr bool X3 = PR == 2;
+    static constexpr bool X3 = PR == 2, BR = PR == 3;
     static constexpr int NCH = R / 32;            // 16-pair chunks per item
     static constexpr int NJB = CS16 / 2;          // units per item
     static constexpr int W = 16 * NCH;            // pairs per item
-    static constexpr int NI = W / 8;              // load instructions per unit: 8 rows x 128 B each
+    static constexpr int NI = BR ? NCH : W / 8;   // load instructions per unit: 8 rows x 128 B each (fp32 rows) / one fragment per chunk (bf16 rows)
     static constexpr int TR = 4 * R;
     static constexpr int NPL = X3 ? 3 : 1;        // planes per weight fragment
     static constexpr int WB = NPL * 2048;         // bytes of packed weights per (offset, 32-channel group): 2 column blocks x NPL x 1 KB
@@ -91,6 +84,7 @@ struct GmmWgWave {
     int lane, i16, tid, wave, K, row0, cs4, q16;
     int64_t cap;
     int k_hi;
+    int cs2;                                      // bf16 rows: bytes per source row
     int ts_s, ts_e;                               // lane k: THIS WAVE's share of the pairs of offset k in the workgroup's rows
     unsigned kmask;                               // offsets with pairs in the workgroup's rows (= the steps; the same in all four waves)
     int kc, step;                                 // current step's offset (32: past the last), its ordinal
@@ -133,27 +127,25 @@ struct GmmWgWave {
     __device__ __forceinline__ void load_idx(const WgItem& it, int (&g)[NI], int (&s_)[NCH]) const {
         const int soff_k = (int)(it.k * cap) * 4;
         const int vg = cg + it.base * 4, vs = cs_ + it.base * 4;
-        if constexpr ((U3D_WGK_ABL & 512) != 0) {
+        if constexpr (BR) {          // the lane's own pair of every chunk, gather and scatter side alike
 #pragma unroll
-            for (int i = 0; i < NI; ++i) g[i] = (vg + i * 32 + soff_k) & 0xffff;
+            for (int c = 0; c < NCH; ++c) g[c] = bload32(rs_g, vs + c * 64, soff_k);
+        } else {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) s_[c] = row0 + ((vs + c * 64) >> 2 & (TR - 1));
-            return;
+            for (int i = 0; i < NI; ++i) g[i] = bload32(rs_g, vg + i * 32, soff_k);
         }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) g[i] = bload32(rs_g, vg + i * 32, soff_k);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) s_[c] = bload32(rs_s, vs + c * 64, soff_k);
     }
     __device__ __forceinline__ void issue(Buf& buf, const int (&g)[NI], int u) const {
-        const int lp16 = (lane & 7) * 16;
-        if constexpr ((U3D_WGK_ABL & 8) != 0) {
+        if constexpr (BR) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(buf.a[i]) : "v"(g[i]));
+            for (int c = 0; c < NCH; ++c) buf.a[c] = bload128(rs_src, (int)__umul24(g[c], cs2) + q16, u * 64);
             return;
         }
+        const int lp16 = (lane & 7) * 16;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) buf.a[i] = bload128(rs_src, (int)__umul24((U3D_WGK_ABL & 16) ? (g[i] & 63) : g[i], cs4) + lp16, u * 128);
+        for (int i = 0; i < NI; ++i) buf.a[i] = bload128(rs_src, (int)__umul24(g[i], cs4) + lp16, u * 128);
     }
     static __device__ __forceinline__ bf16x8 cvt8(const f32x4& lo, const f32x4& hi) {
         return bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
@@ -162,11 +154,6 @@ struct GmmWgWave {
     // rows of one 16-pair chunk: registers -> swizzled LDS image -> fragments (in-order LDS queue of one wave: no barrier)
     template <int C>
     __device__ __forceinline__ Frag frags(const Buf& buf) const {
-        if constexpr ((U3D_WGK_ABL & 256) != 0) {
-            Frag f;
-            f.v[0] = buf.a[C * 2]; f.v[1] = buf.a[C * 2 + 1];
-            return f;
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(stage + wr_off + i * 256) = buf.a[C * 2 + i];
         Frag f;
@@ -261,9 +248,7 @@ struct GmmWgWave {
     template <int U>
     __device__ __forceinline__ void unit(Buf& cur, Buf& nxt) {
         const bool two = NCH == 2 && it0.base + 16 < it0.e;
-        if constexpr (U == 0 && (U3D_WGK_ABL & 32) != 0) {
-            d00 = f32x4{0.f, 0.f, 0.f, 0.f}; d01 = d00; d10 = d00; d11 = d00;
-        } else if constexpr (U == 0) {                // accumulator rows of the item -> C operands
+        if constexpr (U == 0) {                // accumulator rows of the item -> C operands
             d00 = *reinterpret_cast<const f32x4*>(accq + soff0);
             d01 = *reinterpret_cast<const f32x4*>(accq + (soff0 ^ 64));
             if (two) {
@@ -271,17 +256,17 @@ struct GmmWgWave {
                 d11 = *reinterpret_cast<const f32x4*>(accq + (soff1 ^ 64));
             }
         }
-        const Frag f0 = frags<0>(cur);
-        Frag f1 = f0;
-        if (two) f1 = frags<NCH - 1>(cur);
+        Frag f0, f1;
+        if constexpr (!BR) {
+            f0 = frags<0>(cur);
+            f1 = f0;
+            if (two) f1 = frags<NCH - 1>(cur);
+        }
         f32x4 wf[2][NPL];                      // [column block][plane] of this unit's 32-channel group, from the workgroup's slot
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                if constexpr ((U3D_WGK_ABL & 128) != 0) asm volatile("" : "=v"(wf[nb][q]));
-                else wf[nb][q] = *reinterpret_cast<const f32x4*>(wslot + wrd + U * WB + (nb * NPL + q) * 1024);
-            }
+            for (int q = 0; q < NPL; ++q) wf[nb][q] = *reinterpret_cast<const f32x4*>(wslot + wrd + U * WB + (nb * NPL + q) * 1024);
         WgItem it2;
         int g2[NI], s2[NCH], n0 = 0, n1 = 0;
         if constexpr (U == NJB - 1) {
@@ -324,24 +309,27 @@ struct GmmWgWave {
             }
             d00 += t00; d01 += t01;
         } else {
-            const bf16x8 x0 = cvt8(f0.v[0], f0.v[1]);
+            bf16x8 x0, x1;
+            if constexpr (BR) {
+                x0 = __builtin_bit_cast(bf16x8, cur.a[0]);
+                x1 = __builtin_bit_cast(bf16x8, cur.a[NCH - 1]);
+            } else {
+                x0 = cvt8(f0.v[0], f0.v[1]);
+                x1 = cvt8(f1.v[0], f1.v[1]);
+            }
             d00 = wg_mfma(wf[0][0], x0, d00);
             d01 = wg_mfma(wf[1][0], x0, d01);
             if (two) {
-                const bf16x8 x1 = cvt8(f1.v[0], f1.v[1]);
                 d10 = wg_mfma(wf[0][0], x1, d10);
                 d11 = wg_mfma(wf[1][0], x1, d11);
             }
         }
-        if constexpr (U == NJB - 1 && (U3D_WGK_ABL & 32) != 0) asm volatile("" :: "v"(d00), "v"(d01), "v"(d10), "v"(d11));
         if constexpr (U == NJB - 1) {
-            if constexpr ((U3D_WGK_ABL & 32) == 0) {
             *reinterpret_cast<f32x4*>(accq + soff0) = d00;
             *reinterpret_cast<f32x4*>(accq + (soff0 ^ 64)) = d01;
             if (two) {
                 *reinterpret_cast<f32x4*>(accq + soff1) = d10;
                 *reinterpret_cast<f32x4*>(accq + (soff1 ^ 64)) = d11;
-            }
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) { g_cur[i] = ix1_g[i]; ix1_g[i] = g2[i]; }
@@ -412,12 +400,12 @@ __global__ __launch_bounds__(256) void spconv_gmm_wg_k(GmmParams p) {
     }
 
     WV w;
-    w.rs_src = make_rsrc(p.src, p.n_src * p.Cs * 4); w.rs_g = make_rsrc(p.gather, (int64_t)p.K * p.cap * 4);
+    w.rs_src = make_rsrc(p.src, p.n_src * p.Cs * (PR == 3 ? 2 : 4)); w.rs_g = make_rsrc(p.gather, (int64_t)p.K * p.cap * 4);
     w.rs_s = make_rsrc(p.scatter, (int64_t)p.K * p.cap * 4); w.rs_w = make_rsrc(p.w);
     w.accq = reinterpret_cast<char*>(acc);
-    w.stage = smem + wg_acc_floats(R) + wave * WG_STAGE_FLOATS;
-    w.wslot = reinterpret_cast<char*>(smem + wg_acc_floats(R) + 4 * WG_STAGE_FLOATS);
-    w.lane = lane; w.i16 = lane & 15; w.tid = tid; w.wave = wave; w.K = p.K; w.cap = p.cap; w.row0 = (int)row0; w.cs4 = p.Cs * 4;
+    w.stage = smem + wg_acc_floats(R) + wave * wg_stage_floats(PR);
+    w.wslot = reinterpret_cast<char*>(smem + wg_acc_floats(R) + 4 * wg_stage_floats(PR));
+    w.lane = lane; w.i16 = lane & 15; w.tid = tid; w.wave = wave; w.K = p.K; w.cap = p.cap; w.row0 = (int)row0; w.cs4 = p.Cs * 4; w.cs2 = p.Cs * 2;
     const int q = lane >> 4, lr = lane >> 3;
     w.q16 = q << 4;
     w.cg = lr * 4; w.cs_ = (lane & 15) * 4;
@@ -462,7 +450,7 @@ static int launch_wg(const GmmParams& p, hipStream_t s) {
 }
 
 bool gmm_wg_supported(int cs16, int R, int pr) {
-    if (pr != 1 && pr != 2) return false;
+    if (pr != 1 && pr != 2 && pr != 3) return false;
     if (R != 32 && R != 64) return false;
     return cs16 == 2 || cs16 == 4 || cs16 == 6 || cs16 == 8 || cs16 == 10 || cs16 == 12 || cs16 == 16;
 }
@@ -471,6 +459,7 @@ int launch_gmm_wg(const GmmParams& p, int cs16, int R, int pr, hipStream_t s) {
 #define U3D_WG_CASE(cs) \
     if (cs16 == cs) { \
         if (pr == 2) return R == 64 ? launch_wg<cs, 64, 2>(p, s) : launch_wg<cs, 32, 2>(p, s); \
+        if (pr == 3) return R == 64 ? launch_wg<cs, 64, 3>(p, s) : launch_wg<cs, 32, 3>(p, s); \
         return R == 64 ? launch_wg<cs, 64, 1>(p, s) : launch_wg<cs, 32, 1>(p, s); \
     }
     U3D_WG_CASE(2) U3D_WG_CASE(4) U3D_WG_CASE(6) U3D_WG_CASE(8) U3D_WG_CASE(10) U3D_WG_CASE(12) U3D_WG_CASE(16)

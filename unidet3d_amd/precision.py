@@ -14,6 +14,7 @@ The mode is read when an op runs forward and is remembered for that op's backwar
 from __future__ import annotations
 
 import contextlib
+import os
 
 _MODE = 'fp32'
 BF16_FLAG = 16          # include/u3d.h U3D_BF16_OPERANDS
@@ -100,6 +101,32 @@ def conv_kernel(kind: str):
 
 
 FMT_FP32, FMT_BF16, FMT_X3 = 0, 1, 2
+
+# bf16 operands (BASELINE configs[2]): batch-norm outputs and the gradients a batch norm hands back are ALSO written as bf16 rows
+# (a shadow next to the fp32 tensor, sparse.attach_shadow) and the sparse convolutions gather those -- half the gathered bytes, the
+# MFMA fragment straight from the row.  Bit-identical to gathering the fp32 rows and rounding them (what FMT_BF16 does); off:
+# U3D_BF16_ROWS=0 / set_bf16_rows(False).
+_BF16_ROWS = os.environ.get('U3D_BF16_ROWS', '1') != '0'
+
+
+def set_bf16_rows(on: bool) -> bool:
+    global _BF16_ROWS
+    prev, _BF16_ROWS = _BF16_ROWS, bool(on)
+    return prev
+
+
+def bf16_rows() -> bool:
+    """True when bf16-operand mode also keeps bf16 copies of the rows the sparse convolutions gather."""
+    return _MODE == 'bf16' and _BF16_ROWS
+
+
+@contextlib.contextmanager
+def bf16_rows_mode(on: bool):
+    prev = set_bf16_rows(on)
+    try:
+        yield
+    finally:
+        set_bf16_rows(prev)
 
 
 def conv_format() -> int:

@@ -203,6 +203,34 @@ def _plan(Cs, Cd, K, n_dst):
     return R.value, G.value
 
 
+# ---- bf16 shadows of the rows the sparse convolutions gather (precision.bf16_rows) ------------------------------------------
+# A shadow is an attribute of the fp32 tensor it was rounded from: it travels with that tensor object through autograd (torch keeps
+# a tensor's Python object, attributes included, alive as long as the tensor itself) and dies with it; a tensor autograd built by
+# ADDING two gradients is a new object without one, and its consumer then gathers the fp32 rows -- same values, same results.
+SHADOW_STATS = {'hit': 0, 'miss': 0}
+
+
+def to_shadow(t: torch.Tensor) -> torch.Tensor:
+    """The bf16 shadow of an fp32 [n, C] tensor (C % 32 == 0) as the batch-norm kernels write it: rounded to nearest even, each
+    32-channel group in MFMA fragment order -- 8-byte pieces (quad q, half h) at position 2q + h, i.e. the 16 bytes at byte 16 q hold
+    channels 4q..4q+3 and 16+4q..16+4q+3 (csrc/bn.hip store_shadow).  Torch ops, for tests and tools."""
+    n, C = t.shape
+    return t.detach().reshape(n, C // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).to(torch.bfloat16).reshape(n, C).contiguous()
+
+
+def attach_shadow(t: torch.Tensor, shadow: torch.Tensor):
+    t._u3d_shadow = (shadow, t._version)
+
+
+def shadow_of(t: torch.Tensor):
+    e = getattr(t, '_u3d_shadow', None)
+    if e is not None and e[1] == t._version and e[0].shape == t.shape and e[0].device == t.device:
+        SHADOW_STATS['hit'] += 1
+        return e[0]
+    SHADOW_STATS['miss'] += 1
+    return None
+
+
 # ---- all weight packs of a model in one launch ------------------------------------------------------------------------------
 _PACKED: Dict = {}          # (weight data_ptr, transposed, bf16) -> (buffer, weight tensor, version at pack time)
 
@@ -290,13 +318,14 @@ def _pack_floats(numel: int, fmt: int) -> int:
     return {0: numel, 1: numel // 2, 2: numel * 3 // 2}[fmt]
 
 
-def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=0, stats_out=None):
+def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=0, stats_out=None, src_rows_bf16=None):
     """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in).
     ``stats_out`` (a dict, or None): asks the kernel's epilogue for the per-tile column sums of dst that the batch norm behind
     this convolution needs (``partial`` float [n_tiles, 2, Cd], ``n_tiles``); left empty when the launch splits the kernel
     offsets over groups (deep levels: a few thousand rows, the norm then makes its own pass).
     ``bf``: operand format (precision.conv_format: 0 fp32 MFMAs, 1 bf16 operands, 2 fp32 products from three bf16 planes);
-    source channel counts that are not a multiple of 32 (the 6 -> 32 input convolution, padded to 16) stay on the fp32 kernel."""
+    source channel counts that are not a multiple of 32 (the 6 -> 32 input convolution, padded to 16) stay on the fp32 kernel.
+    ``src_rows_bf16``: the bf16 shadow of ``src`` (``shadow_of``) -- the launch then gathers those rows (u3d_spconv_gmm_bf16a)."""
     Cs, Cd = src.shape[1], (weight.shape[2] if transposed else weight.shape[0])
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     if n_dst:
@@ -310,6 +339,11 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
             partial = torch.empty(n_tiles, 2, Cd, dtype=torch.float32, device=src.device)
             stats_out.update(partial=partial, n_tiles=n_tiles)
         bf = int(bf) if Cs % 32 == 0 else 0
+        rows = src_rows_bf16 is not None and bf == P.FMT_BF16       # gather the bf16 shadow: same packed weights, u3d_spconv_gmm_bf16a
+        if rows:
+            src, partial = src_rows_bf16, None
+            if stats_out is not None:
+                stats_out.clear()
         pack_fn, gmm_fn = _GMM_ENTRY[bf]
         hit = _PACKED.get((weight.data_ptr(), int(transposed), bf))
         if hit is not None and hit[2] == weight._version and hit[1].device == src.device:
@@ -317,8 +351,12 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
         else:
             wp = torch.empty(_pack_floats(weight.numel(), bf), dtype=torch.float32, device=src.device)       # MFMA-fragment order
             L.call(pack_fn, L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
-        L.call(gmm_fn, L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
-               rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), L.ptr(partial), float(flops), L.stream())
+        if rows:
+            L.call('u3d_spconv_gmm_bf16a', L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
+                   rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), float(flops), L.stream())
+        else:
+            L.call(gmm_fn, L.ptr(src), src.shape[0], L.ptr(wp), L.ptr(gather), L.ptr(scatter), L.ptr(rb.tile_starts(role, R)),
+                   rb.K, rb.cap, Cs, Cd, n_dst, R, G, L.ptr(addend), L.ptr(dst), L.ptr(ws), L.ptr(partial), float(flops), L.stream())
     return dst
 
 
@@ -368,8 +406,9 @@ class _SparseConvFn(torch.autograd.Function):
             g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
         ctx.bf = P.conv_format()
+        ctx.rows = ctx.bf == P.FMT_BF16 and P.bf16_rows() and cin % 32 == 0
         dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops, ctx.bf,
-                   stats_out)
+                   stats_out, shadow_of(src) if ctx.rows else None)
         ctx.save_for_backward(src, weight)
         ctx.rb, ctx.mode, ctx.has_addend = rb, mode, addend is not None
         return dst
@@ -413,14 +452,19 @@ class _SparseConvFn(torch.autograd.Function):
                 g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
             else:
                 g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
-            dsrc = _gmm(dout, weight.reshape(cout, rb.K, cin).contiguous(), True, rb, g, s, role, n_dst, None, flops, ctx.bf)
+            rows = ctx.bf == P.FMT_BF16 and P.bf16_rows() and cout % 32 == 0
+            dsrc = _gmm(dout, weight.reshape(cout, rb.K, cin).contiguous(), True, rb, g, s, role, n_dst, None, flops, ctx.bf,
+                        None, shadow_of(dout) if rows else None)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return dsrc, dw, None, None, (dout if ctx.has_addend else None), None
 
 
 def sparse_conv(src, weight, rb, mode='fwd', addend=None, stats_out=None):
-    return _SparseConvFn.apply(src, weight, rb, mode, addend, stats_out)
+    dst = _SparseConvFn.apply(src, weight, rb, mode, addend, stats_out)
+    if P.bf16_rows():
+        dst._u3d_from_conv = True      # the batch norm behind this output hands its gradient back with a bf16 shadow (bf16_rows)
+    return dst
 
 
 # ----------------------------------------------------------------------------------------
@@ -441,11 +485,14 @@ def allreduce_bn_sums(sums: torch.Tensor, group=None):
 class _BNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training, sync, nbt=None, want_skip=False,
-                stats=None):
-        """``stats``: dict(partial, n_tiles) from the epilogue of the convolution that produced x (sparse._gmm), or None."""
+                stats=None, yb=None, dx_shadow=False):
+        """``stats``: dict(partial, n_tiles) from the epilogue of the convolution that produced x (sparse._gmm), or None.
+        ``yb`` (bf16 [n, C] or None): receives y rounded to bf16 in the same pass (precision.bf16_rows); ``dx_shadow``: the backward
+        writes such a copy of dx too and attaches it to the gradient it returns (x came out of a sparse convolution)."""
         x = x.contiguous()
         n, C = x.shape
         dev = x.device
+        ctx.dx_shadow = bool(dx_shadow)
         st = torch.empty(4, C, dtype=torch.float32, device=dev)     # mean, invstd, scale, shift
         y = torch.empty_like(x)
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
@@ -464,17 +511,17 @@ class _BNReLUFn(torch.autograd.Function):
                        L.ptr(running_mean), L.ptr(running_var), C, L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]),
                        L.ptr(st[3]), L.ptr(nbt), L.stream())
                 if n:
-                    L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
+                    L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.ptr(yb), L.stream())
             else:                                # one call: stats -> finalize -> apply
                 L.call('u3d_bn_forward', L.ptr(x), n, C, L.ptr(part), n_tiles, L.ptr(gamma), L.ptr(beta), eps, momentum, L.ptr(running_mean),
-                       L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
+                       L.ptr(running_var), L.ptr(nbt), int(relu), L.ptr(y), L.ptr(yb), L.ptr(st), L.ptr(sums), L.ptr(ws), L.stream())
         else:
             st[0] = running_mean
             st[1] = torch.rsqrt(running_var + eps)
             st[2] = gamma * st[1]
             st[3] = beta - running_mean * st[2]
             if n:
-                L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.stream())
+                L.call('u3d_bn_apply', L.ptr(x), L.ptr(st[2]), L.ptr(st[3]), int(relu), n, C, L.ptr(y), L.ptr(yb), L.stream())
         ctx.save_for_backward(x, st, sums)
         ctx.relu, ctx.training, ctx.sync, ctx.want_skip = relu, training, sync, want_skip
         ctx.set_materialize_grads(False)          # an unused skip output sends None, not a zero tensor
@@ -489,18 +536,19 @@ class _BNReLUFn(torch.autograd.Function):
     def backward(ctx, dy, dskip=None):
         x, st, fsums = ctx.saved_tensors
         if dy is None:                                 # only the identity branch carried a gradient
-            return (dskip,) + (None,) * 12
+            return (dskip,) + (None,) * 14
         dy = dy.contiguous()
         dskip = None if dskip is None else dskip.contiguous()
         n, C = x.shape
         dev = x.device
         dx = torch.empty_like(x)
+        dxb = torch.empty(n, C, dtype=torch.bfloat16, device=dev) if ctx.dx_shadow and n else None
         # dgamma, dbeta (local sums: DDP averages later); separate tensors so that autograd can adopt them as .grad without a copy
         dgb = [torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)]
         if not n:
             if ctx.training and fsums is not None and ctx.sync and _dist_on():     # keep the collective sequence of the other ranks
                 dist.all_reduce(torch.zeros(2 * C, dtype=torch.float64, device=dev), op=dist.ReduceOp.SUM)
-            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None, None, None
+            return dx, dgb[0].zero_(), dgb[1].zero_(), None, None, None, None, None, None, None, None, None, None, None, None
         ws = L.scratch(L.lib().u3d_bn_ws_bytes(C), dev)
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
         if ctx.training and fsums is not None:
@@ -512,9 +560,9 @@ class _BNReLUFn(torch.autograd.Function):
                 dgb[0] = sums[C:2 * C].to(torch.float32)
                 dist.all_reduce(sums[:2 * C], op=dist.ReduceOp.SUM)
                 L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                       int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.ptr(dskip), L.stream())
+                       int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), L.ptr(dxb), None, None, L.ptr(dskip), L.stream())
             else:                                    # one call: bwd_stats -> bwd_apply (+ dgamma / dbeta)
-                L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(fsums), L.ptr(sums), n, C, L.ptr(dx),
+                L.call('u3d_bn_backward', L.ptr(x), L.ptr(dy), L.ptr(st), int(ctx.relu), L.ptr(fsums), L.ptr(sums), n, C, L.ptr(dx), L.ptr(dxb),
                        L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(dskip), L.ptr(ws), L.stream())
         else:                                        # eval: statistics are constants -> dx = scale * dy'
             L.call('u3d_bn_bwd_stats', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
@@ -524,8 +572,10 @@ class _BNReLUFn(torch.autograd.Function):
             sums.zero_()
             sums[2 * C] = 1.0
             L.call('u3d_bn_bwd_apply', L.ptr(x), L.ptr(dy), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
-                   int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), None, None, L.ptr(dskip), L.stream())
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
+                   int(ctx.relu), L.ptr(sums), -1.0, n, C, L.ptr(dx), L.ptr(dxb), None, None, L.ptr(dskip), L.stream())
+        if dxb is not None:
+            attach_shadow(dx, dxb)
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class SparseBatchNorm(nn.Module):
@@ -543,16 +593,24 @@ class SparseBatchNorm(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x: torch.Tensor, relu: bool = False, skip: bool = False, stats=None):
+    def forward(self, x: torch.Tensor, relu: bool = False, skip: bool = False, stats=None, shadow: bool = True):
         """``skip=True`` -> (y, x_id): ``x_id`` is x for a second consumer (the identity branch next to this norm); the gradient that
         consumer sends back is added to dx inside this layer's backward kernel.
         ``stats``: the per-tile column sums the producing convolution's epilogue wrote for exactly this ``x``
         (``SparseConvTensor.stats_for``): the statistics then cost no pass over x."""
+        # bf16 operands with bf16 rows in HBM (precision.bf16_rows): y (when a ReLU follows -- the input of a sparse convolution -- and
+        # the channel count suits the bf16 kernels) and the gradient handed back to a producing convolution get a bf16 shadow
+        rows = P.bf16_rows() and x.is_cuda and x.shape[0] > 0 and x.shape[1] % 32 == 0
+        yb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if rows and relu and shadow else None
+        dx_shadow = rows and getattr(x, '_u3d_from_conv', False)
         # num_batches_tracked is incremented by the statistics kernel (one launch less per layer)
-        return _BNReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                               self.momentum, relu, self.training, self.sync,
-                               self.num_batches_tracked if self.training and (x.shape[0] or (self.sync and _dist_on())) else None, skip,
-                               stats if self.training else None)
+        out = _BNReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                              self.momentum, relu, self.training, self.sync,
+                              self.num_batches_tracked if self.training and (x.shape[0] or (self.sync and _dist_on())) else None, skip,
+                              stats if self.training else None, yb, dx_shadow)
+        if yb is not None:
+            attach_shadow(out[0] if skip else out, yb)
+        return out
 
 
 # ----------------------------------------------------------------------------------------
@@ -621,7 +679,8 @@ class SparseSequential(SparseModule):
                 x = m(x)
             elif isinstance(m, SparseBatchNorm):
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = x.replace_feature(m(x.features, relu=fuse, stats=x.stats_for(x.features)))
+                feeds_conv = fuse and i + 2 < len(mods) and isinstance(mods[i + 2], _ConvBase)      # only then a bf16 shadow of y is of use
+                x = x.replace_feature(m(x.features, relu=fuse, stats=x.stats_for(x.features), shadow=feeds_conv))
                 i += 1 if fuse else 0
             elif isinstance(m, nn.Identity):
                 pass
@@ -639,7 +698,7 @@ def _relu(f):
     one = torch.ones(C, device=f.device)
     zero = torch.zeros(C, device=f.device)
     y = torch.empty_like(f)
-    L.call('u3d_bn_apply', L.ptr(f.contiguous()), L.ptr(one), L.ptr(zero), 1, f.shape[0], C, L.ptr(y), L.stream())
+    L.call('u3d_bn_apply', L.ptr(f.contiguous()), L.ptr(one), L.ptr(zero), 1, f.shape[0], C, L.ptr(y), None, L.stream())
     return y
 
 

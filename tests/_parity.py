@@ -144,7 +144,7 @@ def oracle_relu_masks(orac, run):
     return masks, O
 
 
-def oracle_fp64_grads_same_activation_pattern(orac, run, masks):
+def oracle_fp64_grads_same_activation_pattern(orac, run, masks, dtype=torch.float64):
     """fp64 gradients of the oracle on the SAME piece of the piecewise-smooth function the product evaluated: every
     BatchNorm -> ReLU of the backbone takes its on/off decisions from ``masks`` (the product's own forward, product_forward(...,
     relu_masks=True)) instead of re-deciding them in fp64.
@@ -155,7 +155,7 @@ def oracle_fp64_grads_same_activation_pattern(orac, run, masks):
     With the decisions fixed the function is smooth and the fp32 CPU oracle is within 2e-4 of fp64 on every parameter
     (profiles/round3_relu_flip_analysis.txt) -- so the product can be held to the plain 1e-3 north-star bound."""
     import copy
-    o64 = copy.deepcopy(orac).double().train()
+    o64 = copy.deepcopy(orac).to(dtype).train()          # (dtype = float32: the fp32 oracle itself on that pattern, cfg3's reference)
     n = 0
     for name, seq, key in list(bn_relu_pairs(o64)):
         seq._modules[key] = _MaskedReLU(masks[name])

@@ -407,8 +407,9 @@ class _SparseConvFn(torch.autograd.Function):
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
         ctx.bf = P.conv_format()
         ctx.rows = ctx.bf == P.FMT_BF16 and P.bf16_rows() and cin % 32 == 0
+        ctx.src_shadow = shadow_of(src) if ctx.rows else None          # bf16 rows of src: gathered here and by the weight gradient
         dst = _gmm(src, w.contiguous(), False, rb, g, s, role, n_dst, None if addend is None else addend.contiguous(), flops, ctx.bf,
-                   stats_out, shadow_of(src) if ctx.rows else None)
+                   stats_out, ctx.src_shadow)
         ctx.save_for_backward(src, weight)
         ctx.rb, ctx.mode, ctx.has_addend = rb, mode, addend is not None
         return dst
@@ -422,6 +423,7 @@ class _SparseConvFn(torch.autograd.Function):
         dsrc = dw = None
         flops = 2.0 * rb.total_pairs * cin * cout if _PROFILE_FLOPS else 0.0
         side = None
+        dout_shadow = shadow_of(dout) if ctx.bf == P.FMT_BF16 and P.bf16_rows() and cout % 32 == 0 else None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             if mode == 'fwd':
@@ -436,25 +438,28 @@ class _SparseConvFn(torch.autograd.Function):
             # the weight-gradient walk is bound by its row gathers: bf16 operands pay off only where the matrix
             # work is a visible share -- measured (tools/prof_wgrad.py): 32x32 channels 179 us fp32 vs 221 us bf16, 64x64 150 vs 104
             wg = 'u3d_spconv_wgrad_bf16' if ctx.bf == P.FMT_BF16 and cin * cout >= 64 * 64 else 'u3d_spconv_wgrad'
+            xw, gw = src, dout
+            if ctx.src_shadow is not None and dout_shadow is not None and L.lib().u3d_spconv_wgrad_rows_supported(cin, cout):
+                # both operands exist as bf16 rows: whole-row gathers, LDS transpose reads, bf16 MFMAs over 32 pairs (spconv_wgrad_rows.hip)
+                wg, xw, gw = 'u3d_spconv_wgrad_rows', ctx.src_shadow, dout_shadow
             # the weight gradient and the input gradient of a layer are independent: the former runs on a side stream so
             # the two kernels (neither fills the machine alone) share the GPU; joined before the layer's backward returns
             if _WGRAD_SIDE_STREAM and ctx.needs_input_grad[0]:
                 side = _side_stream(weight.device)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    L.call(wg, L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
+                    L.call(wg, L.ptr(xw), xw.shape[0], L.ptr(gw), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                            rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
             else:
-                L.call(wg, L.ptr(src), src.shape[0], L.ptr(dout), L.ptr(rx), L.ptr(rg), L.ptr(ts),
+                L.call(wg, L.ptr(xw), xw.shape[0], L.ptr(gw), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                        rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
         if ctx.needs_input_grad[0]:
             if mode == 'fwd':
                 g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in
             else:
                 g, s, role, n_dst = rb.pair_in, rb.pair_out, 'out', rb.n_out
-            rows = ctx.bf == P.FMT_BF16 and P.bf16_rows() and cout % 32 == 0
             dsrc = _gmm(dout, weight.reshape(cout, rb.K, cin).contiguous(), True, rb, g, s, role, n_dst, None, flops, ctx.bf,
-                        None, shadow_of(dout) if rows else None)
+                        None, dout_shadow)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return dsrc, dw, None, None, (dout if ctx.has_addend else None), None

@@ -223,7 +223,8 @@ def test_conv_on_bf16_rows_equals_conv_rounding_fp32_rows_bit_for_bit(cin, cout,
         assert torch.equal(a, b), f'{name}: max |diff| {float((a - b).abs().max())}'
 
 
-@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (32, 64), (64, 64)])
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (32, 64), (64, 64), (96, 96), (128, 128), (160, 160), (128, 64), (64, 96), (96, 64), (128, 160),
+                                      (160, 128), (192, 96), (256, 128)])
 def test_wgrad_from_bf16_rows_is_the_fp32_kernel_on_rounded_operands(cin, cout):
     """u3d_spconv_wgrad_rows (whole bf16 rows -> LDS -> ds_read_b64_tr_b16 fragments -> bf16 MFMAs over 32 pairs) multiplies exactly
     the rounded values: it must reproduce the fp32 weight-gradient kernel run on pre-rounded x and dy to summation order (2e-5),
@@ -251,7 +252,10 @@ def test_wgrad_from_bf16_rows_is_the_fp32_kernel_on_rounded_operands(cin, cout):
 
     def grads(rows):
         out = []
-        for src, gy, w, book, mode in ((x, go, w3, rb, 'fwd'), (x, go2, w2, rb2, 'fwd'), (x2, x, wi, rb2, 'inv')):
+        cases = [(x, go, w3, rb, 'fwd'), (x, go2, w2, rb2, 'fwd'), (x2, x, wi, rb2, 'inv')]
+        if (cin, cout) in ((128, 64), (192, 96), (256, 128)):
+            cases = cases[:2]             # (the fp32 reference kernel has no 64 -> 128 instantiation: no layer of the model has that shape)
+        for src, gy, w, book, mode in cases:
             wd = w.clone().requires_grad_()
             if rows:
                 with P.operands('bf16'), P.bf16_rows_mode(True):
@@ -261,6 +265,8 @@ def test_wgrad_from_bf16_rows_is_the_fp32_kernel_on_rounded_operands(cin, cout):
                     sparse.sparse_conv(_rb(src), wd, book, mode).backward(_rb(gy))
             out.append(wd.grad)
         return out
+    from unidet3d_amd import _lib as L
+    assert L.lib().u3d_spconv_wgrad_rows_supported(cin, cout) == 1
     got, ref = grads(True), grads(False)
     for name, a, b in zip(('subm', 'down', 'inverse'), got, ref):
         assert torch.isfinite(a).all() and _rel(a, b) < 2e-5, (name, _rel(a, b))
@@ -296,7 +302,7 @@ def test_batch_norm_writes_bf16_shadows_of_its_output_and_of_the_gradient_it_ret
 def test_training_step_with_bf16_rows_is_bit_identical_to_rounding_fp32_rows():
     """The whole cfg3-style step (bf16 operands) with bf16 shadows of every batch-norm output / returned gradient gathered by the
     sparse convolutions, against the same step gathering fp32 rows: loss identical, every parameter gradient identical EXCEPT the
-    convolution weights whose gradient now comes from u3d_spconv_wgrad_rows (32 / 64 channels: bf16 operands where the fp32-row path
+    convolution weights whose gradient now comes from u3d_spconv_wgrad_rows (bf16 operands where the fp32-row path
     keeps fp32 operands below 64 x 64 channels, another summation order) -- those within the bf16 operand tolerance; and the shadows
     are really used (forward + input-gradient launches of every 3x3x3 / strided / inverse convolution behind a batch norm)."""
     import copy
@@ -304,6 +310,7 @@ def test_training_step_with_bf16_rows_is_bit_identical_to_rounding_fp32_rows():
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
     from _detw import fill_state_dict
+    from unidet3d_amd import _lib as L
     from unidet3d_amd import precision as P
     from unidet3d_amd import sparse
     from unidet3d_amd.config import build_model, scannet_model_cfg
@@ -325,7 +332,7 @@ def test_training_step_with_bf16_rows_is_bit_identical_to_rounding_fp32_rows():
     assert torch.equal(res[True][0], res[False][0])
     worst = 0.0
     for n, gr in res[False][1].items():
-        if gr.dim() == 5 and gr.shape[0] in (32, 64) and gr.shape[-1] in (32, 64):        # convolution weights the row kernel serves
+        if gr.dim() == 5 and L.lib().u3d_spconv_wgrad_rows_supported(gr.shape[-1], gr.shape[0]):       # convolution weights the row kernels serve
             worst = max(worst, _rel(res[True][1][n], gr))
         else:
             assert torch.equal(gr, res[True][1][n]), n

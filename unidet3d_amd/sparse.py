@@ -442,6 +442,7 @@ class _SparseConvFn(torch.autograd.Function):
             if ctx.src_shadow is not None and dout_shadow is not None and L.lib().u3d_spconv_wgrad_rows_supported(cin, cout):
                 # both operands exist as bf16 rows: whole-row gathers, LDS transpose reads, bf16 MFMAs over 32 pairs (spconv_wgrad_rows.hip)
                 wg, xw, gw = 'u3d_spconv_wgrad_rows', ctx.src_shadow, dout_shadow
+
             # the weight gradient and the input gradient of a layer are independent: the former runs on a side stream so
             # the two kernels (neither fills the machine alone) share the GPU; joined before the layer's backward returns
             if _WGRAD_SIDE_STREAM and ctx.needs_input_grad[0]:

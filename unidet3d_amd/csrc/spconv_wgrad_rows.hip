@@ -41,6 +41,9 @@ __host__ __device__ inline int frag_channel_of_pos(int p) { return (p & ~31) | (
 // their own) was built and measured for the fp32 path in round 4 and is NOT instantiated: correct (the kernel tests passed at the
 // fp32 bounds) but slower than the strided-fragment fp32 MFMA walk of spconv.hip -- 32 x 32 channels 152 us against 141, 64 x 64
 // 176 against 123 (three plane tiles per operand: 49 / 98 KB of LDS per workgroup, 3x the LDS traffic, the split's VALU time).
+// So was the walk on fp32 rows with native fp32 MFMAs (fp32 tiles, ds_read_b32 operands): 166 us against 139 (32 x 32), 193 against
+// 125 (64 x 64) -- with 4-byte elements the tiles cost the occupancy the 32-cycle fp32 MFMAs need (48 / 80 KB per workgroup), and
+// a K-step covers 4 pairs instead of 32.  The whole-row walk pays for 2-byte rows only.
 template <int NG, int NX, int NP>      // Cd / 16, Cs / 16
 __global__ __launch_bounds__(256) void spconv_wgrad_rows_k(WgRowsParams p) {
     constexpr int CD = NG * 16, CS = NX * 16;

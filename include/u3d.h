@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 107
+#define U3D_ABI_VERSION 108
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -203,6 +203,8 @@ int u3d_weight_pack_batch(const void* desc, int n_desc, int64_t total_blocks, u3
  * the groups' partial sums go through ws = k_groups*n_dst*Cd*4 bytes and a fixed-order reduce).
  * Returns U3D_EUNSUPPORTED for channel counts that are not instantiated. */
 int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups);
+/* the plan u3d_spconv_gmm_bf16a wants (its light items prefer 32-row tiles and fewer offset groups at the small levels) */
+int u3d_spconv_plan_bf16a(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups);
 /* dW[(n*K+k)*Cs + c] = sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]   (dW is overwritten).
  * The pairs of offset k are processed per tile of dy rows: tile_starts = u3d_tile_starts(rows_dy, ..., tile_rows =
  * u3d_spconv_wgrad_tile_rows(...)); per-tile partial blocks go through ws and are summed in a fixed order

@@ -321,14 +321,22 @@ def test_training_step_with_bf16_rows_is_bit_identical_to_rounding_fp32_rows():
     base = fill_state_dict(build_model(cfg), tag0=3300, scale=0.06)
     inputs, samples = make_batch_inputs([make_scene(140 + i, n_points=10_000) for i in range(2)], DEV)
     res = {}
-    for rows in (False, True):
-        model = copy.deepcopy(base).to(DEV).train()
-        sparse.SHADOW_STATS.update(hit=0, miss=0)
-        with P.operands('bf16'), P.bf16_rows_mode(rows):
-            loss = model.loss(inputs, copy.deepcopy(samples))['det_loss']
-            loss.backward()
-        res[rows] = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
-                     dict(sparse.SHADOW_STATS))
+    # (the two kinds of kernel have launch plans of their own at the small levels -- tile height, offset groups -- and offset groups
+    # change the order in which a row's offsets are summed: the comparison pins ONE plan for both)
+    env = {k: os.environ.get(k) for k in ('U3D_GMM_R', 'U3D_GMM_G')}
+    os.environ['U3D_GMM_R'], os.environ['U3D_GMM_G'] = '32', '3'
+    try:
+        for rows in (False, True):
+            model = copy.deepcopy(base).to(DEV).train()
+            sparse.SHADOW_STATS.update(hit=0, miss=0)
+            with P.operands('bf16'), P.bf16_rows_mode(rows):
+                loss = model.loss(inputs, copy.deepcopy(samples))['det_loss']
+                loss.backward()
+            res[rows] = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                         dict(sparse.SHADOW_STATS))
+    finally:
+        for k, v in env.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     assert torch.equal(res[True][0], res[False][0])
     worst = 0.0
     for n, gr in res[False][1].items():

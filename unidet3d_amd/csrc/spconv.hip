@@ -504,12 +504,19 @@ __global__ __launch_bounds__(256) void gmm_reduce_k(const float* __restrict__ pa
 // (fewer than 2048 wave tiles) splits its 27 offsets over NINE groups instead of going to 32-row tiles and three groups
 // (level 3, 192 -> 96 channels: 126 us against 161; level 4, 256 -> 128: 69 against 80); strided / inverse convolutions
 // (8 offsets, no groups) keep 32-row tiles there for the parallelism.
-static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G) {
+// The bf16-row kernel (u3d_spconv_gmm_bf16a: light items, four workgroups per CU) wants the opposite at the small levels: 32-row
+// tiles, and offset groups only as far as it takes to reach ~2048 wave tiles (same sweep on that kernel,
+// profiles/round4_gmm_plan_sweep_bf16rows.txt: level 3, 96 -> 96: 35 us against 42; level 4, 128 -> 128: 25 against 31).
+static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G, bool rows_kernel = false) {
     const int slices = Cd / GMM_CDS;
     const int64_t want = 2048;
     int r = 64, g = 1;
     if (ceil_div(n_dst, 64) * slices < want) {
-        if (K >= 27) g = 9;
+        if (rows_kernel) {
+            r = 32;
+            const int64_t waves = ceil_div(n_dst, 32) * slices;
+            if (waves < want && K >= 27) g = waves * 3 >= want ? 3 : 9;
+        } else if (K >= 27) g = 9;
         else r = 32;
     }
     if (const char* e = getenv("U3D_GMM_R")) r = atoi(e) == 32 ? 32 : 64;      // experiment knobs (tools/prof_gmm.py)
@@ -1009,13 +1016,19 @@ using namespace u3d;
 
 extern "C" {
 
-int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups) {
+static int spconv_plan_impl(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups, bool rows_kernel) {
     if (Cs % 16 || Cd % 32 || Cs <= 0 || Cd <= 0 || Cd > 256 || Cs > 256 || K <= 0 || K > 32 || n_dst <= 0 || !tile_rows || !k_groups)
         return U3D_EUNSUPPORTED;
     const int cs16 = Cs / 16;
     if (!(cs16 == 1 || cs16 == 2 || cs16 == 4 || cs16 == 6 || cs16 == 8 || cs16 == 10 || cs16 == 12 || cs16 == 16)) return U3D_EUNSUPPORTED;
-    plan_gmm(Cs, Cd, K, n_dst, tile_rows, k_groups);
+    plan_gmm(Cs, Cd, K, n_dst, tile_rows, k_groups, rows_kernel);
     return U3D_OK;
+}
+int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups) {
+    return spconv_plan_impl(Cs, Cd, K, n_dst, tile_rows, k_groups, false);
+}
+int u3d_spconv_plan_bf16a(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups) {
+    return spconv_plan_impl(Cs, Cd, K, n_dst, tile_rows, k_groups, true);
 }
 
 static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows, const int32_t* gather, const int32_t* scatter,
@@ -1031,7 +1044,7 @@ static int spconv_gmm_impl(const float* src, int64_t n_src, const float* w_rows,
         return U3D_EUNSUPPORTED;
     }
     int R = 0, G = 0;
-    if (u3d_spconv_plan(Cs, Cd, K, n_dst, &R, &G) != U3D_OK || R != tile_rows || G != k_groups || (G > 1 && !ws)) {
+    if (spconv_plan_impl(Cs, Cd, K, n_dst, &R, &G, pr == 3) != U3D_OK || R != tile_rows || G != k_groups || (G > 1 && !ws)) {
         set_error("spconv_gmm: unsupported Cs=%d Cd=%d or plan mismatch (tile %d/%d groups %d/%d)", Cs, Cd, tile_rows, R, k_groups, G);
         return U3D_EUNSUPPORTED;
     }

@@ -194,11 +194,12 @@ def build_down_rulebook(coords: torch.Tensor, B: int, shape):
 # ----------------------------------------------------------------------------------------
 # convolution (forward / dgrad / wgrad through the C ABI)
 # ----------------------------------------------------------------------------------------
-def _plan(Cs, Cd, K, n_dst):
-    """(rows per wave-tile, offset groups) the kernel wants for this shape."""
+def _plan(Cs, Cd, K, n_dst, rows_kernel=False):
+    """(rows per wave-tile, offset groups) the kernel wants for this shape (``rows_kernel``: u3d_spconv_gmm_bf16a's own plan)."""
     import ctypes
     R, G = ctypes.c_int(0), ctypes.c_int(0)
-    if n_dst <= 0 or L.lib().u3d_spconv_plan(Cs, Cd, K, n_dst, ctypes.byref(R), ctypes.byref(G)) != 0:
+    fn = L.lib().u3d_spconv_plan_bf16a if rows_kernel else L.lib().u3d_spconv_plan
+    if n_dst <= 0 or fn(Cs, Cd, K, n_dst, ctypes.byref(R), ctypes.byref(G)) != 0:
         raise L.U3DError(f'sparse conv: channel combination {Cs}->{Cd} unsupported by the gfx950 kernels')
     return R.value, G.value
 
@@ -329,7 +330,7 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
     Cs, Cd = src.shape[1], (weight.shape[2] if transposed else weight.shape[0])
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     if n_dst:
-        R, G = _plan(Cs, Cd, rb.K, n_dst)
+        R, G = _plan(Cs, Cd, rb.K, n_dst, src_rows_bf16 is not None and int(bf) == P.FMT_BF16 and Cs % 32 == 0)
         if _PROFILE_FLOPS:      # N(Cs+Cd)s + 2P*idx + K*Cs*Cd*s  (s = 4 B, idx = 4 B)
             account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)
         ws = torch.empty(G * n_dst * Cd, dtype=torch.float32, device=src.device) if G > 1 else None

@@ -504,19 +504,19 @@ __global__ __launch_bounds__(256) void gmm_reduce_k(const float* __restrict__ pa
 // (fewer than 2048 wave tiles) splits its 27 offsets over NINE groups instead of going to 32-row tiles and three groups
 // (level 3, 192 -> 96 channels: 126 us against 161; level 4, 256 -> 128: 69 against 80); strided / inverse convolutions
 // (8 offsets, no groups) keep 32-row tiles there for the parallelism.
-// The bf16-row kernel (u3d_spconv_gmm_bf16a: light items, four workgroups per CU) wants the opposite at the small levels: 32-row
-// tiles, and offset groups only as far as it takes to reach ~2048 wave tiles (same sweep on that kernel,
+// The bf16-row kernel (u3d_spconv_gmm_bf16a: light items, occupancy bound by the accumulator tile) wants the opposite: 32-row tiles,
+// and offset groups only as far as it takes to reach ~2048 wave tiles (same sweep on that kernel,
 // profiles/round4_gmm_plan_sweep_bf16rows.txt: level 3, 96 -> 96: 35 us against 42; level 4, 128 -> 128: 25 against 31).
 static void plan_gmm(int Cs, int Cd, int K, int64_t n_dst, int* R, int* G, bool rows_kernel = false) {
     const int slices = Cd / GMM_CDS;
     const int64_t want = 2048;
     int r = 64, g = 1;
-    if (ceil_div(n_dst, 64) * slices < want) {
-        if (rows_kernel) {
-            r = 32;
-            const int64_t waves = ceil_div(n_dst, 32) * slices;
-            if (waves < want && K >= 27) g = waves * 3 >= want ? 3 : 9;
-        } else if (K >= 27) g = 9;
+    if (rows_kernel) {            // 32-row tiles at EVERY level (level 1, 32 -> 32: 61 us against 67; level 2, 64 -> 64: 54 against 64): 21 KB of LDS
+        r = 32;                   // per workgroup instead of 37, seven workgroups per CU
+        const int64_t waves = ceil_div(n_dst, 32) * slices;
+        if (waves < want && K >= 27) g = waves * 3 >= want ? 3 : 9;
+    } else if (ceil_div(n_dst, 64) * slices < want) {
+        if (K >= 27) g = 9;
         else r = 32;
     }
     if (const char* e = getenv("U3D_GMM_R")) r = atoi(e) == 32 ? 32 : 64;      // experiment knobs (tools/prof_gmm.py)

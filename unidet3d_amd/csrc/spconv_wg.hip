@@ -39,7 +39,7 @@ constexpr int wg_acc_floats(int r) { return (4 * r + 4) * 32; }
 constexpr int wg_stage_floats(int pr) { return pr == 3 ? 0 : 16 * 8 * 4; }      // bf16 rows arrive as MFMA fragments: no staging image
 constexpr int wg_slot_bytes(int cs16, int pr) { return (cs16 / 2) * (pr == 2 ? 6144 : 2048); }
 constexpr int wg_fixed_bytes(int r, int pr) { return (wg_acc_floats(r) + 4 * wg_stage_floats(pr)) * 4; }
-constexpr int wg_per_cu(int bytes) { return 160 * 1024 / bytes > 4 ? 4 : 160 * 1024 / bytes; }      // workgroups per CU by LDS (beyond 4 nothing is gained)
+constexpr int wg_per_cu(int bytes) { return 160 * 1024 / bytes > 8 ? 8 : 160 * 1024 / bytes; }      // workgroups per CU by LDS (8 x 4 waves: the CU's wave slots)
 // two weight slots (one barrier per offset) unless the second slot costs a workgroup per CU (then one slot, two barriers)
 constexpr int wg_nslot(int cs16, int r, int pr) {
     return wg_per_cu(wg_fixed_bytes(r, pr) + 2 * wg_slot_bytes(cs16, pr)) >= wg_per_cu(wg_fixed_bytes(r, pr) + wg_slot_bytes(cs16, pr)) ? 2 : 1;

@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 108
+#define U3D_ABI_VERSION 109
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -440,6 +440,11 @@ int64_t u3d_criterion_ws_bytes(int L, int B, int64_t n_tot, int64_t G, int64_t P
  * backward: draw [M][8] from dbox [M][6] (the angle columns receive 0). */
 int u3d_box_decode_fwd(const float* raw, const float* centers, int64_t M, float* box, u3d_stream_t stream);
 int u3d_box_decode_bwd(const float* raw, const float* dbox, int64_t M, float* draw, u3d_stream_t stream);
+/* the same for a head with a heading / a mixed batch (encoder.py:241-283 incl. the rotated branch): box [M][7] = (centre, w, l, size_z,
+ * alpha) on rows with a heading -- yaw_rows[i] != 0, or every row when yaw_rows == NULL -- and (centre, size, 0) on the others, whose
+ * raw heading columns get a zero gradient (the reference never evaluates them for scenes of yaw-free datasets, encoder.py:186-199). */
+int u3d_box_decode7_fwd(const float* raw, const float* centers, const uint8_t* yaw_rows, int64_t M, float* box, u3d_stream_t stream);
+int u3d_box_decode7_bwd(const float* raw, const float* dbox, const uint8_t* yaw_rows, int64_t M, float* draw, u3d_stream_t stream);
 
 #ifdef __cplusplus
 }

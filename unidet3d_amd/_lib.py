@@ -85,6 +85,8 @@ PROTOTYPES = {
     'u3d_criterion_packed': (_i32, [_vp] * 11 + [_i32, _i32, _i64, _i32, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_box_decode_fwd': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'u3d_box_decode_bwd': (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    'u3d_box_decode7_fwd': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    'u3d_box_decode7_bwd': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     'u3d_criterion_ws_bytes': (_i64, [_i32, _i32, _i64, _i64, _i64]),
     'u3d_gemm_nt': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
     'u3d_linear_act': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _f64, _vp]),
@@ -104,7 +106,7 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 108         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 109         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

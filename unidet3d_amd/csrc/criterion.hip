@@ -531,6 +531,69 @@ __global__ __launch_bounds__(256) void box_decode_bwd_k(const float* __restrict_
     reinterpret_cast<float4*>(draw + i * 8)[1] = make_float4(g[4], g[5], g[6], g[7]);
 }
 
+// ---- box decode of a head WITH a heading (7-dof), or of a mixed batch: PredBBox's exp + _bbox_pred_to_bbox incl. its rotated branch
+// (unidet3d/encoder.py:99-111, :241-283) in one pass each way.  raw [M][8], centres [M][3], yaw [M] bytes (nullable = every row has a
+// heading) -> box [M][7]:
+//   rows with a heading:  (centre, w = S / (1 + q), l = w q, size_z, alpha)   S = e0 + e1 + e2 + e3, q = exp(sqrt(r6^2 + r7^2)),
+//                                                                            alpha = atan2(r6, r7) / 2
+//   rows without (scenes of the yaw-free datasets of a mixed batch, whose heading columns the reference never evaluates,
+//   encoder.py:186-199):  (centre, size_x, size_y, size_z, 0); their raw heading columns receive a zero gradient.
+// Replaces ~25 element-wise launches forward and ~50 backward per decoder head of the joint config (7 heads per step).
+__global__ __launch_bounds__(256) void box_decode7_fwd_k(const float* __restrict__ raw, const float* __restrict__ cen, const uint8_t* __restrict__ yaw,
+                                                         int64_t M, float* __restrict__ box) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float4 r0 = reinterpret_cast<const float4*>(raw + i * 8)[0], r1 = reinterpret_cast<const float4*>(raw + i * 8)[1];
+    const float e[6] = {expf(r0.x), expf(r0.y), expf(r0.z), expf(r0.w), expf(r1.x), expf(r1.y)};
+    float o[7];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[a] = cen[i * 3 + a] + (e[2 * a + 1] - e[2 * a]) / 2;
+        o[3 + a] = e[2 * a] + e[2 * a + 1];
+    }
+    o[6] = 0.f;
+    if (!yaw || yaw[i]) {
+        const float S = e[0] + e[1] + e[2] + e[3];
+        const float q = expf(sqrtf(r1.z * r1.z + r1.w * r1.w));
+        o[3] = S / (1.f + q);
+        o[4] = S / (1.f + q) * q;
+        o[6] = 0.5f * atan2f(r1.z, r1.w);
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) box[i * 7 + c] = o[c];
+}
+__global__ __launch_bounds__(256) void box_decode7_bwd_k(const float* __restrict__ raw, const float* __restrict__ dbox, const uint8_t* __restrict__ yaw,
+                                                         int64_t M, float* __restrict__ draw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float4 r0 = reinterpret_cast<const float4*>(raw + i * 8)[0], r1 = reinterpret_cast<const float4*>(raw + i * 8)[1];
+    const float e[6] = {expf(r0.x), expf(r0.y), expf(r0.z), expf(r0.w), expf(r1.x), expf(r1.y)};
+    float d[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) d[c] = dbox[i * 7 + c];
+    float de[6], g6 = 0.f, g7 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { de[2 * a] = -d[a] / 2; de[2 * a + 1] = d[a] / 2; }      // centre_a = c_a + (e_{2a+1} - e_{2a}) / 2
+    de[4] += d[5]; de[5] += d[5];                                                          // size_z = e4 + e5
+    if (!yaw || yaw[i]) {
+        const float a6 = r1.z, a7 = r1.w, rho2 = a6 * a6 + a7 * a7, rho = sqrtf(rho2);
+        const float q = expf(rho), S = e[0] + e[1] + e[2] + e[3], inv = 1.f / (1.f + q);
+        const float dS = (d[3] + d[4] * q) * inv;                  // w = S / (1 + q), l = S q / (1 + q)
+        const float dq = (d[4] - d[3]) * S * inv * inv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) de[c] += dS;
+        if (rho2 > 0.f) {                                          // (rho = 0: torch's sqrt / atan2 backward is 0 * inf there; no gradient is the usable answer)
+            const float drho = dq * q;
+            g6 = drho * a6 / rho + 0.5f * d[6] * a7 / rho2;        // d atan2(y = a6, x = a7): dy = x / (x^2 + y^2), dx = -y / (x^2 + y^2)
+            g7 = drho * a7 / rho - 0.5f * d[6] * a6 / rho2;
+        }
+    } else {
+        de[0] += d[3]; de[1] += d[3]; de[2] += d[4]; de[3] += d[4];          // size_x = e0 + e1, size_y = e2 + e3
+    }
+    reinterpret_cast<float4*>(draw + i * 8)[0] = make_float4(e[0] * de[0], e[1] * de[1], e[2] * de[2], e[3] * de[3]);
+    reinterpret_cast<float4*>(draw + i * 8)[1] = make_float4(e[4] * de[4], e[5] * de[5], g6, g7);
+}
+
 }  // namespace u3d
 
 using namespace u3d;
@@ -549,6 +612,20 @@ int u3d_box_decode_bwd(const float* raw, const float* dbox, int64_t M, float* dr
     if (M == 0) return U3D_OK;
     hipLaunchKernelGGL(box_decode_bwd_k, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, raw, dbox, M, draw);
     return check_launch("box_decode_bwd");
+}
+
+int u3d_box_decode7_fwd(const float* raw, const float* centers, const uint8_t* yaw_rows, int64_t M, float* box, u3d_stream_t stream) {
+    if (!raw || !centers || !box || M < 0) return U3D_EINVAL;
+    if (M == 0) return U3D_OK;
+    hipLaunchKernelGGL(box_decode7_fwd_k, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, raw, centers, yaw_rows, M, box);
+    return check_launch("box_decode7_fwd");
+}
+
+int u3d_box_decode7_bwd(const float* raw, const float* dbox, const uint8_t* yaw_rows, int64_t M, float* draw, u3d_stream_t stream) {
+    if (!raw || !dbox || !draw || M < 0) return U3D_EINVAL;
+    if (M == 0) return U3D_OK;
+    hipLaunchKernelGGL(box_decode7_bwd_k, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, raw, dbox, yaw_rows, M, draw);
+    return check_launch("box_decode7_bwd");
 }
 
 static inline int64_t al64(int64_t x) { return (x + 63) & ~(int64_t)63; }

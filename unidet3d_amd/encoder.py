@@ -153,6 +153,27 @@ class _BoxDecodeFn(torch.autograd.Function):
         return draw, None
 
 
+class _BoxDecode7Fn(torch.autograd.Function):
+    """PredBBox's exp + _bbox_pred_to_bbox of a head with a heading -- or of a mixed batch: ``yaw_rows`` (uint8 [M] or None = all) marks
+    the rows that have one, the others come out as (centre, size, 0) -- as one kernel each way (u3d_box_decode7_*)."""
+
+    @staticmethod
+    def forward(ctx, raw, centers, yaw_rows):
+        raw, centers = raw.contiguous(), centers.contiguous()
+        box = torch.empty(raw.shape[0], 7, dtype=torch.float32, device=raw.device)
+        L.call('u3d_box_decode7_fwd', L.ptr(raw), L.ptr(centers), L.ptr(yaw_rows), raw.shape[0], L.ptr(box), L.stream())
+        ctx.save_for_backward(raw)
+        ctx.yaw_rows = yaw_rows
+        return box
+
+    @staticmethod
+    def backward(ctx, dbox):
+        raw, = ctx.saved_tensors
+        draw = torch.empty_like(raw)
+        L.call('u3d_box_decode7_bwd', L.ptr(raw), L.ptr(dbox.contiguous()), L.ptr(ctx.yaw_rows), raw.shape[0], L.ptr(draw), L.stream())
+        return draw, None, None
+
+
 def _bbox_pred_to_bbox(points, bbox_pred):    # encoder.py:241-283
     if bbox_pred.shape[0] == 0:
         return bbox_pred
@@ -203,43 +224,34 @@ class UniDet3DEncoder(nn.Module):
         w1, b1, w2, b2 = self.outs_cls[0].weight, self.outs_cls[0].bias, self.outs_cls[2].weight, self.outs_cls[2].bias
         single = len(set(datasets_names)) == 1
         yaw_free = single and not self.angles[self.datasets.index(datasets_names[0])]
-        box_all = None if yaw_free else self.out_bboxes.decode(box_raw)
         if single:
             # the dataset's class columns (encoder.py:192-194) are selected as ROWS of the [n_cls, d] output weight: the packed
             # [sum n_i, n_cls] logit matrix is never gathered (nor scattered back in backward)
             idx = self.datasets.index(datasets_names[0])
             cidx = self._cidx(idx, feats.device)
             cls_p = mlp(nq, w1, b1, w2[cidx], b2[cidx], 'relu')
-            box_p = _BoxDecodeFn.apply(box_raw, centers_packed) if yaw_free else _bbox_pred_to_bbox(centers_packed, box_all)
+            box_p = _BoxDecodeFn.apply(box_raw, centers_packed) if yaw_free else _BoxDecode7Fn.apply(box_raw, centers_packed, None)
             return list(cls_p.split(sizes)), list(box_p.split(sizes)), (cls_p, box_p)
-        # mixed batch (joint config): full-width logits once; both box parametrisations once on the packed matrix -- the per-scene
-        # outputs of the reference's dict contract are row slices of them (the reference decodes scene by scene, :186-199)
+        # mixed batch (joint config): full-width logits once, and ONE decode of the packed box matrix (u3d_box_decode7_*): rows of scenes
+        # whose dataset has a heading come out 7-dof, the others as (centre, size, 0) -- the reference never evaluates the heading
+        # columns of a yaw-free dataset's scenes (encoder.py:186-199), and neither does the kernel (zero gradient there) -- the
+        # per-scene outputs of the reference's dict contract are row / column slices of it (the reference decodes scene by scene)
         cls_all = mlp(nq, w1, b1, w2, b2, 'relu')
-        b6 = _bbox_pred_to_bbox(centers_packed, box_all[:, :6])
         idxs = [self.datasets.index(name) for name in datasets_names]
         any_yaw = any(self.angles[i] for i in idxs)
-        b7 = yaw_rows = None
         if any_yaw:
-            # The reference never evaluates the heading columns of a yaw-free dataset's scenes (encoder.py:186-199).  The packed decode
-            # runs on every row, so those rows get a harmless heading (0, 1) BEFORE exp(sqrt(a^2 + b^2)) / atan2: with their own
-            # values -- a = b = 0 exactly, or an overflowing exp -- the zero gradient torch.where sends back would meet inf / nan
-            # factors in sqrt's and exp's backward (0 * inf = nan in out_bboxes.linear's gradient).  Heading rows are untouched.
-            flags = L.h2d([bool(self.angles[i]) for i in idxs], torch.bool, feats.device)
-            yaw_rows = torch.repeat_interleave(flags, L.h2d(list(sizes), torch.int64, feats.device), output_size=int(sum(sizes)))[:, None]
-            safe = torch.where(yaw_rows, box_all[:, 6:8], box_all.new_tensor([0.0, 1.0]))
-            b7 = _bbox_pred_to_bbox(centers_packed, torch.cat((box_all[:, :6], safe), dim=1))
+            flags = L.h2d([int(bool(self.angles[i])) for i in idxs], torch.uint8, feats.device)
+            yaw_rows = torch.repeat_interleave(flags, L.h2d(list(sizes), torch.int64, feats.device), output_size=int(sum(sizes)))
+            box_p = _BoxDecode7Fn.apply(box_raw, centers_packed, yaw_rows)          # [M, 7] for the criterion kernel
+        else:
+            box_p = _BoxDecodeFn.apply(box_raw, centers_packed)                     # [M, 6]
         cls_preds, boxes = [], []
-        for c, p6, p7, raw, idx in zip(cls_all.split(sizes), b6.split(sizes), b7.split(sizes) if any_yaw else [None] * len(sizes),
-                                       box_all.split(sizes), idxs):
+        for c, pb, raw, idx in zip(cls_all.split(sizes), box_p.split(sizes), box_raw.split(sizes), idxs):
             cls_preds.append(c[:, self._cidx(idx, feats.device)])
             if raw.shape[0] == 0:       # the reference returns an EMPTY scene's 8 (or 6) raw columns undecoded (encoder.py:253-254)
                 boxes.append(raw if self.angles[idx] else raw[:, :6])
             else:
-                boxes.append(p7 if self.angles[idx] else p6)
-        if any_yaw:      # [M, 7] for the criterion kernel: heading rows from b7, the others from b6 with a zero heading column
-            box_p = torch.where(yaw_rows, b7, torch.nn.functional.pad(b6, (0, 1)))
-        else:
-            box_p = b6
+                boxes.append(pb if self.angles[idx] or not any_yaw else pb[:, :6])
         return cls_preds, boxes, (cls_all, box_p)
 
     def forward(self, x: List[torch.Tensor], sp_centers: List[torch.Tensor], datasets_names: List[str]):

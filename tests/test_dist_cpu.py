@@ -198,3 +198,48 @@ def test_bucket_order_is_rank_independent_world4_with_empty_gt_and_unused_parame
         want = g if want is None else want + g
     assert np.allclose(res[0][1], (want / world).numpy(), atol=1e-6)
     assert float(np.abs(res[0][1]).max()) > 0
+
+
+def _forced_worker(port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    from unidet3d_amd import dist as D
+    assert D.init_from_env('gloo') == (0, 1, 0) and not dist.is_initialized()        # one rank: no group unless forced
+    D.init_from_env('gloo', force=True)
+    assert dist.is_initialized() and dist.get_world_size() == 1
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **kw: (calls.append((t.dtype, kw.get('group') is not None)), real(t, *a, **kw))[1]
+    torch.manual_seed(3)
+    base = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    x, y = torch.randn(8, 6), torch.randn(8, 3)
+    out = {}
+    for forced in (False, True):
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))      # (the bucket's hooks stay on the parameters)
+        net.load_state_dict(base.state_dict())
+        D.force_collectives(forced)
+        assert D.collectives_on() == forced
+        n0 = len(calls)
+        b = D.FlatGradBucket(net.parameters(), attach=False).enable_overlap(bucket_bytes=64)
+        assert (b.group is not None) == forced                                        # the buckets' own communicator exists only when collectives are on
+        b.clear_grads()
+        ((net(x) - y) ** 2).mean().backward()
+        b.finish()
+        out[forced] = (b.flat.clone(), len(calls) - n0)
+    D.force_collectives(False)
+    dist.all_reduce = real
+    q.put((out[False][1], out[True][1], bool(torch.equal(out[False][0], out[True][0])), all(g for _, g in calls)))
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_on_a_one_rank_group_are_the_identity():
+    """dist.force_collectives(): the bring-up mode tests/test_gpu_dist.py uses to drive the RCCL call sequence on one GPU -- here on
+    gloo: without it a one-rank group issues no collective, with it every bucket goes out (on the buckets' own communicator) and the
+    reduced gradients are bit-identical."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    n_plain, n_forced, equal, own_group = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert n_plain == 0 and n_forced == 3 and equal and own_group

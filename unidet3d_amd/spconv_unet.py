@@ -107,11 +107,13 @@ class SpConvUNet(nn.Module):
     def prepare_geometry(self, x: SparseConvTensor):
         """Build every level's coordinates and rulebooks before any feature kernel is queued: the voxel
         counts of the coarser levels are host read-backs, and taking them here (integer kernels only in
-        flight) keeps them from draining a pipeline full of convolutions later."""
-        [m for m in self.blocks[0].conv_branch if isinstance(m, SubMConv3d) and m.kernel_size == 3][0].geometry(x)
+        flight) keeps them from draining a pipeline full of convolutions later.  The per-tile pair ranges the convolution kernels
+        walk (``Rulebook.tile_starts``) are built here too, for the tile heights the previous step used."""
+        [m for m in self.blocks[0].conv_branch if isinstance(m, SubMConv3d) and m.kernel_size == 3][0].geometry(x).precompute_tiles()
         if len(self.num_planes) > 1:
             down = [m for m in self.conv if isinstance(m, SparseConv3d)][0]
-            oc, oshape, ix2, _ = down.geometry(x)
+            oc, oshape, ix2, rb_down = down.geometry(x)
+            rb_down.precompute_tiles()
             self.u.prepare_geometry(SparseConvTensor(None, oc, oshape, x.batch_size, x.indice_dict, ix2))
 
     def forward(self, input: SparseConvTensor, previous_outputs=None):

@@ -101,6 +101,7 @@ def _rccl_worker(port, out_path):
         calls.append((t.dtype, t.numel(), kw.get('group') is not None, t.is_cuda))
         return real_all_reduce(t, *a, **kw)
 
+    import copy
     inputs, samples = make_batch_inputs([make_scene(70, n_points=8000), make_scene(71, n_points=8000)], 'cuda:0')
     res = {}
     for forced in (True, False):
@@ -126,6 +127,21 @@ def _rccl_worker(port, out_path):
         else:
             assert len(calls) == len(res['calls']), 'the non-distributed step issued a collective'
     D.force_collectives(False)
+    # the same pair in bf16-operand mode: the exchange path's separate statistics / apply launches must write the bf16 shadows the
+    # sparse convolutions gather (precision.bf16_rows) exactly like the fused call does
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    bres = {}
+    for forced in (True, False):
+        D.force_collectives(forced)
+        model = _build()
+        sparse.SHADOW_STATS.update(hit=0, miss=0)
+        with P.operands('bf16'):
+            loss = model.loss(inputs, copy.deepcopy(samples))['det_loss']
+            loss.backward()
+        torch.cuda.synchronize()
+        bres[forced] = (loss.detach().clone(), torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]), dict(sparse.SHADOW_STATS))
+    D.force_collectives(False)
     f64 = [c for c in res['calls'] if c[0] == torch.float64]
     f32 = [c for c in res['calls'] if c[0] == torch.float32]
     ok = dict(n_f64=len(f64), n_f32=len(f32), n_buckets=res[True]['n_buckets'],
@@ -133,7 +149,10 @@ def _rccl_worker(port, out_path):
               flat_equal=bool(torch.equal(res[True]['flat'], res[False]['flat'])), loss_equal=bool(torch.equal(res[True]['loss'], res[False]['loss'])),
               stats_equal=bool(torch.equal(res[True]['rm'], res[False]['rm']) and torch.equal(res[True]['rv'], res[False]['rv'])),
               max_rel=float((res[True]['flat'] - res[False]['flat']).abs().max() / res[False]['flat'].abs().max()),
-              stats_rel=float((res[True]['rv'] - res[False]['rv']).abs().max() / res[False]['rv'].abs().max()))
+              stats_rel=float((res[True]['rv'] - res[False]['rv']).abs().max() / res[False]['rv'].abs().max()),
+              bf16_loss_rel=float((bres[True][0] - bres[False][0]).abs() / bres[False][0].abs()),
+              bf16_grad_rel=float((bres[True][1] - bres[False][1]).abs().max() / bres[False][1].abs().max()),
+              bf16_shadow_hits=int(bres[True][2]['hit']), bf16_shadow_hits_plain=int(bres[False][2]['hit']))
     torch.save(ok, out_path)
     dist.barrier()
     dist.destroy_process_group()
@@ -159,6 +178,9 @@ def test_rccl_one_rank_runs_the_whole_collective_sequence():
     # measured on MI355X / RCCL 2.26.6: loss identical, gradients 4.3e-6 apart (max-norm relative): the exchange path runs batch-norm
     # statistics, finalize and apply as separate launches (fp64 sums handed to the collective), the non-distributed path the fused call
     assert ok['loss_equal'] and ok['max_rel'] < 2e-5 and ok['stats_rel'] < 1e-6, ok
+    # bf16 operands: the shadows are written and used on the exchange path as on the fused one (same hit count), results agree to the
+    # rounding of the separate launches seen through bf16 operands
+    assert ok['bf16_shadow_hits'] == ok['bf16_shadow_hits_plain'] >= 80 and ok['bf16_loss_rel'] < 1e-3 and ok['bf16_grad_rel'] < 5e-2, ok
 
 
 def test_bench_gpus_2_launches_itself():

@@ -392,3 +392,37 @@ def test_training_step_bf16_operands_stays_close_to_fp32():
     print('bf16 step vs fp32 step:', rec)
     assert rec['loss_rel'] < 0.3          # plumbing guard only (a kernel family left in the wrong mode or a broken operand pack shows up
                                           # as O(1)); the measured distances are in the log, the arithmetic is pinned kernel by kernel above
+
+
+def test_eval_mode_forward_with_bf16_rows_equals_the_fp32_row_path():
+    """Inference in bf16-operand mode (eval-mode batch norm: running statistics, `u3d_bn_apply` alone): the shadows are written by that
+    path too, the convolutions gather them, and the decoder outputs equal those of the fp32-row kernels bit for bit (same plan pinned,
+    as in the training-step test)."""
+    import copy
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _detw import fill_state_dict
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    from unidet3d_amd.config import build_model, scannet_model_cfg
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = scannet_model_cfg(voxel_size=0.05)
+    cfg['decoder']['num_layers'] = 2
+    model = fill_state_dict(build_model(cfg), tag0=3300, scale=0.06).to(DEV).eval()
+    inputs, samples = make_batch_inputs([make_scene(150, n_points=10_000)], DEV)
+    env = {k: os.environ.get(k) for k in ('U3D_GMM_R', 'U3D_GMM_G')}
+    os.environ['U3D_GMM_R'], os.environ['U3D_GMM_G'] = '32', '3'
+    out = {}
+    try:
+        for rows in (False, True):
+            sparse.SHADOW_STATS.update(hit=0, miss=0)
+            with torch.no_grad(), P.operands('bf16'), P.bf16_rows_mode(rows):
+                o = model.predict_raw(inputs, copy.deepcopy(samples))
+            out[rows] = (o['cls_preds'][0].clone(), o['bboxes'][0].clone(), dict(sparse.SHADOW_STATS))
+    finally:
+        for k, v in env.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    assert out[True][2]['hit'] >= 40 and out[True][2]['miss'] == 0 and out[False][2]['hit'] == 0, out[True][2]

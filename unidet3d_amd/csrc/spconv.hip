@@ -843,7 +843,10 @@ static int plan_wgrad_rows(int K, int64_t n_rows, int Cs, int Cd) {
     static const int64_t cap = [] { const char* e = getenv("U3D_WGRAD_TILES"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)256; }();
     static const int64_t budget = [] { const char* e = getenv("U3D_WGRAD_PARTIAL_MB"); const int64_t v = e ? atoll(e) : 0; return (v > 0 ? v : (int64_t)64) << 20; }();
     int64_t nt = budget / ((int64_t)K * Cs * Cd * 4);
-    nt = nt > cap ? cap : (nt < 1 ? 1 : nt);      // 256 vs 512 tiles: the fixed-order reduce reads half as much, wgrad itself is unchanged
+    // 256 tiles, more for levels beyond ~330 k rows so that a tile stays near 1300 rows (round 4, 16 scenes = 699 k rows at level 1:
+    // 512 tiles 283 us against 313 for the fp32-row walk, 116 against 125 for the bf16-row kernel; level 2 prefers its 151)
+    const int64_t cap_n = cap > n_rows / 1300 ? cap : n_rows / 1300;
+    nt = nt > cap_n ? cap_n : (nt < 1 ? 1 : nt);
     const int64_t by_len = ceil_div(n_rows, 64);
     if (nt > by_len) nt = by_len;
     return (int)ceil_div(n_rows, nt);

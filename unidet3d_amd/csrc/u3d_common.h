@@ -79,7 +79,10 @@ using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 //   * truncating h as well (11 instructions): remainders twice as large and all of the product's sign -- dropped terms up to
 //     2^-20, biased towards zero; 2.5x larger backbone-gradient errors end to end (tests/test_gpu_full_size.py cfg4 over 1e-3);
 //   * v_cvt_pk_bf16_f32 for both levels (round to nearest even, 11 instructions but slower ones), or add-half on both levels
-//     (15): attention +22 %, GEMM +10 % kernel time for errors this variant already brings to the fp32 level.
+//     (15): attention +22 %, GEMM +10 % kernel time for errors this variant already brings to the fp32 level.  Round 4 retried
+//     the conversion form at its minimum -- v_cvt_pk_bf16_f32 through asm (no re-conversion per use) and ONE v_pk_add_f32 per
+//     level: 9 instructions per pair, 14 % faster than this one in an isolated dependent loop (tools/split_bench.hip), but
+//     attention +5 %, GEMM +1.5 %, convolution +-0 in the bench step: the conversion is not a full-rate instruction.
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned ah = (__builtin_bit_cast(unsigned, a) + 0x8000u) & 0xffff0000u, bh = (__builtin_bit_cast(unsigned, b) + 0x8000u) & 0xffff0000u;
     const float a1 = a - __builtin_bit_cast(float, ah), b1 = b - __builtin_bit_cast(float, bh);

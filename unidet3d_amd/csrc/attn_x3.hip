@@ -9,18 +9,14 @@
 //   S^T (16 keys x 16 queries) = K_tile . Q^T       A = K rows, natural [key][dim] planes in LDS (one 16-byte read per plane),
 //                                                   B = own Q rows, split once into registers
 //   O (16 queries x 16 dims) += P . V               A = two C fragments (keys {4g..4g+3} of two 16-key tiles), split in registers,
-//                                                   B = V in the PAIR layout: the staging thread loads the same four dims of
-//       two consecutive keys and split3_pair() packs them into one dword per plane; the LDS tile is [dim][key-pair slot] dwords
-//       with the slots ordered so that the fragment k = 8g + e <-> key 32t + 16 (e >> 2) + 4g + (e & 3) is FOUR CONSECUTIVE
-//       dwords: one ds_read_b128 per plane (the bf16 kernel needs eight 2-byte reads; with three planes that would put the LDS
-//       pipe level with the matrix pipe).  Slots are XOR-swizzled by the dim group so that the dword stores of the staging
-//       threads (8 threads x the same slot) spread over the banks; 40-dword columns keep the 16-byte reads conflict-free.
-//       The dK / dV kernel, which stages two tensors both ways, uses 32-dword columns (chunk index XORed with (dim >> 1) & 7:
-//       every 16-lane service group of ds_read_b128 still covers the 64 banks once, stores 2-way at most): 6 KB less LDS per
-//       tensor and a loop that keeps 32 instead of 64 queries' P / dS live let THREE of its workgroups share a CU (166 VGPRs,
-//       49.7 KB; round 3: 208 VGPRs, 55.8 KB, two): attention backward 5.17 -> 4.92 ms / step.  At unchanged occupancy the dense
-//       layout measured 7 % slower in the forward kernel and no faster in dQ, which keep the padded one.
-// The backward kernels use the same two layouts in both orientations; tiles that are read both ways are staged in both.
+//                                                   B = a COLUMN of the natural V planes: the fragment k = 8g + e <-> key
+//       32t + 16 (e >> 2) + 4g + (e & 3) of dim i is two ds_read_b64_tr_b16 per plane -- a 16-lane group hands in the [4 keys][16 dims]
+//       block of its lane group (lane t the 8 bytes at key t >> 2, dims 4 (t & 3) ..) and lane t receives dim t over the four keys.
+//       (Rounds 2-3 staged such tensors a second time in a "pair" layout -- two keys per dword, [dim][key-pair slot] -- read with
+//       ds_read_b128; the transpose read makes that copy unnecessary: half the LDS per staged tensor, no second packing and no
+//       dword stores in the staging threads.  Rows 4g + j and 4 (g + 1) + j of a plane differ by 2 in the chunk XOR, so the 32
+//       lanes of a read cover 256 consecutive-bank bytes: conflict-free.)
+// The backward kernels read their staged tiles in both orientations the same way: rows with ds_read_b128, columns with transpose reads.
 // The kernels are templates over the number of planes: NP = 3 is the fp32 path above, NP = 1 the bf16-operand form of
 // BASELINE configs[2] (one bf16 value per operand, rounded to nearest even; u3d_attn_varlen_*_bf16 at the end of the file).
 #include "u3d_common.h"
@@ -32,9 +28,6 @@ typedef bf16x8_t bf16x8;
 constexpr float X_LOG2E = 1.44269504088896340736f, X_LN2 = 0.69314718055994530942f;
 constexpr int XLD = 32;                  // halves per row of a natural plane: unpadded, the 16-byte chunk index is XORed with (row >> 1) & 3
                                          // (conflict-free ds_read_b128 for the lane -> (row = lane & 15, chunk = lane >> 4) map)
-constexpr int XPD = 40;                  // dwords per dim (column) of a pair plane: 32 key-pair slots + 8 pad, chunk index XORed with dim >> 2;
-constexpr int XPD_DENSE = 32;            // ... or unpadded, chunk index XORed with (dim >> 1) & 7 (attn_bwd_dkv_x3_k)
-template <int PD> __device__ __forceinline__ int pair_swz(int dim) { return 4 * (PD == XPD_DENSE ? (dim >> 1) & 7 : (dim >> 2) & 7); }
 constexpr int XN = 64 * XLD;             // halves per natural plane
 #define U3D_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -97,8 +90,7 @@ __device__ __forceinline__ void planes_x8(const f32x4& lo, const f32x4& hi, bf16
 
 // Stage 64 rows x 32 floats of `base` (rows >= len are zero, values scaled before the split): thread (p = tid >> 3, c = tid & 7)
 // holds dims 4c .. 4c+3 of rows 2p and 2p+1; load_x3 issues the global loads (one tile ahead of their use: the compute phase of
-// the tile before covers their latency), store_x3 splits and writes.  NAT: natural planes nat[NP][64][XLD] halves; PAIR: pair planes pr[NP][32 dims][XPD]
-// dwords, row pair p = (t, half, g, w) bits 4 | 3 | 2-1 | 0 in slot 16 t + 4 g + 2 half + w, XORed with pair_swz(dim).
+// the tile before covers their latency), store_x3 splits and writes the natural planes nat[NP][64][XLD] halves.
 struct StageRegs { f32x4 a, b; };
 __device__ __forceinline__ StageRegs load_x3(const float* __restrict__ base, int ld, int row0, int len, int tid) {
     const int p = tid >> 3, c = tid & 7;
@@ -110,33 +102,21 @@ __device__ __forceinline__ StageRegs load_x3(const float* __restrict__ base, int
     if (r0 + 1 < len) r.b = *reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + 1) * ld + c * 4);
     return r;
 }
-template <int NP, bool NAT, bool PAIR, int PD = XPD>
-__device__ __forceinline__ void store_x3(StageRegs r, float scale, __bf16* nat, unsigned* pr, int tid) {
+template <int NP>
+__device__ __forceinline__ void store_x3(StageRegs r, float scale, __bf16* nat, int tid) {
     const int p = tid >> 3, c = tid & 7;
     const f32x4 a = r.a * scale, b = r.b * scale;
-    if constexpr (PAIR) {
-        unsigned w[4][NP];
+    unsigned wa[2][NP], wb[2][NP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) planes_pair<NP>(a[j], b[j], w[j]);
-        const int slot = (p & 16) | ((p & 6) << 1) | ((p & 8) >> 2) | (p & 1);
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pr[q * 32 * PD + (4 * c + j) * PD + (slot ^ pair_swz<PD>(4 * c + j))] = w[j][q];
+    for (int j = 0; j < 2; ++j) {
+        planes_pair<NP>(a[2 * j], a[2 * j + 1], wa[j]);
+        planes_pair<NP>(b[2 * j], b[2 * j + 1], wb[j]);
     }
-    if constexpr (NAT) {
-        unsigned wa[2][NP], wb[2][NP];
+    const int off = (((c >> 1) ^ (p & 3)) * 8) + (c & 1) * 4;          // rows 2p and 2p+1 share (row >> 1) & 3 = p & 3
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            planes_pair<NP>(a[2 * j], a[2 * j + 1], wa[j]);
-            planes_pair<NP>(b[2 * j], b[2 * j + 1], wb[j]);
-        }
-        const int off = (((c >> 1) ^ (p & 3)) * 8) + (c & 1) * 4;          // rows 2p and 2p+1 share (row >> 1) & 3 = p & 3
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p) * XLD + off) = make_uint2(wa[0][q], wa[1][q]);
-            *reinterpret_cast<uint2*>(nat + q * XN + (2 * p + 1) * XLD + off) = make_uint2(wb[0][q], wb[1][q]);
-        }
+    for (int q = 0; q < NP; ++q) {
+        *reinterpret_cast<uint2*>(nat + q * XN + (2 * p) * XLD + off) = make_uint2(wa[0][q], wa[1][q]);
+        *reinterpret_cast<uint2*>(nat + q * XN + (2 * p + 1) * XLD + off) = make_uint2(wb[0][q], wb[1][q]);
     }
 }
 
@@ -163,12 +143,21 @@ __device__ __forceinline__ void nat_frag_x3(const __bf16* nat, int kb, int i16, 
     for (int q = 0; q < NP; ++q) out[q] = *reinterpret_cast<const bf16x8*>(nat + q * XN + (kb * 16 + i16) * XLD + ((g ^ ((i16 >> 1) & 3)) * 8));
 }
 
-// pair planes: column (dim) `col`, rows {4g..4g+3} and {16+4g..16+4g+3} of the 32-row block t: slots 16 t + 4 g .. + 3
-template <int NP, int PD = XPD>
-__device__ __forceinline__ void pair_col_frag_x3(const unsigned* pr, int t, int g, int col, bf16x8 (&out)[NP]) {
-    const unsigned* s = pr + col * PD + ((16 * t + 4 * g) ^ pair_swz<PD>(col));
+// natural planes read by COLUMN: dim 16 cb + i16 over rows {4g..4g+3} and {16+4g..16+4g+3} of the 32-row block t (the k order of
+// pair_frag_x3).  ds_read_b64_tr_b16: lane i16 of a 16-lane group passes the address of 4 halves -- row (i16 >> 2) of the group's four,
+// dims 16 cb + 4 (i16 & 3) .. -- and receives dim 16 cb + i16 of the four rows.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+template <int NP>
+__device__ __forceinline__ void tr_col_frag_x3(const __bf16* nat, int t, int g, int i16, int cb, bf16x8 (&out)[NP]) {
+    const int row = 32 * t + 4 * g + (i16 >> 2), pc = i16 & 3;
+    const __bf16* s = nat + row * XLD + (((2 * cb + (pc >> 1)) ^ ((row >> 1) & 3)) * 8) + 4 * (pc & 1);      // row + 16 has the same chunk XOR
 #pragma unroll
-    for (int q = 0; q < NP; ++q) out[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(s + q * 32 * PD));
+    for (int q = 0; q < NP; ++q) {
+        const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(s + q * XN));
+        const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(s + q * XN + 16 * XLD));
+        out[q] = __builtin_bit_cast(bf16x8, s16x8_t{r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]});
+    }
 }
 
 struct AttnWorkX { int b, h, tile; };
@@ -186,7 +175,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale,
                                                      float* __restrict__ out, float* __restrict__ lse, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) __bf16 Kn[NP * XN];
-    __shared__ __attribute__((aligned(16))) unsigned Vp[NP * 32 * XPD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vn[NP * XN];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
     if (b >= B) return;
@@ -205,8 +194,8 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
     StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        store_x3<NP, true, false>(rk, 1.f, Kn, nullptr, tid);
-        store_x3<NP, false, true>(rv, 1.f, nullptr, Vp, tid);
+        store_x3<NP>(rk, 1.f, Kn, tid);
+        store_x3<NP>(rv, 1.f, Vn, tid);
         if (kt + 1 < ntiles) {
             rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
             rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
@@ -264,8 +253,8 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
         for (int t = 0; t < 2; ++t) {
             bf16x8 pa[NP], v0[NP], v1[NP];
             pair_frag_x3(st[2 * t], st[2 * t + 1], pa);
-            pair_col_frag_x3(Vp, t, g, i16, v0);
-            pair_col_frag_x3(Vp, t, g, 16 + i16, v1);
+            tr_col_frag_x3(Vn, t, g, i16, 0, v0);
+            tr_col_frag_x3(Vn, t, g, i16, 1, v1);
             mfma_x3_2b(pa, v0, v1, o[0], o[1], ol[0], ol[1]);
         }
     }
@@ -301,14 +290,13 @@ __global__ __launch_bounds__(256) void attn_delta_x3_k(const float* __restrict__
     delta[(int64_t)h * n + i] = s;
 }
 
-// dQ: one workgroup per 64-query tile, keys streamed.  K is staged in both layouts (natural for S, pairs for dQ += dS . K).
+// dQ: one workgroup per 64-query tile, keys streamed.  K is read by rows for S and by columns for dQ += dS . K.
 template <int NP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                                                         const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
                                                         float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) __bf16 Kn[NP * XN];
     __shared__ __attribute__((aligned(16))) __bf16 Vn[NP * XN];
-    __shared__ __attribute__((aligned(16))) unsigned Kp[NP * 32 * XPD];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
     if (b >= B) return;
@@ -331,8 +319,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        store_x3<NP, true, true>(rk, 1.f, Kn, Kp, tid);
-        store_x3<NP, true, false>(rv, 1.f, Vn, nullptr, tid);
+        store_x3<NP>(rk, 1.f, Kn, tid);
+        store_x3<NP>(rv, 1.f, Vn, tid);
         if (kt + 1 < ntiles) {
             rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
             rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
@@ -358,8 +346,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
         for (int t = 0; t < 2; ++t) {
             bf16x8 da[NP], k0[NP], k1[NP];
             pair_frag_x3(ds[2 * t], ds[2 * t + 1], da);
-            pair_col_frag_x3(Kp, t, g, i16, k0);
-            pair_col_frag_x3(Kp, t, g, 16 + i16, k1);
+            tr_col_frag_x3(Kn, t, g, i16, 0, k0);
+            tr_col_frag_x3(Kn, t, g, i16, 1, k1);
             mfma_x3_2b(da, k0, k1, dq[0], dq[1], dql[0], dql[1]);
         }
     }
@@ -376,15 +364,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     }
 }
 
-// dK, dV: one workgroup per 64-key tile, queries streamed.  Q and dO are staged in both layouts.
+// dK, dV: one workgroup per 64-key tile, queries streamed.  Q and dO are read by rows (S, dP) and by columns (dK, dV).
+// (three workgroups per CU: the compiler settles at 178 VGPRs without the bound and 166, no spills, with it)
 template <int NP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 3 ? 3 : 1))) void attn_bwd_dkv_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                                                          const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
                                                          float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
     __shared__ __attribute__((aligned(16))) __bf16 Qn[NP * XN];
     __shared__ __attribute__((aligned(16))) __bf16 On[NP * XN];
-    __shared__ __attribute__((aligned(16))) unsigned Qp[NP * 32 * XPD_DENSE];
-    __shared__ __attribute__((aligned(16))) unsigned Op[NP * 32 * XPD_DENSE];
     __shared__ float lse_s[64], del_s[64];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
     const int b = wk_.b, h = wk_.h;
@@ -406,8 +393,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
     StageRegs rq = load_x3(base, ld, 0, len, tid), ro = load_x3(dobase, D, 0, len, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
-        store_x3<NP, true, true, XPD_DENSE>(rq, scale * X_LOG2E, Qn, Qp, tid);        // log2 units; dK is rescaled by ln 2 at the end
-        store_x3<NP, true, true, XPD_DENSE>(ro, 1.f, On, Op, tid);
+        store_x3<NP>(rq, scale * X_LOG2E, Qn, tid);        // log2 units; dK is rescaled by ln 2 at the end
+        store_x3<NP>(ro, 1.f, On, tid);
         if (qt + 1 < ntiles) {
             rq = load_x3(base, ld, qt * 64 + 64, len, tid);
             ro = load_x3(dobase, D, qt * 64 + 64, len, tid);
@@ -438,12 +425,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_x3_k(const float* __restrict
             }
             bf16x8 pa[NP], da[NP], f0[NP], f1[NP];
             pair_frag_x3(p[0], p[1], pa);
-            pair_col_frag_x3<NP, XPD_DENSE>(Op, t, g, i16, f0);
-            pair_col_frag_x3<NP, XPD_DENSE>(Op, t, g, 16 + i16, f1);
+            tr_col_frag_x3(On, t, g, i16, 0, f0);
+            tr_col_frag_x3(On, t, g, i16, 1, f1);
             mfma_x3_2b(pa, f0, f1, dv[0], dv[1], dvl[0], dvl[1]);
             pair_frag_x3(ds[0], ds[1], da);
-            pair_col_frag_x3<NP, XPD_DENSE>(Qp, t, g, i16, f0);
-            pair_col_frag_x3<NP, XPD_DENSE>(Qp, t, g, 16 + i16, f1);
+            tr_col_frag_x3(Qn, t, g, i16, 0, f0);
+            tr_col_frag_x3(Qn, t, g, i16, 1, f1);
             mfma_x3_2b(da, f0, f1, dk[0], dk[1], dkl[0], dkl[1]);
         }
     }

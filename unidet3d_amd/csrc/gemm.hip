@@ -531,11 +531,12 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
 // bf16-operand form of gemm_tn_k (weight gradients of the Linear layers under BASELINE configs[2]): A (= dY) and B (= X) are
 // rounded to bf16 while they are staged, the reduction over the M rows runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 // The reduction index is the ROW index of both operands, so a lane's 8 consecutive k values are a COLUMN of the staged
-// [32 rows][128 cols] tile: eight 2-byte LDS reads per fragment (a half-wave reads 64 contiguous bytes of one row, the two
-// halves rows 8 apart -- conflict free).  The column sums of A (bias gradient) are accumulated from the fp32 values before
-// they are rounded.
+// [32 rows][128 cols] tile: two ds_read_b64_tr_b16 per fragment (a 16-lane group hands in a [4 rows][16 cols] block, lane t
+// receives column t; rounds 2-3 used eight 2-byte reads and four packing instructions).  320-byte rows put the four rows a
+// half-wave reads on four different 64-byte bank groups -- conflict free.  The column sums of A (bias gradient) are accumulated
+// from the fp32 values before they are rounded.
 constexpr int TKH = 32;              // rows per stage
-constexpr int TLH = GT + 8;          // padded LDS row (halves)
+constexpr int TLH = GT + 32;         // padded LDS row (halves)
 
 __global__ __launch_bounds__(256) void gemm_tn_bf16_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
                                                       int colsum, int64_t M, int N, int K, int64_t rows_per_split) {
@@ -574,9 +575,14 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_k(const float* __restrict__ 
             *reinterpret_cast<bf16x4*>(&Bs[buf][(srow + 8 * j) * TLH + sc4 * 4]) = bf16x4{(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
         }
     };
-    auto colfrag = [&](const __bf16* t, int row0, int col) {
-        const __bf16* p = t + row0 * TLH + col;
-        return bf16x8{p[0], p[TLH], p[2 * TLH], p[3 * TLH], p[4 * TLH], p[5 * TLH], p[6 * TLH], p[7 * TLH]};
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int troff = ((lane & 15) >> 2) * TLH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // this lane's 8 bytes of its group's [4 rows][16 cols] block
+    auto colfrag = [&](const __bf16* t, int row0, int col32) {       // column col32 + i32 over rows row0 .. row0 + 7
+        const __bf16* p = t + row0 * TLH + col32 + troff;
+        const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * TLH));
+        return __builtin_bit_cast(bf16x8, s16x8{r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]});
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -600,8 +606,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_k(const float* __restrict__ 
             bf16x8 af[2], bf[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                af[u] = colfrag(As[buf], r0, wr * 64 + u * 32 + i32);
-                bf[u] = colfrag(Bs[buf], r0, wc * 64 + u * 32 + i32);
+                af[u] = colfrag(As[buf], r0, wr * 64 + u * 32);
+                bf[u] = colfrag(Bs[buf], r0, wc * 64 + u * 32);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence on one MI355X: full -m gpu suite (log + parity errors kept), default bench line (fp32 headline + native-MFMA block +
 # cfg3 block + cpu baseline), the cfg4 / cfg5 single-GPU lines, rocprofv3 kernel stats of the fp32 / bf16 / cfg4 / cfg5 bench, PMC traffic of
-# the bench step.  usage: tools/gpu_final.sh <tag> [notests]
+# the bench step (taken before the bench line, which quotes it).  usage: tools/gpu_final.sh <tag> [notests]
 TAG=${1:-final}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
 rm -f gpurun_out/parity_errors.jsonl
 T0=$(date +%s)
@@ -10,6 +10,10 @@ timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 > $OUT/pytest_gpu.t
 tail -6 $OUT/pytest_gpu.txt | cut -c1-300
 cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
 fi
+echo "t=$(( $(date +%s) - T0 ))s"
+# PMC traffic first: the bench line quotes it only when it was taken on exactly the kernel sources it times (bench.py _pmc_traffic)
+PMC_TAG=${TAG}_pmc timeout 400 bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; grep -E "_spconv_gmm" $OUT/pmc.log | cut -c1-200
+cp gpurun_out/${TAG}_pmc/summary.json $OUT/pmc_traffic.json 2>/dev/null && cp $OUT/pmc_traffic.json profiles/round4_pmc_traffic.json
 echo "t=$(( $(date +%s) - T0 ))s"
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.log || tail -5 $OUT/bench.log
 python - <<PY
@@ -36,8 +40,4 @@ for d in fp32 bf16 cfg4 cfg5; do
   [ -n "$S" ] && cp $S $OUT/kernel_stats_$d.csv && (cd $R; python tools/stats_summary.py $OUT/kernel_stats_$d.csv auto 60 > $OUT/summary_$d.txt; head -12 $OUT/summary_$d.txt)
 done
 find $OUT -name "*.csv" -size +1M -delete; rm -rf $OUT/prof_*
-echo "t=$(( $(date +%s) - T0 ))s"
-cd $R
-PMC_TAG=${TAG}_pmc timeout 400 bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; grep -E "_spconv_gmm" $OUT/pmc.log | cut -c1-200
-cp gpurun_out/${TAG}_pmc/summary.json $OUT/pmc_traffic.json 2>/dev/null
 echo "t=$(( $(date +%s) - T0 ))s"

@@ -528,6 +528,148 @@ __global__ __launch_bounds__(256) void gemm_tn_k(const float* __restrict__ A, co
     if (sums && n0 + tid < N) partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = csum;
 }
 
+// gemm_tn_k with fp32 products from three exact bf16 planes per operand (u3d_common.h "bf16x3"), round 4.  The reduction index is
+// the ROW index of both operands, so a lane's eight k values are a COLUMN of the staged [32 rows][T cols] tiles.  What makes that
+// affordable (round 3's form -- pair-packed planes read back with ds_read_b32, every wave splitting the fragments it read -- was not):
+//   * every staged fp32 value is split ONCE, by the thread that loaded it, into three row-major bf16 plane tiles;
+//   * column fragments are ds_read_b64_tr_b16 (a 16-lane group hands in a [4 rows][16 cols] block, lane t receives column t): two
+//     reads per plane and fragment, k slot 8g + e <-> row 4g + (e & 3) + 16 (e >> 2) for both operands.  Rows are padded by 32 bytes
+//     (odd multiples of 32 B): the eight rows a half-wave reads lie on eight different 32-byte bank groups;
+//   * 128 x 64 (FFN weights) and 64 x 64 tiles: the low-order products keep accumulators of their own (the bf16 MFMA truncates at
+//     its C operand's exponent, u3d_common.h) without leaving two waves per SIMD.
+// One LDS stage, two barriers per 32-row trip (the raw rows of trip t+1 wait in registers during the products of trip t).
+constexpr int TXK = 32;
+template <int TA, int TB>          // output rows (columns of A) x output columns (columns of B) per workgroup
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TA == 128 ? 3 : 1))) void gemm_tn_x3_k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ partial,
+                                                    int colsum, int64_t M, int N, int K, int64_t rows_per_split, int S) {
+    constexpr int LA = TA + 16, LB = TB + 16;              // halves per LDS row
+    constexpr int PA = TXK * LA, PB = TXK * LB;            // halves per plane tile
+    constexpr int TPA = TA / 4, TPB = TB / 4;              // staging threads per row (one float4 each)
+    constexpr int RPA = 256 / TPA, RPB = 256 / TPB;        // rows per staging pass
+    constexpr int NPA = TXK / RPA, NPB = TXK / RPB;        // passes per trip
+    constexpr int NA = TA / 32, NB = TB / 32;              // 16-wide blocks per wave and operand (2 x 2 waves)
+    __shared__ __attribute__((aligned(16))) __bf16 As[3 * PA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * PB];
+    __shared__ float csum_s[RPA][TA];
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int tiles_n = (N + TA - 1) / TA, tiles = tiles_n * ((K + TB - 1) / TB);
+    const int slot = blockIdx.x >> 3, tile = slot % tiles;                     // XCD placement as in gemm_tn_k
+    const int split = (slot / tiles) * 8 + (blockIdx.x & 7);
+    if (split >= S) return;
+    const int tid = threadIdx.x, lane = tid & 63, t16 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = (tile % tiles_n) * TA, k0 = (tile / tiles_n) * TB;
+    const int64_t mlo = (int64_t)split * rows_per_split;
+    const int64_t mhi = min(M, mlo + rows_per_split);
+    const int rows = (int)max((int64_t)0, mhi - mlo);
+    const int rowa = tid / TPA, ca4 = tid % TPA, rowb = tid / TPB, cb4 = tid % TPB;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + mlo * N, (int64_t)rows * N * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + mlo * K, (int64_t)rows * K * 4);
+    const int va = n0 + ca4 * 4 < N ? (rowa * N + n0 + ca4 * 4) * 4 : 0x7fffffff;        // rows past the split / columns past N, K read as zeros
+    const int vb = k0 + cb4 * 4 < K ? (rowb * K + k0 + cb4 * 4) * 4 : 0x7fffffff;
+    const bool oka = va != 0x7fffffff, okb = vb != 0x7fffffff;
+    f32x4 ra[NPA], rb[NPB];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) ra[j] = bload128(rs_a, oka ? va + j * RPA * N * 4 : va, t * (TXK * N * 4));
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) rb[j] = bload128(rs_b, okb ? vb + j * RPB * K * 4 : vb, t * (TXK * K * 4));
+    };
+    auto put = [&](__bf16* tile, int plane, int off, const f32x4& v) {
+        unsigned w0[3], w1[3];
+        split3_pair(v[0], v[1], w0[0], w0[1], w0[2]);
+        split3_pair(v[2], v[3], w1[0], w1[1], w1[2]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(tile + q * plane + off) = make_uint2(w0[q], w1[q]);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            cs += ra[j];
+            put(As, PA, (rowa + j * RPA) * LA + ca4 * 4, ra[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) put(Bs, PB, (rowb + j * RPB) * LB + cb4 * 4, rb[j]);
+    };
+    // column blk * 16 + t16 of a plane tile over rows {4g .. 4g+3} and {16+4g .. 16+4g+3}
+    auto frag = [&](const __bf16* tile, int L, int blk) -> bf16x8 {
+        const __bf16* s0 = tile + (4 * g + (t16 >> 2)) * L + blk * 16 + 4 * (t16 & 3);
+        const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)s0);
+        const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s0 + 16 * L));
+        return __builtin_bit_cast(bf16x8, s16x8{r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]});
+    };
+    f32x4 acc[NA][NB], lo[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][b] = acc[a][b]; }
+    const int nt = (rows + TXK - 1) / TXK;
+    if (nt > 0) {
+        gload(0);
+        lstore();
+        if (nt > 1) gload(1);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        bf16x8 fb[NB][3];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fb[b][q] = frag(Bs + q * PB, LB, wc * NB + b);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            bf16x8 fa[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fa[q] = frag(As + q * PA, LA, wr * NA + a);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int o = 2; o >= 1; --o)               // plane-order sum qa + qb = o, smallest terms first
+#pragma unroll
+                    for (int qa = 0; qa <= o; ++qa)
+                        lo[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[qa], fb[b][o - qa], lo[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[b][0], acc[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wave has read trip t
+        if (t + 1 < nt) {
+            lstore();                                      // trip t+1 (loaded one trip ago)
+            if (t + 2 < nt) gload(t + 2);
+        }
+        __syncthreads();
+    }
+    // accumulator element r of lane (t16, g) in block (a, b): output row n0 + 16 (wr NA + a) + 4g + r, column k0 + 16 (wc NB + b) + t16
+    const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)split * pstride, (int64_t)N * K * 4);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int k = k0 + 16 * (wc * NB + b) + t16;
+        const int vo = k < K ? ((n0 + 4 * g) * K + k) * 4 : 0x7fffffff;          // rows past N fall off the end of the descriptor
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[a][b][r] + lo[a][b][r];
+                asm volatile("" : "+v"(v));                 // see gemm_tn_k
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, (16 * (wr * NA + a) + r) * K * 4, 0);
+            }
+    }
+    if (colsum && k0 == 0) {                               // column sums of A from the fp32 values: RPA row slots per column
+#pragma unroll
+        for (int c = 0; c < 4; ++c) csum_s[rowa][ca4 * 4 + c] = cs[c];
+        __syncthreads();
+        if (tid < TA && n0 + tid < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPA; ++r) v += csum_s[r][tid];
+            partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = v;
+        }
+    }
+}
+
 // bf16-operand form of gemm_tn_k (weight gradients of the Linear layers under BASELINE configs[2]): A (= dY) and B (= X) are
 // rounded to bf16 while they are staged, the reduction over the M rows runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 // The reduction index is the ROW index of both operands, so a lane's 8 consecutive k values are a COLUMN of the staged
@@ -821,10 +963,23 @@ int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W
     return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, bf, nullptr, nullptr, f2, (hipStream_t)stream);
 }
 
+// three-plane form (gemm_tn_x3_k): 128 x 64 tiles where gemm_tn_k takes 128 x 128 ones, 64 x 64 otherwise
+static bool tn_x3_on() { static const int on = [] { const char* e = getenv("U3D_TN_X3"); return e ? atoi(e) : 1; }(); return on != 0 && fp32_x3(); }
+static int tn_x3_ta(int N, int K) { return tn_tile(N, K) == GT ? 128 : 64; }
+static int tn_x3_splits(int64_t M, int N, int K) {
+    const int64_t tiles = ceil_div(N, tn_x3_ta(N, K)) * ceil_div(K, 64);
+    int64_t s = ceil_div(768, tiles);
+    const int64_t max_s = ceil_div(M, 4 * TXK);
+    if (s > max_s) s = max_s;
+    return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K) {
     // the fp32 and the bf16 kernel pick their split counts independently (U3D_TN_WGS moves only the former): size for the larger
     const int s32 = tn_splits(M, N, K, GT, false), s32b = tn_splits(M, N, K, tn_tile(N, K), false), s16 = tn_splits(M, N, K, GT, true);
-    const int smax = s32 > s16 ? (s32 > s32b ? s32 : s32b) : (s16 > s32b ? s16 : s32b);
+    const int sx3 = tn_x3_splits(M, N, K);
+    int smax = s32 > s16 ? (s32 > s32b ? s32 : s32b) : (s16 > s32b ? s16 : s32b);
+    smax = smax > sx3 ? smax : sx3;
     return (int64_t)(smax + 8) * ((int64_t)N * K + N) * 4 + 256;       // + 8: the fp32 grid is padded to whole groups of 8 splits
 }
 
@@ -834,19 +989,24 @@ static int gemm_tn_impl(const float* A, const float* B, float* C, float* colsum_
     if (N % 4 || K % 4) { set_error("gemm_tn: N=%d, K=%d must be multiples of 4", N, K); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
-    // The fp32 weight gradients stay on the native fp32 MFMA kernel in both fp32 math modes: a three-plane bf16 form (pair-packed
-    // planes, ds_read_b32 fragments) was built and measured -- 64 x 64 tiles 45 us against 45 us, 128 x 128 tiles 58 against 79 us
-    // but only with all six plane products in one accumulator, i.e. with the truncation bias of the bf16 MFMA (u3d_common.h) in a
-    // sum over 17 k rows; with the low-order products in a tile of their own 128 x 128 no longer fits two waves per SIMD
-    // (268 registers) and 64 x 64 everywhere cost 2.24 ms/step against 1.9 ms for this kernel.  Removed again.
+    // fp32 weight gradients: three-plane products (gemm_tn_x3_k) in the bf16x3 math mode since round 4 -- all GEMM launches of the
+    // bench step 5.87 -> 5.46 ms (U3D_TN_X3=0 keeps gemm_tn_k, same box).  Round 3's attempt (pair-packed planes, ds_read_b32
+    // fragments, every wave splitting what it read) had 64 x 64 tiles at 45 us against 45 us and 128 x 128 tiles out of registers
+    // once the low-order products got a tile of their own; the transpose read and the once-per-element split are what changed.
+    const bool x3 = !bf && tn_x3_on();
     const int T = bf ? GT : tn_tile(N, K);
-    const int S = tn_splits(M, N, K, T, bf);
-    const int64_t rps = ceil_div(ceil_div(M, S), GK) * GK;
-    if ((int64_t)(rps + 2 * GK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + 2 * GK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
+    const int S = x3 ? tn_x3_splits(M, N, K) : tn_splits(M, N, K, T, bf);
+    const int64_t rps = x3 ? ceil_div(ceil_div(M, S), TXK) * TXK : ceil_div(ceil_div(M, S), GK) * GK;
+    if ((int64_t)(rps + 2 * TXK) * N * 4 >= 0x7fffffffLL || (int64_t)(rps + 2 * TXK) * K * 4 >= 0x7fffffffLL || (int64_t)N * K * 4 >= 0x7fffffffLL) {
         set_error("gemm_tn: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
         return U3D_EUNSUPPORTED;
     }
-    if (bf) hipLaunchKernelGGL(gemm_tn_bf16_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
+    if (x3) {
+        const int ta = tn_x3_ta(N, K);
+        const unsigned grid = (unsigned)(ceil_div(S, 8) * 8 * ceil_div(N, ta) * ceil_div(K, 64));
+        if (ta == 128) hipLaunchKernelGGL((gemm_tn_x3_k<128, 64>), dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+        else hipLaunchKernelGGL((gemm_tn_x3_k<64, 64>), dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);
+    } else if (bf) hipLaunchKernelGGL(gemm_tn_bf16_k, dim3((unsigned)ceil_div(N, GT), (unsigned)ceil_div(K, GT), S), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps);
     else {
         const unsigned grid = (unsigned)(ceil_div(S, 8) * 8 * ceil_div(N, T) * ceil_div(K, T));       // whole groups of 8 splits
         if (T == 64) hipLaunchKernelGGL(gemm_tn_k<64>, dim3(grid), dim3(256), 0, s, A, B, (float*)ws, colsum_A ? 1 : 0, M, N, K, rps, S);

@@ -194,13 +194,15 @@ def csrc_hashes(names=None):
     return {n: hashlib.sha256(open(os.path.join(d, n), 'rb').read()).hexdigest()[:16] for n in names}
 
 
-def _pmc_traffic(bf: bool):
+def _pmc_traffic(bf: bool, workload: str = 'cfg2'):
     """HBM bytes per sparse-convolution (forward / input-gradient) launch from the newest committed PMC pass of this command whose
     source hashes match the kernels timed here (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     FETCH x2 on gfx950).  A file taken on other sources is refused, not quoted."""
     import glob
     if bf:
         return None, None
+    if workload != 'cfg2':       # the PMC pass is a pass of the cfg2 command: its per-launch bytes do not describe another workload's launches
+        return None, 'PMC traffic is collected for the cfg2 command only (tools/pmc_bench.sh)'
     want = csrc_hashes(PMC_SOURCES)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_traffic.json')), reverse=True)
     for f in files:
@@ -360,7 +362,7 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
                       'hbm_gbs': gbs, 'frac_hbm': gbs / PEAK_HBM_GBS if gbs else None}
     g = prof['conv_gmm']
     ach = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
-    traffic, traffic_src = _pmc_traffic(bf)
+    traffic, traffic_src = _pmc_traffic(bf, wl)
     fam_ms = sum(v['ms'] for v in prof.values())
     return {
         'value': batch * world * args.steps / dt,

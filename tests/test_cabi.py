@@ -80,6 +80,31 @@ def test_pure_size_queries_run_without_gpu():
     assert l.u3d_down_rulebook_ws_bytes(1000) >= 8 * 1000 * 4
 
 
+def test_gemm_tn_workspace_covers_every_kernel_plan():
+    """u3d_gemm_tn writes one [N*K + N] block of partial sums per row split, grid padded to whole groups of 8 splits; the split
+    count depends on the kernel that runs (fp32 MFMA tiles 128 / 64, bf16, three-plane 128x64 / 64x64 tiles with 32-row trips,
+    gemm.hip tn_splits / tn_x3_splits).  The size query must cover the largest of them for the decoder's shapes and the edge cases."""
+    from unidet3d_amd import _lib
+    l = _lib.lib()
+
+    def cdiv(a, b):
+        return -(-a // b)
+
+    def x3_splits(M, N, K):      # gemm.hip tn_x3_splits
+        ta = 128 if cdiv(N, 128) * cdiv(K, 128) >= 16 else 64
+        tiles = cdiv(N, ta) * cdiv(K, 64)
+        return max(1, min(256, cdiv(768, tiles), cdiv(M, 4 * 32)))
+
+    def fp32_splits(M, N, K, T):  # gemm.hip tn_splits (default target of 768 workgroups, 16-row steps)
+        tiles = cdiv(N, T) * cdiv(K, T)
+        return max(1, min(256, cdiv(768, tiles), cdiv(M, 4 * 16)))
+
+    for M, N, K in [(12300, 1024, 256), (12300, 256, 1024), (12300, 768, 256), (12300, 256, 256), (24600, 256, 32), (2500, 20, 256),
+                    (1, 256, 256), (333, 8, 256), (1_000_000, 256, 256)]:
+        need = max(x3_splits(M, N, K), fp32_splits(M, N, K, 128), fp32_splits(M, N, K, 64))
+        assert l.u3d_gemm_tn_ws_bytes(M, N, K) >= (need + 8) * (N * K + N) * 4, (M, N, K)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only check')
 def test_no_cpu_fallback():
     from unidet3d_amd import _lib, ops

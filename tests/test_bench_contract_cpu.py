@@ -67,6 +67,13 @@ def test_pmc_traffic_is_refused_on_other_kernel_sources(tmp_path, monkeypatch):
     t, src = bench._pmc_traffic(False)
     assert t is None and 'different kernel sources' in src
     assert bench._pmc_traffic(True) == (None, None)
+    # the pass is a pass of the cfg2 command: other workloads never quote it, matching sources or not
+    rec['_meta']['csrc_sha16'] = bench.csrc_hashes(bench.PMC_SOURCES)
+    (prof / 'round9_pmc_traffic.json').write_text(json.dumps(rec))
+    assert bench._pmc_traffic(False, 'cfg2')[0] == 12.5e6
+    for wl in ('cfg4', 'cfg5'):
+        t, src = bench._pmc_traffic(False, wl)
+        assert t is None and 'cfg2' in src
 
 
 def test_kept_bench_lines_follow_the_contract():

@@ -256,8 +256,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
 // bf16 planes, a tile pair takes the six MFMAs h.h, h.m, m.h, h.l, m.m, l.h (smallest terms first) -- 6 x 32 cycles for a
 // 32 x 32 x 16 block instead of the 8 x 64 cycles of v_mfma_f32_32x32x2_f32.  With the matrix time cut to 3/8 the kernel must
 // not be latency bound, so the loop is built differently from gemm_nt_k:
-//   * ONE LDS stage (3 planes x (TM + TN) rows x 80 B = 60 KB at 128 x 128) instead of two, so two workgroups share a CU and
-//     one computes while the other stages (their barriers are independent);
+//   * ONE LDS stage (3 planes x (TM + TN) rows x 80 B = 60 KB at 128 x 128, 45 KB at 128 x 64) instead of two, so two -- at
+//     128 x 64, with the register bound below, three -- workgroups share a CU and one computes while another stages (their
+//     barriers are independent);
 //   * the raw fp32 rows of stage kt+1 wait in registers while stage kt is multiplied, are split AFTER the MFMAs were issued
 //     (VALU work under the matrix pipe, this wave's own and the partner workgroup's), and the loads of stage kt+2 are issued
 //     before the barrier: every global load has a full stage of matrix work to land.
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
 #define U3D_NTX_ABL 0          // timing ablations (wrong results): 1 no MFMAs, 2 no split arithmetic, 4 no global loads in the loop, 8 no LDS stores in the loop
 #endif
 template <int TN, int EPI, int TM = GT>
-__global__ __launch_bounds__(256) void gemm_nt_x3_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ? 3 : 1))) void gemm_nt_x3_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                                     float* __restrict__ C, int64_t M, int N, int K, const float* __restrict__ aux,
                                                     float* __restrict__ pre) {
     constexpr int NB = TN / 64, TA = TM / 64;
@@ -872,6 +873,10 @@ static void launch_nt(const float* A, const float* W, const float* bias, float* 
         const double t = (double)ceil_div(wgs, 256) * tm[c] * tn[c] * over[c];
         if (c == (x3 ? 1 : 0) || t < best_t) { best = c; best_t = t; }
     }
+    // Round 4: under amdgpu_waves_per_eu(3) the three-plane 128 x 64 kernel takes 162 registers instead of 200 (no spills) and three
+    // workgroups share a CU; measured on the bench step (same box, all GEMMs): model's choice 5.39 ms, 128 x 64 everywhere 5.33 ms
+    // (with two per CU, round 3: 5.82 ms) -- the model's rounds of 256 workgroups no longer describe it, so large products take it.
+    if (x3 && M >= 4096) best = 1;
     if (force >= 1 && force <= 3) best = force - 1;
     if (x3 && best == 0) best = 1;
     const dim3 grid((unsigned)(ceil_div(M, tm[best]) * ceil_div(N, tn[best])));       // (row tile, column tile) decoded in the kernel

@@ -222,8 +222,9 @@ int u3d_spconv_wgrad_bf16(const float* x, int64_t n_rows_x, const float* dy, con
 /* Weight gradient from bf16 ROWS: x_bf16 / dy_bf16 are the shadows u3d_bn_apply (y_bf16) and u3d_bn_bwd_apply (dx_bf16) wrote --
  * [n][C] bf16 in fragment order (see u3d_spconv_gmm_bf16a).  Whole rows are gathered, turned in LDS with ds_read_b64_tr_b16 and
  * multiplied by v_mfma_f32_16x16x32_bf16 (32 pairs per instruction), fp32 accumulation, fixed-order reductions; dW comes out in
- * the natural [C_out][K][C_in] layout.  Same tile plan and workspace as u3d_spconv_wgrad.  Instantiated for 32 / 64 channels
- * (u3d_spconv_wgrad_rows_supported); the operands are the bf16 values, so the result equals u3d_spconv_wgrad on the rounded tensors
+ * the natural [C_out][K][C_in] layout.  Same tile plan and workspace as u3d_spconv_wgrad.  Instantiated for 32 / 64 channels (one wave per tile)
+ * and the twelve 64 ... 256-channel combinations of levels 3-5 and the tail blocks (four waves share a tile): ask
+ * u3d_spconv_wgrad_rows_supported; the operands are the bf16 values, so the result equals u3d_spconv_wgrad on the rounded tensors
  * up to fp32 summation order. */
 int u3d_spconv_wgrad_rows(const void* x_bf16, int64_t n_rows_x, const void* dy_bf16, const int32_t* rows_x, const int32_t* rows_dy,
                           const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,

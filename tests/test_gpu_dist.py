@@ -148,6 +148,7 @@ def _rccl_worker(port, out_path):
               f32_on_own_group=all(c[2] for c in f32), all_cuda=all(c[3] for c in res['calls']),
               flat_equal=bool(torch.equal(res[True]['flat'], res[False]['flat'])), loss_equal=bool(torch.equal(res[True]['loss'], res[False]['loss'])),
               stats_equal=bool(torch.equal(res[True]['rm'], res[False]['rm']) and torch.equal(res[True]['rv'], res[False]['rv'])),
+              loss_rel=float((res[True]['loss'] - res[False]['loss']).abs() / res[False]['loss'].abs()),
               max_rel=float((res[True]['flat'] - res[False]['flat']).abs().max() / res[False]['flat'].abs().max()),
               stats_rel=float((res[True]['rv'] - res[False]['rv']).abs().max() / res[False]['rv'].abs().max()),
               bf16_loss_rel=float((bres[True][0] - bres[False][0]).abs() / bres[False][0].abs()),
@@ -162,8 +163,8 @@ def test_rccl_one_rank_runs_the_whole_collective_sequence():
     """the data-parallel step's collectives have only ever met gloo.  One RCCL rank on cuda:0 with
     dist.force_collectives(): every SyncBatchNorm exchange (fp64 [sum x, sum x^2, n], forward and backward) and every gradient
     bucket (fp32, on the communicator dist.new_group() made for them, launched from the backward hooks) goes through librccl;
-    a one-rank all-reduce is the identity, so gradients, loss and running statistics must equal the non-distributed step's (to the
-    rounding of the separate statistics / apply launches the exchange needs; bit equality is logged)."""
+    a one-rank all-reduce is the identity, so gradients, loss and running statistics must equal the non-distributed step's to the
+    rounding of the separate statistics / apply launches the exchange needs (bit equality is logged, never asserted)."""
     out_path = os.path.join(tempfile.mkdtemp(), 'rccl1.pt')
     ctx = mp.get_context('spawn')
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), out_path))
@@ -173,14 +174,22 @@ def test_rccl_one_rank_runs_the_whole_collective_sequence():
     ok = torch.load(out_path)
     import _parity as PA
     PA.log_errors('rccl_one_rank_vs_no_group', {k: (float(v) if not isinstance(v, bool) else v) for k, v in ok.items()})
-    assert ok['n_f64'] >= 40, ok            # SyncBatchNorm layers x (forward + backward)
-    assert ok['n_f32'] == ok['n_buckets'] >= 4 and ok['f32_on_own_group'] and ok['all_cuda'], ok
-    # measured on MI355X / RCCL 2.26.6: loss identical, gradients 4.3e-6 apart (max-norm relative): the exchange path runs batch-norm
-    # statistics, finalize and apply as separate launches (fp64 sums handed to the collective), the non-distributed path the fused call
-    assert ok['loss_equal'] and ok['max_rel'] < 2e-5 and ok['stats_rel'] < 1e-6, ok
+    full = '; '.join(f'{k}={v!r}' for k, v in sorted(ok.items()))          # the whole record, untruncated, in every assertion message
+    assert ok['n_f64'] >= 40, full            # SyncBatchNorm layers x (forward + backward)
+    assert ok['n_f32'] == ok['n_buckets'] >= 4 and ok['f32_on_own_group'] and ok['all_cuda'], full
+    # The exchange path runs batch-norm statistics, finalize and apply as separate launches (fp64 sums handed to the collective), the
+    # non-distributed path the fused call: two DIFFERENT launch sequences, each deterministic, whose results differ by fp32 rounding of
+    # the normalised activations.  Bit equality of loss / gradients / statistics between them is therefore a coincidence of rounding
+    # (seen true for the loss on some trees and false on others: it flipped when an unrelated GEMM tile rule changed the summation
+    # order downstream) and is only LOGGED (flat_equal / loss_equal / stats_equal above).  Asserted: the same bounds the two-rank test
+    # uses.  Measured on MI355X / RCCL 2.26.6 over rounds 4-5: loss 0 ... 1e-7, gradients 5.5e-8 ... 4.3e-6, statistics 1.1e-7.
+    assert ok['loss_rel'] <= 1e-5, full
+    assert ok['max_rel'] <= 1e-4, full
+    assert ok['stats_rel'] <= 1e-5, full
     # bf16 operands: the shadows are written and used on the exchange path as on the fused one (same hit count), results agree to the
     # rounding of the separate launches seen through bf16 operands
-    assert ok['bf16_shadow_hits'] == ok['bf16_shadow_hits_plain'] >= 80 and ok['bf16_loss_rel'] < 1e-3 and ok['bf16_grad_rel'] < 5e-2, ok
+    assert ok['bf16_shadow_hits'] == ok['bf16_shadow_hits_plain'] >= 80, full
+    assert ok['bf16_loss_rel'] < 1e-3 and ok['bf16_grad_rel'] < 5e-2, full
 
 
 def test_bench_gpus_2_launches_itself():

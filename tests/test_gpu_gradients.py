@@ -137,3 +137,40 @@ def test_eval_mode_packs_follow_data_writes_after_invalidate():
     assert PA.rel(a, c) > 1e-3, PA.rel(a, c)
     fresh.load_state_dict(model.state_dict(), strict=True)
     assert PA.rel(c, run(fresh)) < 1e-5
+
+
+def test_eval_mode_fine_tuning_with_grads_set_to_none_sees_every_step():
+    """a root kept in eval() (frozen batch norm) and stepped by ``AdamW(fused=True)`` in the STANDARD loop order --
+    zero_grad(set_to_none=True) -> forward -> backward -> step -- has every ``.grad`` None and every ``_version`` unchanged when the
+    next forward refreshes the packs; the refresh must repack all the same (it keys on autograd being enabled over trainable weights).
+    The loss of step 3 equals that of a fresh model loaded from the stepped state_dict; a stale pack would repeat the step-1 backbone."""
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd.config import build_model
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = _small_cfg()
+    cfg['decoder']['num_layers'] = 2
+    model = fill_state_dict(build_model(cfg), tag0=3500, scale=0.06).to(DEV).eval()
+    inputs, samples0 = make_batch_inputs([make_scene(43, n_points=9000)], DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.05, fused=True)
+    losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        assert all(p.grad is None for p in model.parameters())
+        loss = model.loss(inputs, copy.deepcopy(samples0))['det_loss']
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    opt.zero_grad(set_to_none=True)
+    l2 = float(model.loss(inputs, copy.deepcopy(samples0))['det_loss'].detach())
+    fresh = build_model(cfg).to(DEV).eval()
+    fresh.load_state_dict(model.state_dict(), strict=True)
+    l2_fresh = float(fresh.loss(inputs, copy.deepcopy(samples0))['det_loss'].detach())
+    print('eval-mode fine-tuning losses', losses, l2, 'fresh', l2_fresh)
+    assert abs(l2 - l2_fresh) <= 1e-5 * abs(l2_fresh), (losses, l2, l2_fresh)
+    assert abs(losses[1] - losses[0]) > 1e-3 and abs(l2 - losses[1]) > 1e-3, (losses, l2)       # the steps are visible in the loss
+    # inference afterwards (no autograd) reuses the packs: two forwards, same result, one pack launch at most
+    with torch.no_grad():
+        a = float(model.loss(inputs, copy.deepcopy(samples0))['det_loss'])
+        b = float(model.loss(inputs, copy.deepcopy(samples0))['det_loss'])
+    assert abs(a - b) <= 2e-6 * abs(a), (a, b)

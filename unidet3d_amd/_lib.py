@@ -125,14 +125,16 @@ def lib():
             raise U3DError(f'{LIB_PATH} not found: build it with `python -m unidet3d_amd.csrc.build` '
                            '(hipcc --offload-arch=gfx950); there is no fallback path')
         l = C.CDLL(LIB_PATH)
+        # version first: a stale library that lacks a newer symbol must say "rebuild", not raise AttributeError from the loop below
+        l.u3d_version.restype = C.c_int
+        v = l.u3d_version() if hasattr(l, 'u3d_version') else -1
+        if v != ABI_VERSION:
+            raise U3DError(f'{LIB_PATH} has ABI version {v}, this package expects {ABI_VERSION}: rebuild it '
+                           '(`python -m unidet3d_amd.csrc.build`); a stale library would misread the arguments')
         for name, (res, args) in PROTOTYPES.items():
             f = getattr(l, name)
             f.restype = res
             f.argtypes = args
-        v = l.u3d_version()
-        if v != ABI_VERSION:
-            raise U3DError(f'{LIB_PATH} has ABI version {v}, this package expects {ABI_VERSION}: rebuild it '
-                           '(`python -m unidet3d_amd.csrc.build`); a stale library would misread the arguments')
         _lib = l
     return _lib
 

@@ -341,10 +341,12 @@ static int launch_wgrad_rows(const WgRowsParams& p, float* dW, hipStream_t s) {
     constexpr int CD = NG * 16, CS = NX * 16;
     constexpr int tiles = 4 * NP * 32 * (CD + CS) * 2, red = 2 * CD * CS * 4;
     constexpr int lds = tiles > red ? tiles : red;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};          // the attribute is per DEVICE: one flag per device ordinal
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_wgrad_rows_k<NG, NX, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+        attr_set[dev & 63] = true;
     }
     const int64_t groups = ceil_div(ceil_div(p.n_tiles, 4), 8) * 8;
     hipLaunchKernelGGL((spconv_wgrad_rows_k<NG, NX, NP>), dim3((unsigned)(groups * p.K)), dim3(256), lds, s, p);
@@ -357,10 +359,12 @@ template <int NG, int NX>
 static int launch_wgrad_rows_coop(const WgRowsParams& p, float* dW, hipStream_t s) {
     constexpr int CD = NG * 16, CS = NX * 16;
     constexpr int lds = 2 * 32 * (CD + CS) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};          // the attribute is per DEVICE: one flag per device ordinal
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_wgrad_rows_coop_k<NG, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+        attr_set[dev & 63] = true;
     }
     const int64_t groups = ceil_div(ceil_div(p.n_tiles, 4), 8) * 8;
     hipLaunchKernelGGL((spconv_wgrad_rows_coop_k<NG, NX>), dim3((unsigned)(groups * p.K)), dim3(256), lds, s, p);
@@ -388,7 +392,8 @@ int u3d_spconv_wgrad_rows(const void* x_bf16, int64_t n_rows_x, const void* dy_b
                           float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
     if (!x_bf16 || !dy_bf16 || !rows_x || !rows_dy || !tile_starts || !dW || !ws || K <= 0 || cap <= 0 || n_rows_dy <= 0 || n_rows_x <= 0) return U3D_EINVAL;
     if (!u3d_spconv_wgrad_rows_supported(Cs, Cd)) { set_error("spconv_wgrad_rows: no instantiation for Cs=%d Cd=%d", Cs, Cd); return U3D_EUNSUPPORTED; }
-    if (n_rows_x >= (1 << 24) || n_rows_dy >= (1 << 24) || (int64_t)K * cap * 4 >= 0x7fffffffLL) {
+    if (n_rows_x >= (1 << 24) || n_rows_dy >= (1 << 24) || (int64_t)K * cap * 4 >= 0x7fffffffLL ||
+        n_rows_x * Cs * 2 >= 0x7fffffffLL || n_rows_dy * Cd * 2 >= 0x7fffffffLL) {        // rows are addressed as (int)__umul24(row, C * 2)
         set_error("spconv_wgrad_rows: %lld / %lld rows exceed the kernel's 32-bit addressing", (long long)n_rows_x, (long long)n_rows_dy);
         return U3D_EUNSUPPORTED;
     }

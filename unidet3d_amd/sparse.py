@@ -260,8 +260,8 @@ class WeightPacks:
     refreshed by ONE launch (u3d_weight_pack_batch) instead of one pack launch in front of each of the ~90 convolution launches
     of a step.
 
-    Validity contract: in TRAINING mode -- and in eval mode while any convolution weight carries a ``.grad`` (fine-tuning with
-    frozen batch norm) -- every ``refresh()`` repacks (one launch per step -- what a changed weight costs anyway),
+    Validity contract: in TRAINING mode -- and in eval mode whenever autograd is enabled and a convolution weight requires a gradient
+    (fine-tuning with frozen batch norm) -- every ``refresh()`` repacks (one launch per step -- what a changed weight costs anyway),
     and the first eval-mode ``refresh()`` after a training-mode one repacks too, so no optimizer can leave a stale pack behind.
     Otherwise (eval mode) a pack is reused while ``(data_ptr, Tensor._version)`` of every weight is unchanged.  ``_version`` is
     bumped by torch's for-loop / foreach optimizers, ``load_state_dict`` and in-place ops on the parameter, but NOT by
@@ -297,9 +297,12 @@ class WeightPacks:
         bf = P.conv_format()           # 0 fp32 fragments, 1 bf16, 2 three bf16 planes (precision.conv_format)
         dev = self.convs[0].weight.device
         state = (bf, str(dev), tuple((m.weight.data_ptr(), m.weight._version) for m in self.convs))
-        # a root kept in eval() (frozen batch norm) while an optimizer steps it: a weight that carries a gradient can change
-        # behind _version's back (fused AdamW), so such a model repacks every time, exactly like training mode
-        tuned = any(m.weight.grad is not None for m in self.convs)
+        # a root kept in eval() (frozen batch norm) while an optimizer steps it: a trainable weight can change behind _version's back
+        # (fused AdamW), so every GRAD-ENABLED forward over trainable convolution weights repacks, exactly like training mode.  The
+        # test is on requires_grad, not on .grad: zero_grad(set_to_none=True) -- torch's default, and mmengine's order step ->
+        # zero_grad -- leaves every .grad None at the time the next forward runs.  Inference (torch.no_grad() /
+        # inference_mode, or frozen weights) keeps the version-keyed reuse.
+        tuned = torch.is_grad_enabled() and any(m.weight.requires_grad for m in self.convs)
         if state == self.state and not self.root.training and not self.dirty and not tuned:
             return
         self.dirty = bool(self.root.training or tuned)

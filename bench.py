@@ -194,6 +194,22 @@ def csrc_hashes(names=None):
     return {n: hashlib.sha256(open(os.path.join(d, n), 'rb').read()).hexdigest()[:16] for n in names}
 
 
+def git_head() -> str:
+    """Commit of this tree: `git rev-parse` where .git exists (the build container), else the .git_head file tools/grun.sh writes
+    into the snapshot that travels to the GPU box."""
+    import subprocess
+    try:
+        r = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        return open(os.path.join(ROOT, '.git_head')).read().strip() or '?'
+    except OSError:
+        return '?'
+
+
 def _pmc_traffic(bf: bool, workload: str = 'cfg2'):
     """HBM bytes per sparse-convolution (forward / input-gradient) launch from the newest committed PMC pass of this command whose
     source hashes match the kernels timed here (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,

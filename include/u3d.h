@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 109
+#define U3D_ABI_VERSION 110
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -109,17 +109,24 @@ int64_t u3d_vox_finalize_ws_bytes(int64_t n_pts, int64_t n_vox);
 /* Hashed form of the index ("hash-built rulebook in HBM", csrc/hashidx.hip) for grids whose extent makes the direct-address
  * table impractical: memory follows OCCUPANCY.  Same contract (cell -> canonical row, rows ascending in the cell id):
  *   u3d_hash_index_build: cells int64 [n] (cell ids as u3d_vox_mark / u3d_cells_of_coords write them; duplicates allowed; entries
- *     equal to INT64_MAX are ignored) -> radix sort -> unique: ukeys int64 [n] (the first *n_unique entries = the occupied cells
- *     in canonical order), n_unique device int32 (host reads it back, like word_rank[n_words]) -> open-addressing table
- *     table_keys uint64 [slots] / table_vals int32 [slots], slots = u3d_hash_index_slots(n) (power of two >= 2 n).
+ *     equal to INT64_MAX are ignored) -> radix sort (csrc/radix.hip: hand-written stable LSD sort, no library) -> unique: ukeys
+ *     int64 [n] (the first *n_unique entries = the occupied cells in canonical order), n_unique device int32 (host reads it back,
+ *     like word_rank[n_words]) -> open-addressing table table_keys uint64 [slots] / table_vals int32 [slots] by 64-bit atomicCAS
+ *     insertion, slots = u3d_hash_index_slots(n) (power of two >= 2 n).  n_cells: every valid cell id is < n_cells (the grid's
+ *     B X Y ceil(Z/64) 64) -- the sort then only runs over the bits the grid needs; 0 = unknown (63 bits).
  *   u3d_hash_index_coords: coords int32 [n,4] of the occupied cells; u3d_cells_of_coords: the (parent) cell of every voxel of a
  *     level (shift = 1: next coarser level, parents outside the halved grid -> INT64_MAX).
  * Every entry point that takes (bitmap, word_rank) also takes `hash_slots`: 0 = bitmap form; > 0 = the two pointers are
  * (table_keys, table_vals) of a table with that many slots.  The rulebook / voxel kernels are the same for both forms. */
 int64_t u3d_hash_index_slots(int64_t n);
 int64_t u3d_hash_index_ws_bytes(int64_t n);
-int u3d_hash_index_build(const int64_t* cells, int64_t n, int64_t* ukeys, int32_t* n_unique, uint64_t* table_keys, int32_t* table_vals,
-                         int64_t slots, void* ws, u3d_stream_t stream);
+int u3d_hash_index_build(const int64_t* cells, int64_t n, int64_t n_cells, int64_t* ukeys, int32_t* n_unique, uint64_t* table_keys,
+                         int32_t* table_vals, int64_t slots, void* ws, u3d_stream_t stream);
+/* The sort itself (keys only, or keys + permutation): keys_in uint64 [n] -> keys_out [n] ascending, STABLE; perm_out (nullable)
+ * int32 [n] = position in keys_in of every sorted key.  key_bits: number of significant low bits (passes = ceil(key_bits / 8)).
+ * keys_out must not alias keys_in.  Deterministic: no global atomics, ranks by wave ballots in index order. */
+int u3d_sort_u64(const uint64_t* keys_in, int64_t n, int key_bits, uint64_t* keys_out, int32_t* perm_out, void* ws, u3d_stream_t stream);
+int64_t u3d_sort_ws_bytes(int64_t n, int with_values);
 int u3d_hash_index_coords(const int64_t* ukeys, int64_t n, int X, int Y, int Z, int32_t* coords, u3d_stream_t stream);
 int u3d_cells_of_coords(const int32_t* coords, int64_t n, int shift, int B, int X2, int Y2, int Z2, int64_t* cells, u3d_stream_t stream);
 
@@ -287,7 +294,9 @@ int u3d_bn_backward(const float* x, const float* dy, const float* st, int relu, 
  * K11/K12  superpoint pooling -- replaces x.features[inverse_mapping] + torch_scatter.scatter_mean
  *     (unidet3d/unidet3d.py:130) and the superpoint centres (:332-333, :446-447).
  * ===================================================================================== */
-/* CSR of element ids per segment: offsets int32 [S+1], list int32 [L] (order inside a segment unspecified). */
+/* CSR of element ids per segment: offsets int32 [S+1], list int32 [L], element ids ASCENDING inside every segment (stable radix
+ * sort of the ids by segment id, csrc/radix.hip): the sums the pooling kernels take over a segment then have one order, so pooled
+ * features -- and with them the whole training step -- are bit-reproducible from run to run. */
 int u3d_csr_build(const int64_t* seg_ids, int64_t L, int64_t S, int32_t* offsets, int32_t* list, void* ws,
                   u3d_stream_t stream);
 int64_t u3d_csr_build_ws_bytes(int64_t L, int64_t S);

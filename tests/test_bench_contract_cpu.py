@@ -48,32 +48,52 @@ def test_gpus_n_turns_itself_into_a_torchrun_launch(monkeypatch):
 
 
 def test_pmc_traffic_is_refused_on_other_kernel_sources(tmp_path, monkeypatch):
-    """a PMC summary is quoted only when the hashes of the conv kernels' sources match the tree; the roofline block of
-    a three-plane line prices `frac` against the instruction ceiling and keeps the fp32-peak figure beside it."""
+    """a PMC summary is quoted only when the hashes of EVERY kernel source match the tree (the file describes all
+    kernels of the step, not only the convolutions), it names the commit it was taken at, and the cfg3 block quotes the cfg3 pass."""
     sys.path.insert(0, ROOT)
     import bench
     h = bench.csrc_hashes()
-    assert set(bench.PMC_SOURCES) <= set(h) and all(len(v) == 16 for v in h.values())
+    assert set(bench.PMC_SOURCES) == set(h) and all(len(v) == 16 for v in h.values())
+    assert {'spconv.hip', 'spconv_wg.hip', 'gemm.hip', 'attn_x3.hip', 'bn.hip', 'radix.hip', 'u3d_common.h'} <= set(bench.PMC_SOURCES)
     prof = tmp_path / 'profiles'
     prof.mkdir()
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
     monkeypatch.setattr(bench, 'csrc_hashes', lambda names=None: {n: h[n] for n in (names or h)})
-    rec = {'_spconv_gmm_all': {'hbm_MB_per_launch': 12.5}, '_meta': {'csrc_sha16': dict(h), 'git_head': 'abc'}}
+    assert bench._pmc_traffic(False) == (None, None) and bench._pmc_traffic(True) == (None, None)        # no file at all
+    rec = {'_spconv_gmm_all': {'hbm_MB_per_launch': 12.5}, '_meta': {'csrc_sha16': dict(h), 'git_head': 'abc123'}}
     (prof / 'round9_pmc_traffic.json').write_text(json.dumps(rec))
     t, src = bench._pmc_traffic(False)
-    assert t == 12.5e6 and 'round9_pmc_traffic.json' in src
-    rec['_meta']['csrc_sha16']['spconv_wg.hip'] = '0' * 16
+    assert t == 12.5e6 and 'round9_pmc_traffic.json' in src and 'abc123' in src
+    t, src = bench._pmc_traffic(True)                       # the file holds no cfg3 pass
+    assert t is None and 'no pass of this command' in src
+    rec['cfg3'] = {'_spconv_gmm_all': {'hbm_MB_per_launch': 40.25}}
     (prof / 'round9_pmc_traffic.json').write_text(json.dumps(rec))
-    t, src = bench._pmc_traffic(False)
-    assert t is None and 'different kernel sources' in src
-    assert bench._pmc_traffic(True) == (None, None)
-    # the pass is a pass of the cfg2 command: other workloads never quote it, matching sources or not
-    rec['_meta']['csrc_sha16'] = bench.csrc_hashes(bench.PMC_SOURCES)
+    t, src = bench._pmc_traffic(True)
+    assert t == 40.25e6 and 'cfg3 command' in src
+    for stale in ('spconv_wg.hip', 'gemm.hip'):            # ANY source: a GEMM edit makes the file stale too
+        rec['_meta']['csrc_sha16'] = dict(h, **{stale: '0' * 16})
+        (prof / 'round9_pmc_traffic.json').write_text(json.dumps(rec))
+        for bf in (False, True):
+            t, src = bench._pmc_traffic(bf)
+            assert t is None and 'different kernel sources' in src
+    # the passes are passes of the cfg2 / cfg3 commands: other workloads never quote them, matching sources or not
+    rec['_meta']['csrc_sha16'] = dict(h)
     (prof / 'round9_pmc_traffic.json').write_text(json.dumps(rec))
     assert bench._pmc_traffic(False, 'cfg2')[0] == 12.5e6
     for wl in ('cfg4', 'cfg5'):
         t, src = bench._pmc_traffic(False, wl)
         assert t is None and 'cfg2' in src
+
+
+def test_git_head_falls_back_to_the_stamp_file(tmp_path, monkeypatch):
+    """On the GPU box the snapshot has no .git: bench.git_head() reads the .git_head file tools/grun.sh wrote."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.git_head() not in ('', None)
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    assert bench.git_head() == '?'
+    (tmp_path / '.git_head').write_text('deadbeef1234+dirty(ab12cd34)\n')
+    assert bench.git_head() == 'deadbeef1234+dirty(ab12cd34)'
 
 
 def test_kept_bench_lines_follow_the_contract():

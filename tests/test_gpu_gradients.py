@@ -174,3 +174,34 @@ def test_eval_mode_fine_tuning_with_grads_set_to_none_sees_every_step():
         a = float(model.loss(inputs, copy.deepcopy(samples0))['det_loss'])
         b = float(model.loss(inputs, copy.deepcopy(samples0))['det_loss'])
     assert abs(a - b) <= 2e-6 * abs(a), (a, b)
+
+
+@pytest.mark.parametrize('operands', ['fp32', 'bf16'])
+def test_training_step_is_bit_reproducible(operands):
+    """Run-to-run determinism: the same training step -- fresh model from the same weights, same two scenes -- run
+    three times gives the SAME BITS for the loss, every parameter gradient and the running statistics.  Rounds 1-4 did not: the
+    superpoint CSR was filled through an atomic cursor, so the fp32 sums of the pooling kernel (and everything downstream of it,
+    amplified by ~90 training-mode batch norms on the way back) changed in the last bits from run to run (tools/grad_trace.py;
+    profiles/round5_determinism_*.json).  No kernel of the step uses floating-point atomics; every reduction has a fixed order."""
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.config import build_model
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = _small_cfg()
+    cfg['decoder']['num_layers'] = 2
+    inputs, samples0 = make_batch_inputs([make_scene(70, n_points=8000), make_scene(71, n_points=8000)], DEV)
+    runs = []
+    for _ in range(3):
+        model = fill_state_dict(build_model(cfg), tag0=3000, scale=0.06).to(DEV).train()
+        with P.operands(operands):
+            loss = model.loss(inputs, copy.deepcopy(samples0))['det_loss']
+            loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                     {k: b.clone() for k, b in model.named_buffers()}))
+    for r in runs[1:]:
+        assert torch.equal(runs[0][0], r[0]), (float(runs[0][0]), float(r[0]))
+        diff = [k for k, g in runs[0][1].items() if not torch.equal(g, r[1][k])]
+        assert not diff, f'{len(diff)} gradient tensors differ between two runs of the same step, e.g. {diff[:5]}'
+        assert all(torch.equal(b, r[2][k]) for k, b in runs[0][2].items())

@@ -417,6 +417,53 @@ def test_large_extent_scene_takes_the_hashed_index():
     assert _rel(y, yo) < 1e-5
 
 
+# ---------------------------------------------------------------------------- the library's own radix sort (csrc/radix.hip)
+@pytest.mark.parametrize('n,bits', [(1, 8), (63, 5), (1023, 8), (1024, 9), (1025, 17), (100_003, 17), (100_003, 40), (2_000_000, 23), (300_000, 63)])
+def test_radix_sort_equals_a_stable_sort_bit_for_bit(n, bits):
+    """u3d_sort_u64 (hand-written stable LSD radix sort: LDS histogram, scan, ballot-ranked scatter) against torch.sort(stable=True)
+    on the CPU: keys AND permutation identical -- tile edges (1023 / 1024 / 1025 keys), heavy duplicates (5-bit keys), keys that use
+    all 63 bits, 2 M keys.  The permutation being the stable one is what makes the superpoint CSR lists ascending."""
+    from unidet3d_amd import _lib as L
+    g = torch.Generator().manual_seed(n * 131 + bits)
+    hi = (1 << bits) - 1
+    keys = torch.randint(0, min(hi, (1 << 62)) + 1, (n,), generator=g, dtype=torch.int64)
+    if bits == 63:
+        keys = keys * 2 + torch.randint(0, 2, (n,), generator=g, dtype=torch.int64)
+    if n > 10:
+        keys[n // 3: n // 3 + 5] = keys[0]                    # duplicates even where keys are wide
+    kd = keys.to(_dev())
+    out = torch.empty_like(kd)
+    perm = torch.empty(n, dtype=torch.int32, device=_dev())
+    ws = L.ws(L.lib().u3d_sort_ws_bytes(n, 1), _dev())
+    L.call('u3d_sort_u64', L.ptr(kd), n, bits, L.ptr(out), L.ptr(perm), L.ptr(ws), L.stream())
+    ref_k, ref_p = torch.sort(keys, stable=True)
+    assert torch.equal(out.cpu(), ref_k)
+    assert torch.equal(perm.cpu().long(), ref_p)
+    assert torch.equal(kd.cpu(), keys)                          # the input is left alone
+    out2 = torch.empty_like(kd)                                 # keys only
+    ws2 = L.ws(L.lib().u3d_sort_ws_bytes(n, 0), _dev())
+    L.call('u3d_sort_u64', L.ptr(kd), n, bits, L.ptr(out2), None, L.ptr(ws2), L.stream())
+    assert torch.equal(out2.cpu(), ref_k)
+
+
+def test_csr_lists_are_ascending_inside_every_segment():
+    """u3d_csr_build: offsets = counts, list = element ids stably sorted by segment -- equal to a stable argsort, segment sizes from
+    0 to half of all elements (one thread sorting a segment alone would take milliseconds there), run twice: same bits."""
+    from unidet3d_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, S = 400_000, 5000
+    seg = torch.randint(0, S, (n,), generator=g)
+    seg[torch.rand(n, generator=g) < 0.5] = 17                  # one huge segment (a floor superpoint)
+    seg[seg == 23] = 24                                         # an empty one
+    off, lst = ops.csr_build(seg.to(_dev()), S)
+    ref = torch.sort(seg, stable=True)[1]
+    cnt = torch.bincount(seg, minlength=S)
+    assert torch.equal(off.cpu().long(), torch.cat((torch.zeros(1, dtype=torch.long), cnt.cumsum(0))))
+    assert torch.equal(lst.cpu().long(), ref)
+    off2, lst2 = ops.csr_build(seg.to(_dev()), S)
+    assert torch.equal(lst, lst2) and torch.equal(off, off2)
+
+
 # ---------------------------------------------------------------------------- K11 / K12
 def test_superpoint_pool_and_centers():
     from unidet3d_amd import ops

@@ -34,7 +34,9 @@ PROTOTYPES = {
     'u3d_vox_finalize': (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     'u3d_hash_index_slots': (_i64, [_i64]),
     'u3d_hash_index_ws_bytes': (_i64, [_i64]),
-    'u3d_hash_index_build': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'u3d_hash_index_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'u3d_sort_u64': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'u3d_sort_ws_bytes': (_i64, [_i64, _i32]),
     'u3d_hash_index_coords': (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     'u3d_cells_of_coords': (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'u3d_vox_finalize_ws_bytes': (_i64, [_i64, _i64]),
@@ -106,7 +108,7 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 109         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 110         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

@@ -116,6 +116,13 @@ int exclusive_scan_popc64(const uint64_t* words, int64_t n, int32_t* out, void* 
 int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, hipStream_t s);
 int64_t scan_ws_bytes(int64_t n);
 
+// ---- csrc/radix.hip: stable LSD radix sort (8-bit digits) and unique of a sorted array; hand-written, deterministic ----
+// keys at or above `clamp` sort as `clamp`; `bits` = significant low bits of the (clamped) keys; vals_out (nullable) = the permutation
+int64_t radix_ws_bytes(int64_t n, bool with_values);
+int radix_sort_u64(const uint64_t* keys_in, int64_t n, int bits, uint64_t clamp, uint64_t* keys_out, int32_t* vals_out, void* ws, hipStream_t s);
+int64_t unique_ws_bytes(int64_t n);
+int unique_sorted_u64(const uint64_t* sorted, int64_t n, uint64_t drop, uint64_t* out, int32_t* n_unique, void* ws, hipStream_t s);
+
 // ---- occupancy index (bitmap + popcount rank) ------------------------------------------
 // Key -> canonical row map of one level.  Two forms behind one lookup:
 //  * direct-address (default): occupancy bitmap + popcount rank per 64 z-cells; size follows the grid EXTENT;

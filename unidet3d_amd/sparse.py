@@ -87,7 +87,9 @@ class OccupancyIndex:
             return OccupancyIndex(keys, vals, B, shape, slots, ukeys, n_dev.zero_())
         keys = torch.empty(slots, dtype=torch.int64, device=dev)
         w = L.ws(L.lib().u3d_hash_index_ws_bytes(n), dev)
-        L.call('u3d_hash_index_build', L.ptr(cells), n, L.ptr(ukeys), L.ptr(n_dev), L.ptr(keys), L.ptr(vals), slots, L.ptr(w), L.stream())
+        n_cells = int(B) * int(shape[0]) * int(shape[1]) * ((int(shape[2]) + 63) // 64) * 64       # cell ids are < n_cells: bounds the sort's passes
+        L.call('u3d_hash_index_build', L.ptr(cells), n, n_cells if n_cells < (1 << 62) else 0, L.ptr(ukeys), L.ptr(n_dev), L.ptr(keys), L.ptr(vals),
+               slots, L.ptr(w), L.stream())
         return OccupancyIndex(keys, vals, B, shape, slots, ukeys, n_dev)
 
     def build_rank(self):

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument('--optimizer', default='adamw', choices=['adamw', 'sgd'],
                     help='adamw = configs/unidet3d_1xb8_scannet.py:710-713 (the reported config); sgd = diagnostic (DESIGN.md section 2: '
                          "AdamW's first updates are lr*sign(g), which turns rounding-level gradient differences into different trajectories)")
+    ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2],
+                    help="sparse-conv weight gradients on a side stream (unidet3d_amd/sparse.py set_wgrad_overlap): 0 off, 1 next to the layer's "
+                         'input gradient, 2 a chain of their own joined at the end of backward; default: the library setting')
     ap.add_argument('--no-prefetch', action='store_true',
                     help="build the next step's voxel grid / rulebooks at the start of that step instead of on a side stream")
     return ap.parse_args()
@@ -254,6 +257,8 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
     from unidet3d_amd.synthetic import make_scene
 
     precision.set_operand_dtype(dtype)
+    if getattr(args, 'wgrad_overlap', None) is not None:
+        sparse.set_wgrad_overlap(args.wgrad_overlap)
     if fp32_math or getattr(args, 'fp32_math', None):
         precision.set_fp32_math(fp32_math or args.fp32_math)
     x3 = dtype == 'fp32' and precision.get_fp32_math() == 'bf16x3'
@@ -342,6 +347,7 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
     # ---- per-family kernel times: HIP events around every launch of a family, on the stream it runs on, over extra steps
     # OUTSIDE the timed region (recording ~300 event pairs per step costs ~1 ms/step of host time) ----------------------
     prof_steps = max(1, min(args.steps, 5))
+    overlap_was = sparse.set_wgrad_overlap(0)       # per-family times are those of kernels running alone (overlapped kernels stretch each other)
     for _, c in families:
         L.prof_enable(c, True)
     account.reset()
@@ -356,6 +362,7 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
         prof[name] = dict(ms=ms, launches=n, flops=work, bytes=acc.get(name, {}).get('bytes', 0.0),
                           flops_booked=acc.get(name, {}).get('flops', 0.0))
     sparse.set_profile_flops(False)
+    sparse.set_wgrad_overlap(overlap_was)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -415,7 +422,7 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
                                'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else f'+clip+{args.optimizer}')
                                + ('' if args.no_prefetch else "; each step's voxelise+rulebook part is queued on a side stream during "
                                   "the previous step's backward"),
-                   'front_prefetch': not args.no_prefetch, 'fp32_math': ('bf16x3' if x3 else 'mfma') if not bf else None,
+                   'front_prefetch': not args.no_prefetch, 'wgrad_overlap': overlap_was, 'fp32_math': ('bf16x3' if x3 else 'mfma') if not bf else None,
                    'global_batch': batch * world, 'points_per_scene': args.points if wl == 'cfg2' else n_points_total // max(batch, 1),
                    'points_per_gpu': n_points_total,
                    'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val, 'warmup_losses': warm_losses},

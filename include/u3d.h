@@ -389,6 +389,9 @@ int u3d_gemm_tn_bf16(const float* A, const float* B, float* C, float* colsum_A, 
                      u3d_stream_t stream);
 int64_t u3d_gemm_tn_ws_bytes(int64_t M, int N, int K);
 int u3d_transpose(const float* in /*[R,C]*/, float* out /*[C,R]*/, int R, int C, u3d_stream_t stream);
+/* All transposed copies of a step in one launch: desc int64 [n_desc][5] = {src ptr ([R][C] floats), dst ptr ([C][R]), R, C, first
+ * block}; a matrix takes ceil(R/32) * ceil(C/32) blocks, total_blocks = their sum (descriptors in ascending first-block order). */
+int u3d_transpose_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream);
 
 /* =====================================================================================
  * K15 LayerNorm of the decoder (unidet3d/encoder.py:21,38-40,61,78-79,140,167) with the preceding residual add fused in.

@@ -205,3 +205,56 @@ def test_training_step_is_bit_reproducible(operands):
         diff = [k for k, g in runs[0][1].items() if not torch.equal(g, r[1][k])]
         assert not diff, f'{len(diff)} gradient tensors differ between two runs of the same step, e.g. {diff[:5]}'
         assert all(torch.equal(b, r[2][k]) for k, b in runs[0][2].items())
+
+
+@pytest.mark.parametrize('operands', ['fp32', 'bf16'])
+def test_weight_gradients_on_the_side_stream_give_the_same_bits(operands):
+    """sparse.set_wgrad_overlap(1 | 2): the sparse convolutions' weight gradients run on a side stream -- next to the layer's input
+    gradient (1) or as a chain of their own that is only joined when the backward pass ends (2).  Same kernels, same inputs: loss and
+    EVERY gradient must equal the single-stream step bit for bit (the step is bit-reproducible, so any difference is a race: a buffer
+    recycled under a running kernel, a gradient read before its kernel finished).  Also with gradients ACCUMULATED into existing .grad
+    tensors (mode 2 must then join before autograd adds), and through FlatGradBucket's copy."""
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    from unidet3d_amd.config import build_model
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.dist import FlatGradBucket
+    from unidet3d_amd.synthetic import make_scene
+    cfg = _small_cfg()
+    cfg['decoder']['num_layers'] = 2
+    inputs, samples0 = make_batch_inputs([make_scene(80, n_points=20000), make_scene(81, n_points=20000)], DEV)
+
+    def run(mode, accumulate=False, bucket=False):
+        prev = sparse.set_wgrad_overlap(mode)
+        try:
+            model = fill_state_dict(build_model(cfg), tag0=3000, scale=0.06).to(DEV).train()
+            params = [p for p in model.parameters() if p.requires_grad]
+            fb = FlatGradBucket(params, attach=False) if bucket else None
+            if accumulate:
+                for p in params:
+                    p.grad = torch.full_like(p, 0.25)
+            with P.operands(operands):
+                loss = model.loss(inputs, copy.deepcopy(samples0))['det_loss']
+                loss.backward()
+            if fb is not None:
+                fb.sync()
+            torch.cuda.synchronize()
+            return loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        finally:
+            sparse.set_wgrad_overlap(prev)
+
+    ref_loss, ref = run(0)
+    for mode in (1, 2, 2, 2):
+        loss, g = run(mode)
+        assert torch.equal(loss, ref_loss)
+        bad = [k for k in ref if not torch.equal(ref[k], g[k])]
+        assert not bad, (mode, len(bad), bad[:5])
+    _, acc0 = run(0, accumulate=True)
+    _, acc2 = run(2, accumulate=True)
+    bad = [k for k in acc0 if not torch.equal(acc0[k], acc2[k])]
+    assert not bad, ('accumulate', len(bad), bad[:5])
+    assert any(not torch.equal(acc0[k], ref[k]) for k in ref)             # the 0.25 really was added to
+    _, b2 = run(2, bucket=True)
+    bad = [k for k in ref if not torch.equal(ref[k], b2[k])]
+    assert not bad, ('bucket', len(bad), bad[:5])

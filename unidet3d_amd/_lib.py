@@ -102,6 +102,7 @@ PROTOTYPES = {
     'u3d_gemm_tn_bf16': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp]),
     'u3d_gemm_tn_ws_bytes': (_i64, [_i64, _i32, _i32]),
     'u3d_transpose': (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    'u3d_transpose_batch': (_i32, [_vp, _i32, _i64, _vp]),
     'u3d_attn_varlen_fwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_fwd_bf16': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
@@ -177,6 +178,24 @@ def h2d(values, dtype, device) -> torch.Tensor:
     if torch.device(device).type != 'cuda':
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
+
+
+def h2d_pack(specs, device):
+    """Several small host lists -> device tensors through ONE pinned staging buffer and ONE non-blocking copy.  ``specs``: [(values,
+    dtype), ...] (nested lists are flattened row-major); returns the 1-D device tensors in order (views of one buffer, 16-byte aligned)."""
+    parts, off = [], 0
+    for values, dtype in specs:
+        t = torch.tensor(values, dtype=dtype).reshape(-1)
+        parts.append((t, off))
+        off = (off + t.numel() * t.element_size() + 15) // 16 * 16
+    host = torch.empty(max(off, 16), dtype=torch.uint8)
+    if torch.device(device).type == 'cuda':
+        host = host.pin_memory()
+    for t, o in parts:
+        if t.numel():
+            host[o:o + t.numel() * t.element_size()].view(t.dtype).copy_(t)
+    dev = host.to(device, non_blocking=True)
+    return [dev[o:o + t.numel() * t.element_size()].view(t.dtype) for t, o in parts]
 
 
 _SCRATCH = {}

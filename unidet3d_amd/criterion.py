@@ -15,6 +15,8 @@ from torch import nn
 
 from . import _lib as L
 from ._lib import h2d as _h2d
+from ._lib import h2d_pack as _h2d_pack
+from .ops import cat_views
 from .registry import MODELS, TASK_UTILS
 from .structures import InstanceData_
 
@@ -240,6 +242,9 @@ class _FusedCriterionFn(torch.autograd.Function):
 
 
 def _gt_boxes(b):
+    rows = getattr(b, 'gt_rows', None)
+    if rows is not None and rows.shape[0] == b.tensor.shape[0]:       # computed once for the whole batch (UniDet3D._prepare_train)
+        return rows
     return torch.cat((b.gravity_center, b.tensor[:, 3:] if b.with_yaw else b.tensor[:, 3:6]), dim=1)
 
 
@@ -412,7 +417,7 @@ class UniDet3DCriterion:
         if with_gt:
             rows = [_gt_boxes(i.bboxes_3d).float() for i in with_gt]
             rows = [r if r.shape[1] == bd else torch.nn.functional.pad(r, (0, bd - r.shape[1])) for r in rows]
-            boxes = torch.cat(rows).contiguous()
+            boxes = cat_views(rows).contiguous()           # row views of one cached tensor: no copy
         qmask = torch.cat([i.query_masks.reshape(-1) for i in with_gt]).contiguous().view(torch.uint8) if with_gt else None
         meta, coff, cflat = [], 0, []
         for b in range(len(insts)):
@@ -420,11 +425,14 @@ class UniDet3DCriterion:
             if cidx is not None:
                 cflat.extend(int(c) for c in cidx[b])
                 coff += len(cidx[b])
+        # the six small host arrays travel in ONE pinned buffer / one H2D copy
+        cu_d, go_d, qo_d, meta_d, w_d, cidx_d = _h2d_pack(
+            [(cu, torch.int32), (go, torch.int32), (qo, torch.int64), (meta, torch.int32), ([float(w) for w in weights], torch.float32),
+             (cflat if cidx is not None else [], torch.int32)], device)
         return dict(B=len(insts), G=go[-1], P=qo[-1], max_gt=max(gs, default=0),
                     slack=min([n - (k + 1) for g, n, k in zip(gs, sizes, topks) if g], default=0),
-                    cu=_h2d(cu, torch.int32, device), gt_off=_h2d(go, torch.int32, device), qm_off=_h2d(qo, torch.int64, device),
-                    meta=_h2d(meta, torch.int32, device), scene_w=_h2d([float(w) for w in weights], torch.float32, device),
-                    cidx=_h2d(cflat, torch.int32, device) if cidx is not None else None,
+                    cu=cu_d, gt_off=go_d, qm_off=qo_d, meta=meta_d.view(-1, 4), scene_w=w_d,
+                    cidx=cidx_d if cidx is not None else None,
                     labels=labels, boxes=boxes, qmask=qmask)
 
     @staticmethod

@@ -841,6 +841,30 @@ __global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in,
         if (bx + j < Ccols && by + tx < R) out[(int64_t)(bx + j) * R + by + tx] = tile[tx][j];
 }
 
+// Every transposed weight copy a step's input-gradient GEMMs need (dX = dY . W as an NT product over W^T), in ONE launch: desc[i] =
+// {src [R][C], dst [C][R], R, C, first block}; block b belongs to the last descriptor whose first block is <= b (the pattern of
+// u3d_weight_pack_batch).  Replaces ~31 transpose_k launches of ~4 us per training step.
+struct TrDesc { const float* src; float* dst; int64_t R, C, block0; };
+__global__ __launch_bounds__(256) void transpose_batch_k(const TrDesc* __restrict__ desc, int n_desc) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n_desc;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[mid].block0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const TrDesc d = desc[lo];
+    const int R = (int)d.R, Ccols = (int)d.C;
+    const int tiles_x = (Ccols + 31) / 32;
+    const int rem = (int)((int64_t)blockIdx.x - d.block0);
+    const int bx = (rem % tiles_x) * 32, by = (rem / tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < R && bx + tx < Ccols) tile[j][tx] = d.src[(int64_t)(by + j) * Ccols + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < Ccols && by + tx < R) d.dst[(int64_t)(bx + j) * R + by + tx] = tile[tx][j];
+}
+
 // 64 x 64 tiles while 128 x 128 ones would be fewer than 16 (every decoder weight except the FFN's 1024 x 256)
 static int tn_tile(int N, int K) { return ceil_div(N, GT) * ceil_div(K, GT) < 16 ? 64 : GT; }
 static int tn_splits(int64_t M, int N, int K, int T, bool bf) {
@@ -1052,6 +1076,12 @@ int u3d_transpose(const float* in, float* out, int R, int C, u3d_stream_t stream
     if (!in || !out || R <= 0 || C <= 0) return U3D_EINVAL;
     hipLaunchKernelGGL(transpose_k, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
     return check_launch("transpose");
+}
+
+int u3d_transpose_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream) {
+    if (!desc || n_desc <= 0 || total_blocks <= 0 || total_blocks >= 0x7fffffffLL) return U3D_EINVAL;
+    hipLaunchKernelGGL(transpose_batch_k, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const TrDesc*)desc, n_desc);
+    return check_launch("transpose_batch");
 }
 
 }  // extern "C"

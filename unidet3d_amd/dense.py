@@ -43,6 +43,66 @@ def _gemm_nt(a, w, bias, bf=False):
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
+# ---- transposed weight copies of a whole forward pass in one launch ----------------------------------------------------------------
+# dX = dY . W runs as an NT product over W^T, so every Linear's backward needs a [K, N] copy of its [N, K] weight: ~31 transpose
+# launches of ~4 us per training step.  ``transposed_weights(module)`` makes them all with ONE u3d_transpose_batch launch when the
+# forward pass starts; the Linear / MLP functions pick their copy up in FORWARD (while the context is active) and keep it for their
+# backward, so a copy can never outlive the weights it was made from (weights are not modified between a forward and its backward).
+# Outside the context every op falls back to its own u3d_transpose launch.
+_WT_ACTIVE = None          # data_ptr of a weight -> its [K, N] copy, while a transposed_weights() context is open
+
+
+class transposed_weights:
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+
+    def __enter__(self):
+        global _WT_ACTIVE
+        self.prev = _WT_ACTIVE
+        ws = []
+        if torch.is_grad_enabled():
+            seen = set()
+            for w in self.module.parameters():          # every [N, K] matrix: nn.Linear weights, in_proj_weight, 1x1x1 convolutions
+                if not (w.dim() == 2 or (w.dim() == 5 and tuple(w.shape[1:4]) == (1, 1, 1))):
+                    continue
+                if not w.is_cuda or not w.requires_grad or w.data_ptr() in seen or not w.is_contiguous():
+                    continue
+                N, K = w.shape[0], w.numel() // w.shape[0]
+                if N % 16 == 0 and K % 4 == 0:
+                    seen.add(w.data_ptr())
+                    ws.append((w, N, K))
+        if ws:
+            dev = ws[0][0].device
+            flat = torch.empty(sum(N * K for _, N, K in ws), dtype=torch.float32, device=dev)
+            rows, blocks, off, table = [], 0, 0, {}
+            for w, N, K in ws:
+                wt = flat[off:off + N * K].view(K, N)
+                off += N * K
+                rows.append([w.data_ptr(), wt.data_ptr(), N, K, blocks])
+                blocks += ((N + 31) // 32) * ((K + 31) // 32)
+                table[w.data_ptr()] = wt
+            desc = L.h2d(rows, torch.int64, dev)
+            L.call('u3d_transpose_batch', L.ptr(desc), len(rows), blocks, L.stream())
+            table['_keep'] = (flat, desc)
+            _WT_ACTIVE = table
+        else:
+            _WT_ACTIVE = None
+        return self
+
+    def __exit__(self, *exc):
+        global _WT_ACTIVE
+        _WT_ACTIVE = self.prev
+        return False
+
+
+def _wt_of(weight):
+    """the [K, N] copy of ``weight`` made by the enclosing transposed_weights() context (None outside one / for other tensors)"""
+    if _WT_ACTIVE is None:
+        return None
+    wt = _WT_ACTIVE.get(weight.data_ptr())
+    return wt if wt is not None and wt.shape == (weight.numel() // weight.shape[0], weight.shape[0]) else None
+
+
 def _flops(M, N, K, extra_mn=0):
     """algorithmic flops of an [M,K] x [K,N] product, booked with its bytes (operands + result (+ extra [M,N] streams))"""
     if not _PROFILE_FLOPS:
@@ -51,7 +111,7 @@ def _flops(M, N, K, extra_mn=0):
     return 2.0 * M * N * K
 
 
-def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False):
+def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False, wt=None):
     """dX[M,K] = dY[M,N] . W[N,K], optionally times act'(aux) in the GEMM epilogue (u3d_linear_dact): the input gradient
     THROUGH the activation that produced this layer's input (aux = its ReLU output / GELU pre-activation)."""
     M, N = dy.shape
@@ -59,8 +119,9 @@ def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False):
     dev = dy.device
     q = 32 if bf else 16                                # reduction-depth granule of the kernel
     if N % q == 0:
-        wt = torch.empty(K, N, dtype=torch.float32, device=dev)
-        L.call('u3d_transpose', L.ptr(weight.contiguous()), L.ptr(wt), N, K, L.stream())
+        if wt is None:              # (``wt``: the copy transposed_weights() made for this forward pass)
+            wt = torch.empty(K, N, dtype=torch.float32, device=dev)
+            L.call('u3d_transpose', L.ptr(weight.contiguous()), L.ptr(wt), N, K, L.stream())
     else:                                               # tiny heads (N = 19, 8): pad the reduction dim with zero columns
         Np = (N + q - 1) // q * q
         wt = torch.zeros(K, Np, dtype=torch.float32, device=dev)
@@ -115,6 +176,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.bf = P.bf16()
+        ctx.wt = _wt_of(weight)
         return _gemm_nt(x, weight.contiguous(), bias, ctx.bf)
 
     @staticmethod
@@ -123,7 +185,7 @@ class _LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, weight, bf=ctx.bf)
+            dx = _input_grad(dy, weight, bf=ctx.bf, wt=ctx.wt)
         if ctx.needs_input_grad[1]:
             dw, db = _weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2], ctx.bf)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
@@ -159,6 +221,7 @@ class _MLPFn(torch.autograd.Function):
         z = torch.empty(M, d_out, dtype=torch.float32, device=dev)
         w1c, w2c = w1.contiguous(), w2.contiguous()
         ctx.bf = P.bf16()
+        ctx.wt1, ctx.wt2 = _wt_of(w1c), _wt_of(w2c)
         ctx.fused = act != ACT_GELU or FUSE_GELU
         if M and not ctx.fused:                      # plain GEMM (+bias) -> GELU pass -> plain GEMM
             h = _gemm_nt(x, w1c, b1, ctx.bf)
@@ -180,14 +243,14 @@ class _MLPFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dw2, db2 = _weight_grad(dz, a, ctx.bias[1] and need[4], ctx.bf) if need[3] else (None, None)
         if ctx.fused:
-            dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf)
+            dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf, wt=ctx.wt2)
         else:
-            da = _input_grad(dz, w2, bf=ctx.bf)
+            da = _input_grad(dz, w2, bf=ctx.bf, wt=ctx.wt2)
             dh = torch.empty_like(da)
             if da.numel():
                 L.call('u3d_gelu_bwd', L.ptr(da), L.ptr(h), L.ptr(dh), da.numel(), L.stream())
         dw1, db1 = _weight_grad(dh, x, ctx.bias[0] and need[2], ctx.bf) if need[1] else (None, None)
-        dx = _input_grad(dh, w1, bf=ctx.bf) if need[0] else None
+        dx = _input_grad(dh, w1, bf=ctx.bf, wt=ctx.wt1) if need[0] else None
         return dx, dw1, db1, dw2, db2, None
 
 

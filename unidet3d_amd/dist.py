@@ -20,6 +20,11 @@ import torch.distributed as dist
 _FORCE = False
 
 
+def _join_side_streams():
+    from .sparse import join_wgrad_stream
+    join_wgrad_stream()
+
+
 def force_collectives(on: bool = True) -> bool:
     """Issue every collective of the data-parallel path even when the process group has ONE rank (SyncBatchNorm sums, gradient
     buckets, the buckets' own communicator).  A single-GPU box can then drive the exact RCCL call sequence of an N-GPU run --
@@ -72,6 +77,7 @@ class FlatGradBucket:
             p.grad = None
 
     def pack(self):
+        _join_side_streams()
         src, dst = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -145,6 +151,7 @@ class FlatGradBucket:
             self._next -= 1
 
     def _launch(self, b, sync: bool = False):
+        _join_side_streams()                   # weight gradients still running on the side stream (sparse.set_wgrad_overlap(2))
         src, dst = [], []
         for i in range(b['lo'], b['hi']):
             p, v = self.params[i], self.views[i]

@@ -25,6 +25,7 @@ from . import _lib as L
 from . import precision as P
 from . import account
 from .dense import LayerNorm, linear, ln_linear, mlp
+from .ops import cat_views
 from .registry import MODELS
 
 
@@ -260,8 +261,10 @@ class UniDet3DEncoder(nn.Module):
         cu = L.h2d([0] + list(itertools.accumulate(sizes)), torch.int32, dev)
         max_len = max(sizes) if sizes else 0
         sum_sq = sum(s * s for s in sizes)
-        centers_packed = torch.cat(sp_centers) if len(sp_centers) > 1 else sp_centers[0]
-        x0 = torch.cat(x) if len(x) > 1 else x[0]
+        # the per-scene lists are row slices of one packed tensor when they come from UniDet3D.extract_feat: use it as it is (no cat
+        # kernel forward, no 8 x (zero-fill + copy) + 7 adds backward)
+        centers_packed = cat_views(sp_centers)
+        x0 = cat_views(x)
         feats = mlp(x0, self.input_proj[0].weight, self.input_proj[0].bias, self.input_proj[2].weight, self.input_proj[2].bias, 'relu')
         layer_feats = [feats]
         for i in range(self.num_layers):

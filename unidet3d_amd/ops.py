@@ -234,3 +234,24 @@ def trim_boxes_by_superpoints(points: torch.Tensor, sp_offsets: torch.Tensor, sp
                L.ptr(b), nb, int(b.shape[1]), float(low_sp_thr), float(up_sp_thr), L.ptr(mm), L.stream())
     mn, mx = mm[:, :3], mm[:, 3:]
     return torch.cat(((mx + mn) / 2, mx - mn), dim=1)
+
+
+def cat_views(ts):
+    """``torch.cat(ts)`` -- without the copy (and without the slice / cat nodes in the autograd graph) when ``ts`` are the consecutive row
+    slices of ONE contiguous tensor that together cover it, which is how the per-scene lists of the reference's interface are made
+    here (``pooled[o_i:o_{i+1}]``): the base tensor itself is returned.  Anything else is concatenated."""
+    ts = list(ts)
+    if len(ts) == 1:
+        return ts[0]
+    base = getattr(ts[0], '_base', None)
+    if base is not None and base.is_contiguous() and base.dim() >= 1:
+        off, ok = base.storage_offset(), True
+        for t in ts:
+            if t._base is not base or not t.is_contiguous() or t.dim() != base.dim() or t.shape[1:] != base.shape[1:] or t.storage_offset() != off:
+                ok = False
+                break
+            off += t.numel()
+        if ok and off == base.storage_offset() + base.numel():
+            return base
+    return torch.cat(ts)
+

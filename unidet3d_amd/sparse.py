@@ -385,16 +385,45 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
     return dst
 
 
-# opt-in: weight gradient on a side stream next to the input gradient.  Measured +0.9 % step throughput (44.09 -> 43.71 ms);
-# off by default because overlapped kernels stretch each other and the per-kernel HIP-event timings (bench roofline) with them
-_WGRAD_SIDE_STREAM = os.environ.get('U3D_WGRAD_SIDE_STREAM', '0') == '1'
+# Weight gradients on a side stream (U3D_WGRAD_SIDE_STREAM / set_wgrad_overlap):
+#   0  off: every kernel of the backward pass on the one stream;
+#   1  the weight gradient of a layer runs next to that layer's input gradient and is joined before the layer's backward returns
+#      (round 2: +0.9 % step throughput);
+#   2  decoupled: the weight gradients form their own chain on the side stream -- each waits for the gradient it reads, nothing on the
+#      main stream waits for them until the backward pass ends (an autograd-engine callback joins the streams; FlatGradBucket joins
+#      before it copies a bucket).  Nothing downstream of a layer needs its dW, so the dgrad / batch-norm chain never stalls on a
+#      weight-gradient kernel, and the small-level kernels of both chains (a few dozen workgroups each) share the chip.
+# Overlapped kernels stretch each other, so the bench's per-family HIP-event timings are taken with the overlap off.
+_WGRAD_OVERLAP = int(os.environ.get('U3D_WGRAD_SIDE_STREAM', '0') or 0)
 _SIDE = {}
+_JOIN_PENDING = {}
+
+
+def set_wgrad_overlap(mode: int) -> int:
+    global _WGRAD_OVERLAP
+    prev, _WGRAD_OVERLAP = _WGRAD_OVERLAP, int(mode)
+    return prev
 
 
 def _side_stream(device):
     if device not in _SIDE:
         _SIDE[device] = torch.cuda.Stream(device=device)
     return _SIDE[device]
+
+
+def join_wgrad_stream(device=None):
+    """Make the current stream wait for the weight-gradient kernels queued on the side stream (mode 2).  Called by the autograd
+    callback at the end of a backward pass and by anything that reads ``.grad`` of a convolution weight earlier than that
+    (``dist.FlatGradBucket`` before it copies a bucket).  A no-op when nothing is pending."""
+    for dev in ([device] if device is not None else list(_JOIN_PENDING)):
+        if _JOIN_PENDING.pop(dev, None):
+            torch.cuda.current_stream(dev).wait_stream(_SIDE[dev])
+
+
+def _queue_join(device):
+    if not _JOIN_PENDING.get(device):
+        _JOIN_PENDING[device] = True
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(device))
 
 
 _PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops
@@ -458,7 +487,7 @@ class _SparseConvFn(torch.autograd.Function):
             if _PROFILE_FLOPS:
                 account.add('conv_wgrad', flops, 4.0 * (src.shape[0] * cin + n_dy * cout) + 8.0 * rb.total_pairs + 4.0 * rb.K * cin * cout)
             Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
-            ws = L.scratch(L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout), weight.device)
+            ws_bytes = L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout)
             ts = rb.tile_starts(role, Tw)
             # the weight-gradient walk is bound by its row gathers: bf16 operands pay off only where the matrix
             # work is a visible share -- measured (tools/prof_wgrad.py): 32x32 channels 179 us fp32 vs 221 us bf16, 64x64 150 vs 104
@@ -468,15 +497,23 @@ class _SparseConvFn(torch.autograd.Function):
                 # both operands exist as bf16 rows: whole-row gathers, LDS transpose reads, bf16 MFMAs over 32 pairs (spconv_wgrad_rows.hip)
                 wg, xw, gw = 'u3d_spconv_wgrad_rows', ctx.src_shadow, dout_shadow
 
-            # the weight gradient and the input gradient of a layer are independent: the former runs on a side stream so
-            # the two kernels (neither fills the machine alone) share the GPU; joined before the layer's backward returns
-            if _WGRAD_SIDE_STREAM and ctx.needs_input_grad[0]:
+            overlap = _WGRAD_OVERLAP if ctx.needs_input_grad[0] else 0       # (the first convolution has no input gradient to run next to)
+            if overlap == 2 and not (weight.is_leaf and weight.grad is None):
+                overlap = 1      # autograd will ADD dw to an existing .grad (or feed it to another node) on this stream right away: join first
+            if overlap:
                 side = _side_stream(weight.device)
-                side.wait_stream(torch.cuda.current_stream())
+                side.wait_stream(torch.cuda.current_stream())                 # dout (and everything before it) is complete
                 with torch.cuda.stream(side):
+                    ws = L.scratch(ws_bytes, weight.device)                   # the side stream's own workspace (keyed by stream)
                     L.call(wg, L.ptr(xw), xw.shape[0], L.ptr(gw), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                            rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
+                for t in (xw, gw, dw, ts, rx, rg):                             # blocks must not be recycled while the side kernel uses them
+                    t.record_stream(side)
+                if overlap == 2:
+                    _queue_join(weight.device)
+                    side = None
             else:
+                ws = L.scratch(ws_bytes, weight.device)
                 L.call(wg, L.ptr(xw), xw.shape[0], L.ptr(gw), L.ptr(rx), L.ptr(rg), L.ptr(ts),
                        rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
         if ctx.needs_input_grad[0]:

@@ -36,6 +36,13 @@ class DepthInstance3DBoxes:
         self.tensor = t
         self.with_yaw = with_yaw
         self.box_dim = box_dim
+        self.gt_rows = None
+
+    def cache_gt_rows(self):
+        """(gravity centre, size[, heading]) rows -- what the criterion packs per scene (criterion._gt_boxes) -- computed once for
+        all boxes; row slices of this object (``__getitem__`` with a slice) carry the matching row views."""
+        self.gt_rows = torch.cat((self.gravity_center, self.tensor[:, 3:] if self.with_yaw else self.tensor[:, 3:6]), dim=1)
+        return self.gt_rows
 
     @property
     def gravity_center(self):
@@ -52,12 +59,14 @@ class DepthInstance3DBoxes:
         b = DepthInstance3DBoxes.__new__(DepthInstance3DBoxes)
         b.tensor = self.tensor[idx].reshape(-1, self.box_dim)
         b.with_yaw, b.box_dim = self.with_yaw, self.box_dim
+        b.gt_rows = self.gt_rows[idx] if self.gt_rows is not None and isinstance(idx, slice) else None
         return b
 
     def to(self, device):
         b = DepthInstance3DBoxes.__new__(DepthInstance3DBoxes)
         b.tensor = self.tensor.to(device)
         b.with_yaw, b.box_dim = self.with_yaw, self.box_dim
+        b.gt_rows = None
         return b
 
 

@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import ops
+from . import dense, ops
 from .registry import MODELS
 from .sparse import SparseBatchNorm, SparseConvTensor, SparseSequential, SubMConv3d
 from .structures import DepthInstance3DBoxes, InstanceData_
@@ -235,12 +235,17 @@ class UniDet3D(nn.Module):
                 box_off.append(box_off[-1] + len(ds.gt_instances_3d.labels_3d))
             if box_off[-1] > 0:
                 boxes_all = ops.instance_boxes(vb, torch.cat(ids) if B > 1 else ids[0], box_off[-1], self.voxel_size)
+        all_boxes = None
+        if boxes_all is not None:
+            # ONE box object for the batch (the bottom-centre round trip of DepthInstance3DBoxes is element-wise: the same bits as per
+            # scene) plus the (gravity centre, size) rows the criterion reads, computed once; the per-scene objects are row views
+            all_boxes = DepthInstance3DBoxes(boxes_all, with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5))
+            all_boxes.cache_gt_rows()
         for i, ds in enumerate(batch_data_samples):
             inst = ds.gt_instances_3d
             dataset = dsets[i]
-            if boxes_all is not None:
-                inst.bboxes_3d = DepthInstance3DBoxes(boxes_all[box_off[i]:box_off[i + 1]], with_yaw=False, box_dim=6,
-                                                      origin=(0.5, 0.5, 0.5))
+            if all_boxes is not None:
+                inst.bboxes_3d = all_boxes[box_off[i]:box_off[i + 1]]
             elif self.bbox_by_mask[dataset]:
                 if vb.coord_src is not None:
                     pts = (batch_inputs_dict['elastic_coords'][i] - vb.stats[i, :3]) * self.voxel_size
@@ -302,9 +307,10 @@ class UniDet3D(nn.Module):
         vb, plan, batch_offsets, names = prep['vb'], prep['plan'], prep['batch_offsets'], prep['names']
         sp_gt_instances, x = prep['sp_gt_instances'], prep['x']
         self._vb = vb
-        feats = self.extract_feat(x, plan, vb.inverse, batch_offsets)
-        queries, sp_centers_q, sp_gt_instances = self._select_queries(feats, sp_gt_instances, query_perms)
-        out = self.decoder(queries, sp_centers_q, names)
+        with dense.transposed_weights(self):        # every [K, N] weight copy the backward pass needs, in one launch
+            feats = self.extract_feat(x, plan, vb.inverse, batch_offsets)
+            queries, sp_centers_q, sp_gt_instances = self._select_queries(feats, sp_gt_instances, query_perms)
+            out = self.decoder(queries, sp_centers_q, names)
         return self.criterion(out, sp_gt_instances, names)
 
     # ------------------------------------------------------------------ inference up to the decoder (unidet3d.py:411-462)

@@ -66,8 +66,8 @@ def parse():
                     help='adamw = configs/unidet3d_1xb8_scannet.py:710-713 (the reported config); sgd = diagnostic (DESIGN.md section 2: '
                          "AdamW's first updates are lr*sign(g), which turns rounding-level gradient differences into different trajectories)")
     ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2],
-                    help="sparse-conv weight gradients on a side stream (unidet3d_amd/sparse.py set_wgrad_overlap): 0 off, 1 next to the layer's "
-                         'input gradient, 2 a chain of their own joined at the end of backward; default: the library setting')
+                    help="weight gradients on a side stream (unidet3d_amd/sparse.py set_wgrad_overlap): 0 off, 1 next to the layer's "
+                         'input gradient, 2 (default here) a chain of their own joined at the end of backward')
     ap.add_argument('--no-prefetch', action='store_true',
                     help="build the next step's voxel grid / rulebooks at the start of that step instead of on a side stream")
     return ap.parse_args()
@@ -257,8 +257,9 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
     from unidet3d_amd.synthetic import make_scene
 
     precision.set_operand_dtype(dtype)
-    if getattr(args, 'wgrad_overlap', None) is not None:
-        sparse.set_wgrad_overlap(args.wgrad_overlap)
+    # weight gradients (sparse conv + Linear) as a stream chain of their own, joined when backward ends: the training loop's choice,
+    # like the front-end prefetch; same kernels, bit-identical gradients (tests/test_gpu_gradients.py).  Same-box A/B: +2.7 % (r5)
+    sparse.set_wgrad_overlap(2 if getattr(args, 'wgrad_overlap', None) is None else args.wgrad_overlap)
     if fp32_math or getattr(args, 'fp32_math', None):
         precision.set_fp32_math(fp32_math or args.fp32_math)
     x3 = dtype == 'fp32' and precision.get_fp32_math() == 'bf16x3'
@@ -421,7 +422,9 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
                                               'fp32-level error; --fp32-math mfma = native fp32 MFMAs); ' if x3 else 'fp32 (native fp32 MFMAs); ')) +
                                'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else f'+clip+{args.optimizer}')
                                + ('' if args.no_prefetch else "; each step's voxelise+rulebook part is queued on a side stream during "
-                                  "the previous step's backward"),
+                                  "the previous step's backward")
+                               + ({0: '', 1: "; conv weight gradients on a side stream next to each layer's input gradient",
+                                   2: '; weight-gradient kernels (sparse conv + Linear) run as a side-stream chain joined at the end of backward'}[overlap_was]),
                    'front_prefetch': not args.no_prefetch, 'wgrad_overlap': overlap_was, 'fp32_math': ('bf16x3' if x3 else 'mfma') if not bf else None,
                    'global_batch': batch * world, 'points_per_scene': args.points if wl == 'cfg2' else n_points_total // max(batch, 1),
                    'points_per_gpu': n_points_total,

@@ -169,12 +169,40 @@ def _weight_grad(dy, x, want_bias, bf=False):
     return dw, db
 
 
+def _weight_grad_overlapped(dy, x, want_bias, bf, weight, bias):
+    """``_weight_grad`` on the weight-gradient side stream when sparse.set_wgrad_overlap(2) is on (nothing downstream of a Linear needs
+    its dW: the GEMM joins the sparse convolutions' weight-gradient chain and the dX chain goes on without it).  Only for leaf
+    parameters without an existing .grad -- autograd then just stores the tensor; anything else is computed in line."""
+    from . import sparse
+    ok = sparse._WGRAD_OVERLAP == 2 and _OVERLAP_TN and dy.is_cuda and weight.is_leaf and weight.grad is None and \
+        (bias is None or (bias.is_leaf and bias.grad is None))
+    if not ok:
+        return _weight_grad(dy, x, want_bias, bf)
+    dev = dy.device
+    main = torch.cuda.current_stream(dev)
+    side = sparse._side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw, db = _weight_grad(dy, x, want_bias, bf)
+    dy.record_stream(side)
+    x.record_stream(side)
+    for t in (dw, db):                      # allocated from the side stream's pool, consumed on the main stream after the join
+        if t is not None:
+            t.record_stream(main)
+    sparse._queue_join(dev)
+    return dw, db
+
+
+_OVERLAP_TN = os.environ.get('U3D_OVERLAP_TN', '1') != '0'
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.bf = P.bf16()
         ctx.wt = _wt_of(weight)
         return _gemm_nt(x, weight.contiguous(), bias, ctx.bf)
@@ -184,10 +212,10 @@ class _LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = db = None
+        if ctx.needs_input_grad[1]:           # first: on the side stream it then waits for dy only, not for the dX product below
+            dw, db = _weight_grad_overlapped(dy, x, ctx.has_bias and ctx.needs_input_grad[2], ctx.bf, weight, ctx.bias_ref)
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dy, weight, bf=ctx.bf, wt=ctx.wt)
-        if ctx.needs_input_grad[1]:
-            dw, db = _weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2], ctx.bf)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db
@@ -234,6 +262,7 @@ class _MLPFn(torch.autograd.Function):
                    L.ptr(h), L.ptr(a), L.ptr(z), M, d_in, hid, d_out, 1.0 if _PROFILE_FLOPS else 0.0, L.stream())
         ctx.save_for_backward(x, w1c, w2c, a, h)
         ctx.act, ctx.bias = act, (b1 is not None, b2 is not None)
+        ctx.bias_refs = (b1, b2)
         return z
 
     @staticmethod
@@ -241,7 +270,7 @@ class _MLPFn(torch.autograd.Function):
         x, w1, w2, a, h = ctx.saved_tensors
         dz = dz.contiguous()
         need = ctx.needs_input_grad
-        dw2, db2 = _weight_grad(dz, a, ctx.bias[1] and need[4], ctx.bf) if need[3] else (None, None)
+        dw2, db2 = _weight_grad_overlapped(dz, a, ctx.bias[1] and need[4], ctx.bf, w2, ctx.bias_refs[1]) if need[3] else (None, None)
         if ctx.fused:
             dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf, wt=ctx.wt2)
         else:
@@ -249,7 +278,7 @@ class _MLPFn(torch.autograd.Function):
             dh = torch.empty_like(da)
             if da.numel():
                 L.call('u3d_gelu_bwd', L.ptr(da), L.ptr(h), L.ptr(dh), da.numel(), L.stream())
-        dw1, db1 = _weight_grad(dh, x, ctx.bias[0] and need[2], ctx.bf) if need[1] else (None, None)
+        dw1, db1 = _weight_grad_overlapped(dh, x, ctx.bias[0] and need[2], ctx.bf, w1, ctx.bias_refs[0]) if need[1] else (None, None)
         dx = _input_grad(dh, w1, bf=ctx.bf, wt=ctx.wt1) if need[0] else None
         return dx, dw1, db1, dw2, db2, None
 

@@ -255,3 +255,18 @@ def cat_views(ts):
             return base
     return torch.cat(ts)
 
+
+def offset_ids(ids, biases, keep_negative: bool = False) -> torch.Tensor:
+    """``torch.cat([ids[i] + biases[i] for i])`` for per-scene id tensors (superpoint / instance ids made batch-global) in a handful of
+    launches whatever the number of scenes: one cat, one H2D copy of (biases, lengths), one repeat_interleave, one add.
+    ``keep_negative``: ids < 0 ("no instance") stay as they are."""
+    if len(ids) == 1:
+        t = ids[0]
+        if not biases[0]:
+            return t
+        return torch.where(t >= 0, t + biases[0], t) if keep_negative else t + biases[0]
+    flat = torch.cat(ids)
+    b, n = L.h2d_pack([(list(biases), torch.int64), ([int(t.shape[0]) for t in ids], torch.int64)], flat.device)
+    per = torch.repeat_interleave(b, n, output_size=int(flat.shape[0]))
+    return torch.where(flat >= 0, flat + per, flat) if keep_negative else flat + per
+

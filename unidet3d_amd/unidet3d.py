@@ -199,11 +199,11 @@ class UniDet3D(nn.Module):
         vb = self._vb
         sp_list, batch_offsets, bias = [], [0], 0
         for ds in batch_data_samples:
-            sp = ds.gt_pts_seg.sp_pts_mask.to(points[0].device) + bias
-            bias = bias + int(ds.n_superpoints) if hasattr(ds, 'n_superpoints') else int(sp.max().item()) + 1
+            sp = ds.gt_pts_seg.sp_pts_mask.to(points[0].device)
+            bias = bias + int(ds.n_superpoints) if hasattr(ds, 'n_superpoints') else bias + int(sp.max().item()) + 1
             batch_offsets.append(bias)
             sp_list.append(sp)
-        plan = ops.PoolPlan(vb, torch.cat(sp_list) if B > 1 else sp_list[0], bias)
+        plan = ops.PoolPlan(vb, ops.offset_ids(sp_list, batch_offsets[:-1]), bias)      # batch-global superpoint ids
         if elastic is not None and training:
             # unidet3d.py:295-299: the training frame is (elastic - scene min) * voxel_size (ElasticTransfrom always provides
             # elastic_coords in the reference's train pipeline); the mean commutes with the scaling up to rounding
@@ -230,11 +230,10 @@ class UniDet3D(nn.Module):
             # GT boxes of every instance of the batch in one pass over the points (u3d_segment_minmax_xyz)
             ids = []
             for ds in batch_data_samples:
-                m = ds.gt_pts_seg.pts_instance_mask.to(vb.points.device)
-                ids.append(torch.where(m >= 0, m + box_off[-1], m))
+                ids.append(ds.gt_pts_seg.pts_instance_mask.to(vb.points.device))
                 box_off.append(box_off[-1] + len(ds.gt_instances_3d.labels_3d))
             if box_off[-1] > 0:
-                boxes_all = ops.instance_boxes(vb, torch.cat(ids) if B > 1 else ids[0], box_off[-1], self.voxel_size)
+                boxes_all = ops.instance_boxes(vb, ops.offset_ids(ids, box_off[:-1], keep_negative=True), box_off[-1], self.voxel_size)
         all_boxes = None
         if boxes_all is not None:
             # ONE box object for the batch (the bottom-centre round trip of DepthInstance3DBoxes is element-wise: the same bits as per

@@ -257,16 +257,16 @@ def cat_views(ts):
 
 
 def offset_ids(ids, biases, keep_negative: bool = False) -> torch.Tensor:
-    """``torch.cat([ids[i] + biases[i] for i])`` for per-scene id tensors (superpoint / instance ids made batch-global) in a handful of
-    launches whatever the number of scenes: one cat, one H2D copy of (biases, lengths), one repeat_interleave, one add.
-    ``keep_negative``: ids < 0 ("no instance") stay as they are."""
-    if len(ids) == 1:
-        t = ids[0]
-        if not biases[0]:
-            return t
-        return torch.where(t >= 0, t + biases[0], t) if keep_negative else t + biases[0]
-    flat = torch.cat(ids)
-    b, n = L.h2d_pack([(list(biases), torch.int64), ([int(t.shape[0]) for t in ids], torch.int64)], flat.device)
-    per = torch.repeat_interleave(b, n, output_size=int(flat.shape[0]))
-    return torch.where(flat >= 0, flat + per, flat) if keep_negative else flat + per
-
+    """``torch.cat([ids[i] + biases[i] for i])`` for per-scene int64 id tensors (superpoint / instance ids made batch-global) in a handful
+    of multi-tensor launches whatever the number of scenes.  ``keep_negative``: ids < 0 ("no instance") stay as they are:
+    id + bias * min(max(id + 1, 0), 1)."""
+    ids, biases = list(ids), [int(b) for b in biases]
+    if keep_negative:
+        live = torch._foreach_add(ids, 1)
+        torch._foreach_clamp_min_(live, 0)
+        torch._foreach_clamp_max_(live, 1)
+        torch._foreach_mul_(live, biases)
+        out = torch._foreach_add(live, ids)
+    else:
+        out = torch._foreach_add(ids, biases)
+    return torch.cat(out) if len(out) > 1 else out[0]

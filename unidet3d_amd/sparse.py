@@ -405,19 +405,29 @@ def set_wgrad_overlap(mode: int) -> int:
     return prev
 
 
+_N_SIDE = max(1, int(os.environ.get('U3D_SIDE_STREAMS', '1') or 1))      # weight-gradient chains (round-robin); A/B: tools, DESIGN.md 4.14
+_SIDE_RR = {}
+
+
 def _side_stream(device):
+    """next weight-gradient stream of ``device`` (round-robin over U3D_SIDE_STREAMS streams)"""
     if device not in _SIDE:
-        _SIDE[device] = torch.cuda.Stream(device=device)
-    return _SIDE[device]
+        _SIDE[device] = [torch.cuda.Stream(device=device) for _ in range(_N_SIDE)]
+        _SIDE_RR[device] = 0
+    i = _SIDE_RR[device]
+    _SIDE_RR[device] = (i + 1) % len(_SIDE[device])
+    return _SIDE[device][i]
 
 
 def join_wgrad_stream(device=None):
-    """Make the current stream wait for the weight-gradient kernels queued on the side stream (mode 2).  Called by the autograd
+    """Make the current stream wait for the weight-gradient kernels queued on the side stream(s) (mode 2).  Called by the autograd
     callback at the end of a backward pass and by anything that reads ``.grad`` of a convolution weight earlier than that
     (``dist.FlatGradBucket`` before it copies a bucket).  A no-op when nothing is pending."""
     for dev in ([device] if device is not None else list(_JOIN_PENDING)):
         if _JOIN_PENDING.pop(dev, None):
-            torch.cuda.current_stream(dev).wait_stream(_SIDE[dev])
+            cur = torch.cuda.current_stream(dev)
+            for st in _SIDE[dev]:
+                cur.wait_stream(st)
 
 
 def _queue_join(device):

@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 110
+#define U3D_ABI_VERSION 111
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -392,6 +392,15 @@ int u3d_transpose(const float* in /*[R,C]*/, float* out /*[C,R]*/, int R, int C,
 /* All transposed copies of a step in one launch: desc int64 [n_desc][5] = {src ptr ([R][C] floats), dst ptr ([C][R]), R, C, first
  * block}; a matrix takes ceil(R/32) * ceil(C/32) blocks, total_blocks = their sum (descriptors in ascending first-block order). */
 int u3d_transpose_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream);
+/* Pre-split W operands for the three-plane ("bf16x3") NT products.  u3d_weight_planes_batch: desc int64 [n_desc][4] = {src ptr (fp32,
+ * n8 * 8 values), dst ptr (bf16 [3][n8 * 8]: the three exact planes of every value, 8-element groups split exactly as the GEMM
+ * kernels split them in flight), n8, first block}; a matrix takes ceil(n8 / 256) blocks; one launch for every weight (and transposed
+ * copy) of a training step.  u3d_gemm_w_planes(p, p2): the NEXT NT entry point called on this host thread (u3d_gemm_nt,
+ * u3d_linear_act, u3d_linear_dact, u3d_gemm_nt_add, u3d_ln_linear; u3d_ffn_fwd takes p for W1 and p2 for W2) reads its W operand from
+ * these planes ([3][N][K] bf16, same N, K as its fp32 W, which must still be passed) when it runs the three-plane kernel; consumed by
+ * that call whatever kernel it picks; NULL = none.  Results are bit-identical with and without. */
+int u3d_weight_planes_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream);
+int u3d_gemm_w_planes(const void* planes, const void* planes2);
 
 /* =====================================================================================
  * K15 LayerNorm of the decoder (unidet3d/encoder.py:21,38-40,61,78-79,140,167) with the preceding residual add fused in.

@@ -258,3 +258,48 @@ def test_weight_gradients_on_the_side_stream_give_the_same_bits(operands):
     _, b2 = run(2, bucket=True)
     bad = [k for k in ref if not torch.equal(ref[k], b2[k])]
     assert not bad, ('bucket', len(bad), bad[:5])
+
+
+def test_presplit_weight_planes_and_batched_transposes_change_no_bit():
+    """dense.transposed_weights(): every Linear weight's [K, N] copy (one u3d_transpose_batch launch) and, for the three-plane fp32
+    products, the three bf16 planes of every weight and transposed copy (one u3d_weight_planes_batch launch; the NT kernels then load
+    their W operand pre-split, u3d_gemm_w_planes) -- against the same step with neither (per-launch transposes, in-kernel splits):
+    loss and every gradient identical to the bit, in both fp32 math modes."""
+    import unidet3d_amd  # noqa: F401
+    from unidet3d_amd import dense
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.config import build_model
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = _small_cfg()
+    cfg['decoder']['num_layers'] = 2
+    inputs, samples0 = make_batch_inputs([make_scene(90, n_points=9000), make_scene(91, n_points=7000)], DEV)
+
+    def run(planes, batch):
+        was = dense._W_PLANES
+        dense._W_PLANES = planes
+        model = fill_state_dict(build_model(cfg), tag0=3000, scale=0.06).to(DEV).train()
+        ctx_cls = dense.transposed_weights
+        if not batch:                                   # no context: every backward transposes for itself, no planes
+            class _Off:
+                def __init__(self, m): pass
+                def __enter__(self): return self
+                def __exit__(self, *a): return False
+            dense.transposed_weights = _Off
+        try:
+            loss = model.loss(inputs, copy.deepcopy(samples0))['det_loss']
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            dense.transposed_weights = ctx_cls
+            dense._W_PLANES = was
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    for math in ('bf16x3', 'mfma'):
+        with P.fp32_math(math):
+            ref_loss, ref = run(False, False)
+            for planes, batch in ((True, True), (False, True)):
+                loss, g = run(planes, batch)
+                assert torch.equal(loss, ref_loss), (math, planes, batch, float(loss), float(ref_loss))
+                bad = [k for k in ref if not torch.equal(ref[k], g[k])]
+                assert not bad, (math, planes, batch, len(bad), bad[:5])

@@ -103,13 +103,15 @@ PROTOTYPES = {
     'u3d_gemm_tn_ws_bytes': (_i64, [_i64, _i32, _i32]),
     'u3d_transpose': (_i32, [_vp, _vp, _i32, _i32, _vp]),
     'u3d_transpose_batch': (_i32, [_vp, _i32, _i64, _vp]),
+    'u3d_weight_planes_batch': (_i32, [_vp, _i32, _i64, _vp]),
+    'u3d_gemm_w_planes': (_i32, [_vp, _vp]),
     'u3d_attn_varlen_fwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_fwd_bf16': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 110         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 111         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

@@ -265,10 +265,14 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(const float* __restrict__ 
 #ifndef U3D_NTX_ABL
 #define U3D_NTX_ABL 0          // timing ablations (wrong results): 1 no MFMAs, 2 no split arithmetic, 4 no global loads in the loop, 8 no LDS stores in the loop
 #endif
-template <int TN, int EPI, int TM = GT>
+// WP: the W operand arrives ALREADY split -- `Wpl` = three bf16 planes [3][N][K] written once per training step for all weights
+// (planes_batch_k below: the same split3_x8 on the same 8-element groups, so the staged planes and the results are bit-identical) --
+// and the thread that stages a W row piece loads three 16-byte plane pieces instead of 32 bytes of fp32 and runs no split for it: a
+// third of the kernel's split arithmetic (13 VALU per pair of values, issued in the matrix pipe's time) at TM = 128, TN = 64.
+template <int TN, int EPI, int TM = GT, bool WP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ? 3 : 1))) void gemm_nt_x3_k(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                                     float* __restrict__ C, int64_t M, int N, int K, const float* __restrict__ aux,
-                                                    float* __restrict__ pre) {
+                                                    float* __restrict__ pre, const void* __restrict__ Wpl) {
     constexpr int NB = TN / 64, TA = TM / 64;
     __shared__ __attribute__((aligned(16))) __bf16 As[3][TM * GLH];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[3][TN * GLH];
@@ -285,7 +289,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
     // staging map: thread -> (row = tid>>2 (+64 j), 8 floats at column 8 * (tid&3))
     const int srow = tid >> 2, sc8 = tid & 3;
     const int vo = (srow * K + sc8 * 8) * 4, vstep = 64 * K * 4;
-    f32x4 ra[TA][2], rb[NB][2];
+    // pre-split W: plane q of rows n0 .. n0 + rows_b (loads past the last row return zeros, like the fp32 rows)
+    const char* wpl = reinterpret_cast<const char*>(Wpl);
+    const __amdgpu_buffer_rsrc_t rs_p0 = make_rsrc(wpl + ((int64_t)0 * N + n0) * K * 2, (int64_t)rows_b * K * 2);
+    const __amdgpu_buffer_rsrc_t rs_p1 = make_rsrc(wpl + ((int64_t)1 * N + n0) * K * 2, (int64_t)rows_b * K * 2);
+    const __amdgpu_buffer_rsrc_t rs_p2 = make_rsrc(wpl + ((int64_t)2 * N + n0) * K * 2, (int64_t)rows_b * K * 2);
+    const int vop = (srow * K + sc8 * 8) * 2, vstep_p = 64 * K * 2;
+    f32x4 ra[TA][2], rb[NB][WP ? 3 : 2];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < TA; ++j) {
@@ -294,8 +304,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            rb[j][0] = bload128(rs_b, vo + j * vstep, kt * (GKH * 4));
-            rb[j][1] = bload128(rs_b, vo + j * vstep + 16, kt * (GKH * 4));
+            if constexpr (WP) {
+                rb[j][0] = bload128(rs_p0, vop + j * vstep_p, kt * (GKH * 2));
+                rb[j][1] = bload128(rs_p1, vop + j * vstep_p, kt * (GKH * 2));
+                rb[j][2] = bload128(rs_p2, vop + j * vstep_p, kt * (GKH * 2));
+            } else {
+                rb[j][0] = bload128(rs_b, vo + j * vstep, kt * (GKH * 4));
+                rb[j][1] = bload128(rs_b, vo + j * vstep + 16, kt * (GKH * 4));
+            }
         }
     };
     bf16x8 pa[TA][3], pb[NB][3];
@@ -310,7 +326,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
 #pragma unroll
         for (int j = 0; j < TA; ++j) split3_x8(ra[j][0], ra[j][1], pa[j]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) split3_x8(rb[j][0], rb[j][1], pb[j]);
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (WP) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pb[j][q] = __builtin_bit_cast(bf16x8, rb[j][q]);
+            } else {
+                split3_x8(rb[j][0], rb[j][1], pb[j]);
+            }
+        }
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -865,6 +888,26 @@ __global__ __launch_bounds__(256) void transpose_batch_k(const TrDesc* __restric
         if (bx + j < Ccols && by + tx < R) d.dst[(int64_t)(bx + j) * R + by + tx] = tile[tx][j];
 }
 
+// The three bf16 planes of every weight (and of its transposed copy) a step's NT products take as their W operand, in ONE launch:
+// desc[i] = {src fp32 [n8 * 8], dst planes [3][n8 * 8] bf16, n8, first block}; thread = one group of 8 consecutive values, split
+// by the SAME split3_x8 the GEMM kernels run on the fly, so the pre-split operand is bit-identical to the in-kernel one.
+struct PlDesc { const float* src; bf16x8* dst; int64_t n8, block0; };
+__global__ __launch_bounds__(256) void planes_batch_k(const PlDesc* __restrict__ desc, int n_desc) {
+    int lo = 0, hi = n_desc;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[mid].block0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const PlDesc d = desc[lo];
+    const int64_t idx = ((int64_t)blockIdx.x - d.block0) * 256 + threadIdx.x;
+    if (idx >= d.n8) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(d.src + idx * 8), b = *reinterpret_cast<const f32x4*>(d.src + idx * 8 + 4);
+    bf16x8 out[3];
+    split3_x8(a, b, out);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) d.dst[q * d.n8 + idx] = out[q];
+}
+
 // 64 x 64 tiles while 128 x 128 ones would be fewer than 16 (every decoder weight except the FFN's 1024 x 256)
 static int tn_tile(int N, int K) { return ceil_div(N, GT) * ceil_div(K, GT) < 16 ? 64 : GT; }
 static int tn_splits(int64_t M, int N, int K, int T, bool bf) {
@@ -886,7 +929,7 @@ static int tn_splits(int64_t M, int N, int K, int T, bool bf) {
 // GEMMs 6.71 ms with 128x64 everywhere, 6.37 ms with 64x64 everywhere -> the overhead of the small tile is small: 4 % / 8 %.
 template <int EPI>
 static void launch_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, const float* aux, float* pre,
-                      bool bf16_operands, bool x3, hipStream_t s) {
+                      bool bf16_operands, bool x3, hipStream_t s, const void* wplanes = nullptr) {
     static const int force = [] { const char* e = getenv("U3D_NT_TILE"); return e ? atoi(e) : 0; }();       // 1 / 2 / 3 = 128x128 / 128x64 / 64x64
     const int tm[3] = {128, 128, 64}, tn[3] = {128, 64, 64};
     const double over[3] = {1.0, 1.04, 1.08};
@@ -909,16 +952,28 @@ static void launch_nt(const float* A, const float* W, const float* bias, float* 
     else if (best == 1) hipLaunchKernelGGL((KERNEL<64, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);            \
     else hipLaunchKernelGGL((KERNEL<64, EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
     if (bf16_operands) { U3D_NT_LAUNCH(gemm_nt_bf16_k) }
-    else if (x3) {
-        if (best == 1) hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 128>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
-        else hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre);
+    else if (x3 && wplanes) {
+        if (best == 1) hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 128, true>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre, wplanes);
+        else hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 64, true>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre, wplanes);
+    } else if (x3) {
+        if (best == 1) hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 128, false>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre, (const void*)nullptr);
+        else hipLaunchKernelGGL((gemm_nt_x3_k<64, EPI, 64, false>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K, aux, pre, (const void*)nullptr);
     } else { U3D_NT_LAUNCH(gemm_nt_k) }
 #undef U3D_NT_LAUNCH
 }
 
 // epi: 0..4 (see nt_epilogue); + 8: bf16 MFMA operands (fp32 data in HBM, fp32 accumulation)
+// The pre-split planes of the NEXT launch's W operand (u3d_gemm_w_planes): per host thread, consumed (and cleared) by the next NT
+// entry point called on that thread -- the caller sets them immediately before the call they belong to.
+static thread_local const void* g_wplanes[2] = {nullptr, nullptr};
+static const void* take_wplanes(int i) {
+    const void* p = g_wplanes[i];
+    g_wplanes[i] = nullptr;
+    return p;
+}
+
 static int gemm_nt_epi(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, int epi, const float* aux,
-                       float* pre, double flops_hint, hipStream_t s) {
+                       float* pre, double flops_hint, hipStream_t s, const void* wplanes = nullptr) {
     const bool bf = (epi & 8) != 0;
     epi &= 7;
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 5 || (epi == 2 && !pre) || (epi >= 3 && !aux)) return U3D_EINVAL;
@@ -927,12 +982,12 @@ static int gemm_nt_epi(const float* A, const float* W, const float* bias, float*
     ProfScope prof(U3D_K_GEMM, s, flops_hint);
     if ((int64_t)GT * K * 4 >= 0x7fffffffLL || (int64_t)GT * N * 4 >= 0x7fffffffLL) { set_error("gemm_nt: N=%d / K=%d too large for 32-bit tile offsets", N, K); return U3D_EUNSUPPORTED; }
     switch (epi) {
-        case 0: launch_nt<0>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
-        case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
-        case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
-        case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
-        case 4: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
-        default: launch_nt<5>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s); break;
+        case 0: launch_nt<0>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s, wplanes); break;
+        case 1: launch_nt<1>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s, wplanes); break;
+        case 2: launch_nt<2>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s, wplanes); break;
+        case 3: launch_nt<3>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s, wplanes); break;
+        case 4: launch_nt<4>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s, wplanes); break;
+        default: launch_nt<5>(A, W, bias, C, M, N, K, aux, pre, bf, x3, s, wplanes); break;
     }
     return check_launch("gemm_nt");
 }
@@ -946,7 +1001,9 @@ extern "C" {
 
 int u3d_gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, double flops_hint,
                 u3d_stream_t stream) {
-    return gemm_nt_epi(A, W, bias, C, M, N, K, 0, nullptr, nullptr, flops_hint, (hipStream_t)stream);
+    const void* wp = take_wplanes(0);
+    take_wplanes(1);
+    return gemm_nt_epi(A, W, bias, C, M, N, K, 0, nullptr, nullptr, flops_hint, (hipStream_t)stream, wp);
 }
 
 // `act` of the three entry points below: 0 none, 1 ReLU, 2 GELU; + U3D_BF16_OPERANDS (16) selects the bf16-operand kernels
@@ -954,42 +1011,53 @@ int u3d_linear_act(const float* X, const float* W, const float* bias, int act, f
                    double flops_hint, u3d_stream_t stream) {
     const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
     act &= ~U3D_BF16_OPERANDS;
+    const void* wp = take_wplanes(0);
+    take_wplanes(1);
     if (act < 0 || act > 2) return U3D_EINVAL;
-    return gemm_nt_epi(X, W, bias, Y, M, N, K, act | bf, nullptr, pre, flops_hint, (hipStream_t)stream);
+    return gemm_nt_epi(X, W, bias, Y, M, N, K, act | bf, nullptr, pre, flops_hint, (hipStream_t)stream, wp);
 }
 
 int u3d_linear_dact(const float* dY, const float* Wt, const float* aux, int act, float* dX, int64_t M, int N, int K, double flops_hint,
                     u3d_stream_t stream) {
     const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
     act &= ~U3D_BF16_OPERANDS;
+    const void* wp = take_wplanes(0);
+    take_wplanes(1);
     if (act < 0 || act > 2) return U3D_EINVAL;
-    return gemm_nt_epi(dY, Wt, nullptr, dX, M, N, K, (act == 0 ? 0 : act + 2) | bf, aux, nullptr, flops_hint, (hipStream_t)stream);
+    return gemm_nt_epi(dY, Wt, nullptr, dX, M, N, K, (act == 0 ? 0 : act + 2) | bf, aux, nullptr, flops_hint, (hipStream_t)stream, wp);
 }
 
 int u3d_gemm_nt_add(const float* A, const float* W, const float* addend, int flags, float* C, int64_t M, int N, int K, double flops_hint,
                     u3d_stream_t stream) {
-    return gemm_nt_epi(A, W, nullptr, C, M, N, K, 5 | ((flags & U3D_BF16_OPERANDS) ? 8 : 0), addend, nullptr, flops_hint, (hipStream_t)stream);
+    const void* wp = take_wplanes(0);
+    take_wplanes(1);
+    return gemm_nt_epi(A, W, nullptr, C, M, N, K, 5 | ((flags & U3D_BF16_OPERANDS) ? 8 : 0), addend, nullptr, flops_hint, (hipStream_t)stream, wp);
 }
 
 int u3d_ln_linear(const float* X, const float* RES, const float* gamma, const float* beta, float eps, float* SUM, float* NQ, float* STATS,
                   const float* W, const float* bias, int act, float* PRE, float* Y, int64_t M, int C, int N, double flops_hint,
                   u3d_stream_t stream) {
+    const void* wp = take_wplanes(0);
+    take_wplanes(1);
     if (!NQ || !Y || !W) return U3D_EINVAL;
     int rc = u3d_layer_norm_fwd(X, RES, gamma, beta, M, C, eps, SUM, NQ, STATS, stream);
     if (rc || M == 0) return rc;
+    g_wplanes[0] = wp;
     return u3d_linear_act(NQ, W, bias, act, PRE, Y, M, N, C, flops_hint, stream);
 }
 
 int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, int act, float* H, float* A, float* Z,
                 int64_t M, int d_in, int hid, int d_out, double flops_hint, u3d_stream_t stream) {
+    const void* wp1 = take_wplanes(0);
+    const void* wp2 = take_wplanes(1);
     const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
     act &= ~U3D_BF16_OPERANDS;
     if (act != 1 && act != 2) return U3D_EINVAL;
     if (!A || !Z) return U3D_EINVAL;
     const double f1 = flops_hint > 0 ? 2.0 * M * d_in * hid : 0.0, f2 = flops_hint > 0 ? 2.0 * M * hid * d_out : 0.0;
-    int rc = gemm_nt_epi(X, W1, b1, A, M, hid, d_in, act | bf, nullptr, H, f1, (hipStream_t)stream);
+    int rc = gemm_nt_epi(X, W1, b1, A, M, hid, d_in, act | bf, nullptr, H, f1, (hipStream_t)stream, wp1);
     if (rc) return rc;
-    return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, bf, nullptr, nullptr, f2, (hipStream_t)stream);
+    return gemm_nt_epi(A, W2, b2, Z, M, d_out, hid, bf, nullptr, nullptr, f2, (hipStream_t)stream, wp2);
 }
 
 // three-plane form (gemm_tn_x3_k): 128 x 64 tiles where gemm_tn_k takes 128 x 128 ones, 64 x 64 otherwise
@@ -1076,6 +1144,18 @@ int u3d_transpose(const float* in, float* out, int R, int C, u3d_stream_t stream
     if (!in || !out || R <= 0 || C <= 0) return U3D_EINVAL;
     hipLaunchKernelGGL(transpose_k, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
     return check_launch("transpose");
+}
+
+int u3d_weight_planes_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream) {
+    if (!desc || n_desc <= 0 || total_blocks <= 0 || total_blocks >= 0x7fffffffLL) return U3D_EINVAL;
+    hipLaunchKernelGGL(planes_batch_k, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PlDesc*)desc, n_desc);
+    return check_launch("weight_planes_batch");
+}
+
+int u3d_gemm_w_planes(const void* planes, const void* planes2) {
+    g_wplanes[0] = planes;
+    g_wplanes[1] = planes2;
+    return U3D_OK;
 }
 
 int u3d_transpose_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream) {

@@ -24,8 +24,9 @@ def _pad_k(t, mult):
     return t if k % mult == 0 else torch.nn.functional.pad(t, (0, mult - k % mult))
 
 
-def _gemm_nt(a, w, bias, bf=False):
-    """a [M,K] . w[N,K]^T (+ bias); ``bf``: bf16 MFMA operands (K is zero-padded to a multiple of 32 when needed)."""
+def _gemm_nt(a, w, bias, bf=False, planes=None):
+    """a [M,K] . w[N,K]^T (+ bias); ``bf``: bf16 MFMA operands (K is zero-padded to a multiple of 32 when needed);
+    ``planes``: the pre-split planes of ``w`` (three-plane products only)."""
     M = a.shape[0]
     N = w.shape[0]
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
@@ -36,6 +37,7 @@ def _gemm_nt(a, w, bias, bf=False):
                    _flops(M, N, a.shape[1]), L.stream())
         else:
             K = a.shape[1]
+            _use_planes(planes)
             L.call('u3d_gemm_nt', L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(c), M, N, K, _flops(M, N, K), L.stream())
     return c
 
@@ -84,6 +86,22 @@ class transposed_weights:
             desc = L.h2d(rows, torch.int64, dev)
             L.call('u3d_transpose_batch', L.ptr(desc), len(rows), blocks, L.stream())
             table['_keep'] = (flat, desc)
+            if _W_PLANES and not P.bf16() and P.get_fp32_math() == 'bf16x3':
+                # three-plane products: the planes of every weight AND of its transposed copy, one launch (u3d_weight_planes_batch);
+                # planes[(data_ptr of the fp32 matrix)] -> bf16 [3, rows, cols]
+                mats = [(w, N * K) for w, N, K in ws] + [(table[w.data_ptr()], N * K) for w, N, K in ws]
+                pflat = torch.empty(3 * sum(n for _, n in mats), dtype=torch.bfloat16, device=dev)
+                prow, pblocks, poff, planes = [], 0, 0, {}
+                for m, n in mats:
+                    pl = pflat[poff:poff + 3 * n]
+                    poff += 3 * n
+                    prow.append([m.data_ptr(), pl.data_ptr(), n // 8, pblocks])
+                    pblocks += (n // 8 + 255) // 256
+                    planes[m.data_ptr()] = pl
+                pdesc = L.h2d(prow, torch.int64, dev)
+                L.call('u3d_weight_planes_batch', L.ptr(pdesc), len(prow), pblocks, L.stream())
+                table['_planes'] = planes
+                table['_keep'] += (pflat, pdesc)
             _WT_ACTIVE = table
         else:
             _WT_ACTIVE = None
@@ -93,6 +111,27 @@ class transposed_weights:
         global _WT_ACTIVE
         _WT_ACTIVE = self.prev
         return False
+
+
+# Pre-split W operands of the three-plane NT products (u3d_weight_planes_batch + u3d_gemm_w_planes): built, bit-identical, and OFF by
+# default -- measured on MI355X (round 5, same box, two runs each): all GEMMs 5.40 / 5.34 ms with the planes, 5.41 / 5.41 without, step
+# 293.5 / 292.5 vs 294.8 / 295.7 scenes/s.  The W split is a third of the NT kernel's split arithmetic (loop VALU 156 -> 110
+# instructions, tools/isa_mix.py) and removing it buys nothing: the kernel is not bound by its VALU issue.  U3D_W_PLANES=1 turns it on.
+_W_PLANES = os.environ.get('U3D_W_PLANES', '0') == '1'
+
+
+def _planes_of(mat):
+    """bf16 [3 * N * K] planes of an fp32 matrix (a weight or its transposed copy) made by the enclosing transposed_weights()
+    context; None outside one.  Callers keep the tensor (ctx) for as long as a launch may read it."""
+    if _WT_ACTIVE is None or mat is None:
+        return None
+    return _WT_ACTIVE.get('_planes', {}).get(mat.data_ptr())
+
+
+def _use_planes(p1, p2=None):
+    """hand the next NT launch its pre-split W operand(s) (include/u3d.h u3d_gemm_w_planes); no call when there are none"""
+    if p1 is not None or p2 is not None:
+        L.lib().u3d_gemm_w_planes(L.ptr(p1), L.ptr(p2))
 
 
 def _wt_of(weight):
@@ -111,7 +150,7 @@ def _flops(M, N, K, extra_mn=0):
     return 2.0 * M * N * K
 
 
-def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False, wt=None):
+def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False, wt=None, wt_planes=None):
     """dX[M,K] = dY[M,N] . W[N,K], optionally times act'(aux) in the GEMM epilogue (u3d_linear_dact): the input gradient
     THROUGH the activation that produced this layer's input (aux = its ReLU output / GELU pre-activation)."""
     M, N = dy.shape
@@ -119,10 +158,12 @@ def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False, wt=None):
     dev = dy.device
     q = 32 if bf else 16                                # reduction-depth granule of the kernel
     if N % q == 0:
-        if wt is None:              # (``wt``: the copy transposed_weights() made for this forward pass)
+        if wt is None:              # (``wt``: the copy transposed_weights() made for this forward pass; ``wt_planes``: its planes)
             wt = torch.empty(K, N, dtype=torch.float32, device=dev)
             L.call('u3d_transpose', L.ptr(weight.contiguous()), L.ptr(wt), N, K, L.stream())
-    else:                                               # tiny heads (N = 19, 8): pad the reduction dim with zero columns
+            wt_planes = None
+    else:
+        wt_planes = None                                               # tiny heads (N = 19, 8): pad the reduction dim with zero columns
         Np = (N + q - 1) // q * q
         wt = torch.zeros(K, Np, dtype=torch.float32, device=dev)
         wt[:, :N] = weight.t()
@@ -130,9 +171,11 @@ def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False, wt=None):
         dyp[:, :N] = dy
         dy, N = dyp, Np
     if act == ACT_NONE:
-        return _gemm_nt(dy, wt, None, bf)
+        return _gemm_nt(dy, wt, None, bf, None if bf else wt_planes)
     dx = torch.empty(M, K, dtype=torch.float32, device=dev)
     if M:
+        if not bf:
+            _use_planes(wt_planes)
         L.call('u3d_linear_dact', L.ptr(dy), L.ptr(wt), L.ptr(aux), act | (P.BF16_FLAG if bf else 0), L.ptr(dx), M, K, N,
                _flops(M, K, N, extra_mn=1), L.stream())
     return dx
@@ -205,7 +248,8 @@ class _LinearFn(torch.autograd.Function):
         ctx.bias_ref = bias
         ctx.bf = P.bf16()
         ctx.wt = _wt_of(weight)
-        return _gemm_nt(x, weight.contiguous(), bias, ctx.bf)
+        ctx.wt_planes = _planes_of(ctx.wt)
+        return _gemm_nt(x, weight.contiguous(), bias, ctx.bf, None if ctx.bf else _planes_of(weight))
 
     @staticmethod
     def backward(ctx, dy):
@@ -215,7 +259,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:           # first: on the side stream it then waits for dy only, not for the dX product below
             dw, db = _weight_grad_overlapped(dy, x, ctx.has_bias and ctx.needs_input_grad[2], ctx.bf, weight, ctx.bias_ref)
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, weight, bf=ctx.bf, wt=ctx.wt)
+            dx = _input_grad(dy, weight, bf=ctx.bf, wt=ctx.wt, wt_planes=ctx.wt_planes)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db
@@ -250,14 +294,17 @@ class _MLPFn(torch.autograd.Function):
         w1c, w2c = w1.contiguous(), w2.contiguous()
         ctx.bf = P.bf16()
         ctx.wt1, ctx.wt2 = _wt_of(w1c), _wt_of(w2c)
+        ctx.wtp1, ctx.wtp2 = _planes_of(ctx.wt1), _planes_of(ctx.wt2)
+        p1, p2 = (None, None) if ctx.bf else (_planes_of(w1c), _planes_of(w2c))
         ctx.fused = act != ACT_GELU or FUSE_GELU
         if M and not ctx.fused:                      # plain GEMM (+bias) -> GELU pass -> plain GEMM
-            h = _gemm_nt(x, w1c, b1, ctx.bf)
+            h = _gemm_nt(x, w1c, b1, ctx.bf, p1)
             L.call('u3d_gelu_fwd', L.ptr(h), L.ptr(a), M * hid, L.stream())
-            z = _gemm_nt(a, w2c, b2, ctx.bf)
+            z = _gemm_nt(a, w2c, b2, ctx.bf, p2)
         elif M:
             _flops(M, hid, d_in, extra_mn=1 if act == ACT_GELU else 0)
             _flops(M, d_out, hid)
+            _use_planes(p1, p2)
             L.call('u3d_ffn_fwd', L.ptr(x), L.ptr(w1c), L.ptr(b1), L.ptr(w2c), L.ptr(b2), act | (P.BF16_FLAG if ctx.bf else 0),
                    L.ptr(h), L.ptr(a), L.ptr(z), M, d_in, hid, d_out, 1.0 if _PROFILE_FLOPS else 0.0, L.stream())
         ctx.save_for_backward(x, w1c, w2c, a, h)
@@ -272,14 +319,14 @@ class _MLPFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dw2, db2 = _weight_grad_overlapped(dz, a, ctx.bias[1] and need[4], ctx.bf, w2, ctx.bias_refs[1]) if need[3] else (None, None)
         if ctx.fused:
-            dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf, wt=ctx.wt2)
+            dh = _input_grad(dz, w2, ctx.act, h if ctx.act == ACT_GELU else a, bf=ctx.bf, wt=ctx.wt2, wt_planes=ctx.wtp2)
         else:
-            da = _input_grad(dz, w2, bf=ctx.bf, wt=ctx.wt2)
+            da = _input_grad(dz, w2, bf=ctx.bf, wt=ctx.wt2, wt_planes=ctx.wtp2)
             dh = torch.empty_like(da)
             if da.numel():
                 L.call('u3d_gelu_bwd', L.ptr(da), L.ptr(h), L.ptr(dh), da.numel(), L.stream())
         dw1, db1 = _weight_grad_overlapped(dh, x, ctx.bias[0] and need[2], ctx.bf, w1, ctx.bias_refs[0]) if need[1] else (None, None)
-        dx = _input_grad(dh, w1, bf=ctx.bf, wt=ctx.wt1) if need[0] else None
+        dx = _input_grad(dh, w1, bf=ctx.bf, wt=ctx.wt1, wt_planes=ctx.wtp1) if need[0] else None
         return dx, dw1, db1, dw2, db2, None
 
 

@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd); OUT=$1; SRCS=${2//,/ }; shift 2
 C=$R/unidet3d_amd/csrc; TMP=$(mktemp -d)
 for SRC in $SRCS; do
     EXTRA=""; { [ "$SRC" = "spconv.hip" ] || [ "$SRC" = "spconv_wg.hip" ] || [ "$SRC" = "attn_x3.hip" ]; } && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; [ "$SRC" = "postproc.hip" ] && EXTRA="-ffp-contract=off"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -I $R/include -I $C $EXTRA "$@" -c $C/$SRC -o $TMP/${SRC%.hip}.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I $R/include -I $C $EXTRA "$@" -c $C/$SRC -o $TMP/${SRC%.hip}.o &
 done
 wait
 for SRC in $SRCS; do [ -f $TMP/${SRC%.hip}.o ] || { echo "compile of $SRC failed"; exit 1; }; done

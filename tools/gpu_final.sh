@@ -6,14 +6,14 @@ TAG=${1:-final}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir
 rm -f gpurun_out/parity_errors.jsonl
 T0=$(date +%s)
 if [ "$2" != "notests" ]; then
-timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt
+timeout 2400 python -m pytest tests -m gpu -x -q --timeout 1200 > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt
 tail -6 $OUT/pytest_gpu.txt | cut -c1-300
 cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
 fi
 echo "t=$(( $(date +%s) - T0 ))s"
 # PMC traffic first: the bench line quotes it only when it was taken on exactly the kernel sources it times (bench.py _pmc_traffic)
-PMC_TAG=${TAG}_pmc timeout 400 bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; grep -E "_spconv_gmm" $OUT/pmc.log | cut -c1-200
-cp gpurun_out/${TAG}_pmc/summary.json $OUT/pmc_traffic.json 2>/dev/null && cp $OUT/pmc_traffic.json profiles/round4_pmc_traffic.json
+PMC_TAG=${TAG}_pmc timeout 600 bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; grep -E "_spconv_gmm" $OUT/pmc.log | cut -c1-200
+cp gpurun_out/${TAG}_pmc/summary.json $OUT/pmc_traffic.json 2>/dev/null && cp $OUT/pmc_traffic.json profiles/round5_pmc_traffic.json
 echo "t=$(( $(date +%s) - T0 ))s"
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.log || tail -5 $OUT/bench.log
 python - <<PY
@@ -24,6 +24,7 @@ c = d.get('cfg3')
 if c: print('cfg3:', round(c['value'], 1), round(c['ms_per_step'], 2), {k: round(v['ms_per_step'], 2) for k, v in c['kernels'].items()})
 n = d.get('fp32_native_mfma')
 if n: print('native fp32 MFMAs:', round(n['value'], 1), round(n['ms_per_step'], 2))
+print('summary:', d.get('summary'))
 print('cpu:', d.get('cpu_baseline', {}).get('value'), 'roofline:', {k: d['roofline'][k] for k in ('achieved', 'peak', 'frac', 'frac_of_dtype_peak', 'traffic') if k in d['roofline']})
 PY
 for c in cfg4 cfg5; do

@@ -37,8 +37,12 @@ __global__ void stats_init_k(StatsWs* ws, int B, int32_t* grid_max) {
     if (b < 3) grid_max[b] = 0;
 }
 
+// min / max: integer atomics on order-preserving keys (order-free).  Coordinate sums: every (scene, block) writes ONE fp64 partial
+// (its four waves added in a fixed order), stats_fin_k adds a scene's partials in block order -- no floating-point atomics: the scene
+// mean, and with it every voxel feature, has the same bits run after run.
+constexpr int STATS_MAX_BLK = 256;
 __global__ __launch_bounds__(256) void scene_stats_k(const float* __restrict__ points, const float* __restrict__ csrc,
-                                                     const int64_t* __restrict__ offs, StatsWs* ws) {
+                                                     const int64_t* __restrict__ offs, StatsWs* ws, double* __restrict__ part) {
     const int b = blockIdx.y;
     const int64_t lo = offs[b], hi = offs[b + 1];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -61,18 +65,26 @@ __global__ __launch_bounds__(256) void scene_stats_k(const float* __restrict__ p
             sm[a] += __shfl_xor(sm[a], d, 64);
         }
     }
-    if ((threadIdx.x & 63) == 0 && lo < hi) {
+    __shared__ double wsum[4][3];
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&ws[b].mn[a], f2ord(mn[a]));
-            atomicMax(&ws[b].mx[a], f2ord(mx[a]));
-            atomicAdd(&ws[b].sum[a], sm[a]);
+        for (int a = 0; a < 3; ++a) wsum[threadIdx.x >> 6][a] = sm[a];
+        if (lo < hi) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&ws[b].mn[a], f2ord(mn[a]));
+                atomicMax(&ws[b].mx[a], f2ord(mx[a]));
+            }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        part[((int64_t)b * STATS_MAX_BLK + blockIdx.x) * 3 + threadIdx.x] =
+            ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
 }
 
-__global__ void stats_fin_k(const StatsWs* ws, const int64_t* offs, int B, float vs, float inv_vs, int mode,
-                            float* stats, int32_t* grid_max) {
+__global__ void stats_fin_k(const StatsWs* ws, const double* __restrict__ part, int nblk, const int64_t* offs, int B, float vs, float inv_vs,
+                            int mode, float* stats, int32_t* grid_max) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double n = (double)(offs[b + 1] - offs[b]);
@@ -80,7 +92,9 @@ __global__ void stats_fin_k(const StatsWs* ws, const int64_t* offs, int B, float
         float mn = ord2f(ws[b].mn[a]), mx = ord2f(ws[b].mx[a]);
         stats[b * 12 + a] = mn;
         stats[b * 12 + 3 + a] = mx;
-        stats[b * 12 + 6 + a] = n > 0 ? (float)(ws[b].sum[a] / n) : 0.f;
+        double sum = 0.0;
+        for (int k = 0; k < nblk; ++k) sum += part[((int64_t)b * STATS_MAX_BLK + k) * 3 + a];
+        stats[b * 12 + 6 + a] = n > 0 ? (float)(sum / n) : 0.f;
         stats[b * 12 + 9 + a] = 0.f;
         if (n > 0) atomicMax(&grid_max[a], cell_of(mx, mn, vs, inv_vs, mode));
     }
@@ -178,7 +192,7 @@ using namespace u3d;
 
 extern "C" {
 
-int64_t u3d_vox_scene_stats_ws_bytes(int B) { return (int64_t)B * sizeof(StatsWs) + 64; }
+int64_t u3d_vox_scene_stats_ws_bytes(int B) { return (int64_t)B * sizeof(StatsWs) + (int64_t)B * STATS_MAX_BLK * 3 * sizeof(double) + 128; }
 
 int u3d_vox_scene_stats(const float* points, const float* coord_src, const int64_t* pt_offsets, int B,
                         int64_t max_pts, float voxel_size, int div_mode, float* stats, int32_t* grid_max,
@@ -189,9 +203,10 @@ int u3d_vox_scene_stats(const float* points, const float* coord_src, const int64
     StatsWs* w = (StatsWs*)ws;
     hipLaunchKernelGGL(stats_init_k, dim3((B + 63) / 64 + 1), dim3(64), 0, s, w, B, grid_max);
     int nblk = (int)ceil_div(max_pts, 256 * 8);
-    nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
-    hipLaunchKernelGGL(scene_stats_k, dim3(nblk, B), dim3(256), 0, s, points, coord_src, pt_offsets, w);
-    hipLaunchKernelGGL(stats_fin_k, dim3((B + 63) / 64), dim3(64), 0, s, (const StatsWs*)w, pt_offsets, B,
+    nblk = nblk < 1 ? 1 : (nblk > STATS_MAX_BLK ? STATS_MAX_BLK : nblk);
+    double* part = (double*)(((uintptr_t)(w + B) + 63) & ~(uintptr_t)63);
+    hipLaunchKernelGGL(scene_stats_k, dim3(nblk, B), dim3(256), 0, s, points, coord_src, pt_offsets, w, part);
+    hipLaunchKernelGGL(stats_fin_k, dim3((B + 63) / 64), dim3(64), 0, s, (const StatsWs*)w, (const double*)part, nblk, pt_offsets, B,
                        voxel_size, 1.0f / voxel_size, div_mode, stats, grid_max);
     return check_launch("vox_scene_stats");
 }

@@ -19,6 +19,9 @@
 // The backward kernels read their staged tiles in both orientations the same way: rows with ds_read_b128, columns with transpose reads.
 // The kernels are templates over the number of planes: NP = 3 is the fp32 path above, NP = 1 the bf16-operand form of
 // BASELINE configs[2] (one bf16 value per operand, rounded to nearest even; u3d_attn_varlen_*_bf16 at the end of the file).
+#include <mutex>
+#include <stdlib.h>
+
 #include "u3d_common.h"
 
 namespace u3d {
@@ -458,17 +461,54 @@ void attn_fwd_x3_launch(const float* qkv, const int32_t* cu, int B, int max_len,
     else hipLaunchKernelGGL(attn_fwd_x3_k<3>, dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
 }
 
+// dQ and dK / dV are independent given delta: with U3D_ATTN_FORK=1 the dQ kernel is forked onto a per-device side stream and joined
+// before the call hands `s` back (events only; nothing blocks the host).  Each of the two grids leaves the last of its ~2.8 waves of
+// workgroups a quarter full; side by side they fill each other's tail: attention backward 4.88 / 4.95 -> 4.75 / 4.76 ms per step
+// alone -- and the training step got SLOWER (302.3 / 301.2 -> 297.8 / 296.8 scenes/s, same box, round 5): the fork competes with the
+// weight-gradient chain that already runs beside the decoder's backward (sparse.set_wgrad_overlap(2)).  OFF by default.
+struct AttnFork {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static AttnFork* attn_fork_of_device() {
+    static AttnFork forks[64];
+    static std::mutex mu;
+    static const bool on = [] { const char* e = getenv("U3D_ATTN_FORK"); return e && atoi(e) != 0; }();
+    if (!on) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    AttnFork& f = forks[dev & 63];
+    std::lock_guard<std::mutex> lk(mu);
+    if (!f.side) {
+        if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
+        hipEventCreateWithFlags(&f.fork, hipEventDisableTiming);
+        hipEventCreateWithFlags(&f.join, hipEventDisableTiming);
+    }
+    return &f;
+}
+
 void attn_bwd_x3_launch(const float* qkv, const float* out, const float* dout, const float* lse, const int32_t* cu, int B, int max_len,
                         int64_t n_total, int H, float scale, float* dqkv, float* delta_ws, hipStream_t s, int planes) {
     hipLaunchKernelGGL(attn_delta_x3_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, out, dout, n_total, H, delta_ws);
     const int n_tiles = (max_len + 63) / 64;
     const dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * n_tiles));
+    AttnFork* f = attn_fork_of_device();
+    hipStream_t sq = s;
+    if (f) {
+        hipEventRecord(f->fork, s);
+        hipStreamWaitEvent(f->side, f->fork, 0);
+        sq = f->side;
+    }
     if (planes == 1) {
-        hipLaunchKernelGGL(attn_bwd_dq_x3_k<1>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL(attn_bwd_dq_x3_k<1>, grid, dim3(256), 0, sq, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
         hipLaunchKernelGGL(attn_bwd_dkv_x3_k<1>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_x3_k<3>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL(attn_bwd_dq_x3_k<3>, grid, dim3(256), 0, sq, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
         hipLaunchKernelGGL(attn_bwd_dkv_x3_k<3>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+    }
+    if (f) {
+        hipEventRecord(f->join, f->side);
+        hipStreamWaitEvent(s, f->join, 0);
     }
 }
 

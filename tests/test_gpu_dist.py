@@ -36,6 +36,8 @@ def _worker(rank, world, port, out_path):
     from unidet3d_amd.dist import FlatGradBucket, broadcast_params, init_from_env
     from unidet3d_amd.synthetic import make_scene
     init_from_env('gloo')
+    from unidet3d_amd import sparse
+    sparse.set_wgrad_overlap(2)        # the bench's setting: weight gradients on their own stream chain; the bucket hooks must join it
     model = _build()
     broadcast_params(model)
     params = [p for p in model.parameters() if p.requires_grad]

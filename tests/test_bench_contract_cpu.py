@@ -99,7 +99,7 @@ def test_git_head_falls_back_to_the_stamp_file(tmp_path, monkeypatch):
 def test_kept_bench_lines_follow_the_contract():
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round2_final_bench_*.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'round3_bench_*.json')) +
-                   glob.glob(os.path.join(ROOT, 'profiles', 'round4_bench_*.json')))
+                   glob.glob(os.path.join(ROOT, 'profiles', 'round4_bench_*.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'round5_bench_*.json')))
     assert files, 'no bench line kept under profiles/'
     for f in files:
         d = json.load(open(f))
@@ -115,7 +115,7 @@ def test_kept_bench_lines_follow_the_contract():
         for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
             assert k in r, (f, k)
         assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-        if 'round4' in os.path.basename(f) and d['config'].get('fp32_math') == 'bf16x3':
+        if ('round4' in os.path.basename(f) or 'round5' in os.path.basename(f)) and d['config'].get('fp32_math') == 'bf16x3':
             # round 4 on: a three-plane line prices frac against the instruction ceiling, the fp32-peak figure rides along
             assert abs(r['peak'] - 2500.0 / 6) < 1e-9 and r['dtype_peak'] == 157.3 and abs(r['frac_of_dtype_peak'] - r['achieved'] / 157.3) < 1e-9
             assert 0 < r['frac'] < 1 and r['frac_of_dtype_peak'] > r['frac']
@@ -139,3 +139,24 @@ def test_kept_bench_lines_follow_the_contract():
     assert nm['value'] > 0 and abs(nm['value'] - 8 / nm['ms_per_step'] * 1e3) < 1e-6 * nm['value']
     assert nm['roofline']['peak'] == 157.3 and 'math' not in nm['roofline']
     assert nm['warmup_losses'][0] == main['config']['warmup_losses'][0]          # same initial weights and scenes
+
+
+def test_round5_line_prices_every_family_by_the_mfma_it_issues_and_ends_with_a_summary():
+    """cfg3's weight gradient runs on bf16 MFMAs and is priced against the bf16 peak (round 4 quoted 0.82 of the fp32
+    peak for it); the cfg3 block carries PMC traffic; the line names its commit and ends with the numbers a reader wants first."""
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'round5_bench_fp32.json')))
+    assert list(d)[-1] == 'summary' and d['git_head'] not in ('', '?')
+    sm = d['summary']
+    assert abs(sm['scenes_per_s'] - d['value']) < 0.01 and abs(sm['cfg3_bf16_scenes_per_s'] - d['cfg3']['value']) < 0.01
+    assert abs(sm['fp32_native_mfma_scenes_per_s'] - d['fp32_native_mfma']['value']) < 0.01 and sm['cpu_baseline_scenes_per_s'] == d['cpu_baseline']['value']
+    assert d['config']['wgrad_overlap'] == 2 and 'side-stream chain' in d['config']['workload']
+    for k, v in d['cfg3']['kernels'].items():
+        assert v['mfma_peak'] == 2500.0 and 'bf16' in v['mfma_instr'] and 0 < v['frac_mfma'] < 1, k
+    for k, v in d['kernels'].items():
+        assert v['mfma_peak'] == 157.3 and 0 < v['frac_mfma'] < 1, k
+    assert 'f32' in d['kernels']['conv_wgrad']['mfma_instr'] and 'bf16x3_ceiling' not in d['kernels']['conv_wgrad']
+    for blk in (d, d['cfg3']):
+        r = blk['roofline']
+        assert r['traffic'] and r['traffic'] > 0.5 * r['algorithmic_bytes_per_launch'] and d['git_head'][:12] in r['traffic_source']
+    pm = json.load(open(os.path.join(ROOT, 'profiles', 'round5_pmc_traffic.json')))
+    assert pm['_meta']['git_head'] == d['git_head'] and 'cfg3' in pm and '_spconv_wgrad_all' in pm

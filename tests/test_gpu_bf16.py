@@ -119,7 +119,6 @@ def test_attention_bf16_fwd_bwd(lens):
 def test_subm_conv_bf16_self_consistent_and_close(cin, cout):
     """SubM 3x3x3 conv forward + input gradient with bf16 operands == the fp32 kernel on pre-rounded operands (1e-5), and
     within bf16 tolerance of the fp32 result on the original operands."""
-    from oracle import sparse_ops as so
     from unidet3d_amd import ops, sparse, precision as P
     from unidet3d_amd.synthetic import make_scene
     scenes = [make_scene(21 + i, n_points=12_000) for i in range(2)]
@@ -390,8 +389,11 @@ def test_training_step_bf16_operands_stays_close_to_fp32():
     rec = dict(loss_fp32=l32, loss_bf16=l16, loss_rel=abs(l16 - l32) / abs(l32), min_cos_decoder_grads=cos_dec, cos_all_grads=cos(flat32, flat16))
     PA.log_errors('bf16_step_vs_fp32_step', rec)
     print('bf16 step vs fp32 step:', rec)
-    assert rec['loss_rel'] < 0.3          # plumbing guard only (a kernel family left in the wrong mode or a broken operand pack shows up
-                                          # as O(1)); the measured distances are in the log, the arithmetic is pinned kernel by kernel above
+    # measured over rounds 3-5 (identical to three digits every time): loss 2.1e-4, worst decoder tensor's cosine 0.99955, all gradients
+    # 0.99856.  Bounds with ~20x / 10x / 7x of that distance to 1 as margin: a kernel family left in the wrong mode or a broken operand
+    # pack moves these by orders of magnitude; the arithmetic itself is pinned kernel by kernel above
+    assert rec['loss_rel'] < 5e-3, rec
+    assert rec['min_cos_decoder_grads'] > 0.995 and rec['cos_all_grads'] > 0.99, rec
 
 
 def test_eval_mode_forward_with_bf16_rows_equals_the_fp32_row_path():

@@ -431,9 +431,11 @@ def join_wgrad_stream(device=None):
 
 
 def _queue_join(device):
-    if not _JOIN_PENDING.get(device):
-        _JOIN_PENDING[device] = True
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(device))
+    """Ask the autograd engine to join the side stream(s) when the running backward pass ends.  A callback is queued for EVERY side-stream
+    launch (the first one to run joins and clears the pending flag, the rest are no-ops): a flag-guarded single callback would be lost
+    for good if a backward pass died between queueing and running it."""
+    _JOIN_PENDING[device] = True
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(device))
 
 
 _PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops

@@ -417,6 +417,31 @@ def test_large_extent_scene_takes_the_hashed_index():
     assert _rel(y, yo) < 1e-5
 
 
+def test_precomputed_weight_gradient_tiles_follow_the_new_row_count():
+    """the tile lists a rulebook builds ahead (Rulebook.precompute_tiles, on the prefetch stream) replay what the previous
+    rulebook with the same indice_key was asked for -- but a weight-gradient tile height depends on the row count, so it is recomputed
+    for the new rulebook instead of replaying a height that no longer matches (a wasted launch + a second one on the main stream)."""
+    from unidet3d_amd import _lib as L, ops, sparse
+    sparse._TILE_HISTORY.pop(('subm', 'tkey'), None)
+    rbs = []
+    for seed, n_pts in ((11, 30_000), (12, 22_000)):
+        vb = ops.voxelize([torch.from_numpy(s.points).to(_dev()) for s in _scene_points(2, n_pts, seed0=seed)], 0.02, 128)
+        rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+        rb.tag = ('subm', 'tkey')
+        rbs.append(rb)
+    a, b = rbs
+    Ta = L.lib().u3d_spconv_wgrad_tile_rows(27, a.n_out, 32, 32)
+    Tb = L.lib().u3d_spconv_wgrad_tile_rows(27, b.n_out, 32, 32)
+    assert Ta != Tb
+    a.tile_starts('out', 64)
+    ts_a = a.tile_starts('out', Ta, wgrad=(32, 32))
+    b.precompute_tiles()
+    assert set(b._tiles) == {('out', 64), ('out', Tb)}
+    ref = sparse.Rulebook(b.pair_in, b.pair_out, b.counts, 27, b.n_in, b.n_out)._tile_starts('out', Tb)
+    assert torch.equal(b._tiles[('out', Tb)], ref)
+    assert ts_a.shape[0] == 27
+
+
 # ---------------------------------------------------------------------------- the library's own radix sort (csrc/radix.hip)
 @pytest.mark.parametrize('n,bits', [(1, 8), (63, 5), (1023, 8), (1024, 9), (1025, 17), (100_003, 17), (100_003, 40), (2_000_000, 23), (300_000, 63)])
 def test_radix_sort_equals_a_stable_sort_bit_for_bit(n, bits):

@@ -152,18 +152,27 @@ class Rulebook:
             self._tiles[key] = ts
         return self._tiles[key]
 
-    def tile_starts(self, role: str, T: int) -> torch.Tensor:
+    def tile_starts(self, role: str, T: int, wgrad=None) -> torch.Tensor:
+        """``wgrad`` = (C_in, C_out) when T is a weight-gradient tile height: that height follows the row count (u3d_spconv_wgrad_tile_rows),
+        so the history remembers the layer shape and the next rulebook recomputes ITS height instead of replaying this one."""
         if self.tag is not None:
-            _TILE_HISTORY.setdefault(self.tag, set()).add((role, T))        # what the next rulebook with this tag builds ahead
+            _TILE_HISTORY.setdefault(self.tag, set()).add((role, T) if wgrad is None else (role, 'wgrad', int(wgrad[0]), int(wgrad[1])))
         return self._tile_starts(role, T)
 
     def precompute_tiles(self):
-        """Build the tile lists the PREVIOUS rulebook with this tag was asked for (a tile height that no longer fits this batch costs
-        one small launch, is not used, and is forgotten: only this step's real requests are remembered for the next)."""
+        """Build the tile lists the PREVIOUS rulebook with this tag was asked for: fixed heights (the forward / input-gradient kernels'
+        32 / 64 rows) as they were, weight-gradient heights recomputed for THIS rulebook's row count.  Only this step's real requests
+        are remembered for the next."""
         if self.tag is None or not _TILE_PRECOMPUTE:
             return
-        for role, T in sorted(_TILE_HISTORY.pop(self.tag, ())):
-            self._tile_starts(role, T)
+        for key in sorted(_TILE_HISTORY.pop(self.tag, ()), key=str):
+            if len(key) == 2:
+                self._tile_starts(*key)
+            else:
+                role, _, cin, cout = key
+                n_dy = self.n_out if role == 'out' else self.n_in
+                if n_dy > 0:
+                    self._tile_starts(role, int(L.lib().u3d_spconv_wgrad_tile_rows(self.K, n_dy, cin, cout)))
 
     @property
     def total_pairs(self) -> int:
@@ -500,7 +509,7 @@ class _SparseConvFn(torch.autograd.Function):
                 account.add('conv_wgrad', flops, 4.0 * (src.shape[0] * cin + n_dy * cout) + 8.0 * rb.total_pairs + 4.0 * rb.K * cin * cout)
             Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
             ws_bytes = L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout)
-            ts = rb.tile_starts(role, Tw)
+            ts = rb.tile_starts(role, Tw, wgrad=(cin, cout))
             # the weight-gradient walk is bound by its row gathers: bf16 operands pay off only where the matrix
             # work is a visible share -- measured (tools/prof_wgrad.py): 32x32 channels 179 us fp32 vs 221 us bf16, 64x64 150 vs 104
             wg = 'u3d_spconv_wgrad_bf16' if ctx.bf == P.FMT_BF16 and cin * cout >= 64 * 64 else 'u3d_spconv_wgrad'

@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 112
+#define U3D_ABI_VERSION 111
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -236,18 +236,6 @@ int u3d_spconv_wgrad_bf16(const float* x, int64_t n_rows_x, const float* dy, con
 int u3d_spconv_wgrad_rows(const void* x_bf16, int64_t n_rows_x, const void* dy_bf16, const int32_t* rows_x, const int32_t* rows_dy,
                           const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
                           float* dW, void* ws, double flops_hint, u3d_stream_t stream);
-/* Row-synchronous weight gradient of the 27-offset, 32 -> 32 channel SubM layers (csrc/spconv.hip spconv_wgrad_sync_k): a workgroup of
- * eight waves owns consecutive 128-row chunks of dy -- staged once per chunk in LDS by a contiguous copy -- and all 27 offsets of them,
- * three or four offsets' 32 x 32 blocks per wave in registers; only the x rows are gathered.  chunk_starts = u3d_tile_starts over the
- * dy-side rows with T = u3d_spconv_wgrad_sync_chunk_rows() (int32 [27][ceil(n_rows_dy / T) + 1]); ws >= u3d_spconv_wgrad_sync_ws_bytes.
- * fp32 operands on v_mfma_f32_16x16x4_f32, fixed-order reduction over the workgroups' partial blocks; dW [32][27][32] as
- * u3d_spconv_wgrad writes it.  u3d_spconv_wgrad_sync_supported: 1 for (27, 32, 32) unless env U3D_WGRAD_SYNC=0. */
-int u3d_spconv_wgrad_sync_supported(int K, int Cs, int Cd);
-int u3d_spconv_wgrad_sync_chunk_rows(void);
-int64_t u3d_spconv_wgrad_sync_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd);
-int u3d_spconv_wgrad_sync(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
-                          const int32_t* chunk_starts, int K, int64_t cap, int64_t n_rows_dy, int Cs, int Cd, float* dW, void* ws,
-                          double flops_hint, u3d_stream_t stream);
 int u3d_spconv_wgrad_rows_supported(int Cs, int Cd);
 int u3d_spconv_wgrad_tile_rows(int K, int64_t n_rows_dy, int Cs, int Cd);
 int64_t u3d_spconv_wgrad_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd);

@@ -58,10 +58,6 @@ PROTOTYPES = {
     'u3d_spconv_wgrad': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
     'u3d_spconv_wgrad_bf16': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
     'u3d_spconv_wgrad_rows': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
-    'u3d_spconv_wgrad_sync_supported': (_i32, [_i32, _i32, _i32]),
-    'u3d_spconv_wgrad_sync_chunk_rows': (_i32, []),
-    'u3d_spconv_wgrad_sync_ws_bytes': (_i64, [_i32, _i64, _i32, _i32]),
-    'u3d_spconv_wgrad_sync': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _f64, _vp]),
     'u3d_spconv_wgrad_rows_supported': (_i32, [_i32, _i32]),
     'u3d_spconv_wgrad_tile_rows': (_i32, [_i32, _i64, _i32, _i32]),
     'u3d_spconv_wgrad_ws_bytes': (_i64, [_i32, _i64, _i32, _i32]),
@@ -115,7 +111,7 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 112         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 111         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

@@ -871,166 +871,6 @@ static int launch_wgrad(const WgParams& p0, float* dW, hipStream_t s) {
     return check_launch("spconv_wgrad");
 }
 
-// ------------------------------------------------------------------------------------------
-// Row-synchronous weight gradient for the 32 -> 32 channel SubM layers of level 1 (27 offsets) -- VERDICT r4 item 2.
-// spconv_wgrad_k lets every (row range, offset) pair be walked by a wave of its own: 27 walkers per range, each at its own pace
-// (a corner offset has a fifth of the centre's pairs), ~1700 of them resident at once -- a dy or x row is gathered ~24 times, from
-// walkers that pass it at different times, and the 4 MB L2 of an XCD cannot hold what lies between (PMC: 429 MB fetched per launch for
-// 125 MB of rows + indices).  Here a workgroup of EIGHT waves owns a run of consecutive 128-row chunks of dy and all 27 offsets of it:
-//   * the chunk's dy rows are contiguous: staged ONCE into LDS by a coalesced copy (double buffered: the next chunk's loads are in
-//     flight while this one is walked) and read from there by every pair of every offset -- half of the kernel's gathers (and of
-//     the texture path's cache-line look-ups, which is what paces the walk) are gone, dy is fetched from HBM once;
-//   * each wave keeps the dW blocks of its 3-4 offsets in registers (16 VGPRs per 32 x 32 block: the table below balances the waves
-//     by the expected pair density of an offset: centre 1, faces 0.6, edges 0.38, corners 0.25) and walks the chunk's pairs of
-//     those offsets; one barrier per chunk keeps the eight waves on the same rows, so the x rows the 27 offsets gather -- all within
-//     a few hundred rows of the chunk -- meet in L1 / L2 while they are hot;
-//   * one partial block per (workgroup, offset), summed in a fixed order by wgrad_reduce_k: deterministic, no atomics.
-// MFMA operand construction, channel striding and the partial layout are spconv_wgrad_k's (SG = SX = 1).
-constexpr int WSY_CHUNK = 128, WSY_WAVES = 8, WSY_SLOTS = 4;
-__constant__ signed char WSY_KTAB[WSY_WAVES][WSY_SLOTS] = {{13, 0, 2, -1}, {4, 10, 6, -1}, {12, 14, 8, -1}, {16, 22, 18, -1},
-                                                           {1, 3, 5, 20},  {7, 9, 11, 24}, {15, 17, 19, 26}, {21, 23, 25, -1}};
-struct WsyParams {
-    const float* x;
-    const float* dy;
-    const int32_t* rows_x;
-    const int32_t* rows_dy;
-    const int32_t* cs;        // chunk_starts [27][n_chunks + 1]: pairs of offset k whose dy row lies in chunk c (tile_starts with T = 128)
-    float* partial;           // [27][n_wg][32 * 32] in accumulator-register order
-    int64_t cap, n_dy;
-    int n_chunks, n_wg, per_wg;
-};
-
-template <int NG, int NX>
-__global__ __launch_bounds__(512) void spconv_wgrad_sync_k(WsyParams p) {
-    constexpr int CD = NG * 16, CS = NX * 16;
-    constexpr int F4 = WSY_CHUNK * CD / 4 / 512;                 // float4 pieces of a chunk per thread
-    static_assert(WSY_CHUNK * CD / 4 % 512 == 0, "chunk staging map");
-    __shared__ __attribute__((aligned(16))) float dyt[2][WSY_CHUNK * CD];
-    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = (int)xcd_swizzle(blockIdx.x, gridDim.x);      // neighbouring row runs share an XCD (their x windows overlap)
-    const int c0 = wg * p.per_wg, c1 = min(c0 + p.per_wg, p.n_chunks);
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_rx = make_rsrc(p.rows_x), rs_rg = make_rsrc(p.rows_dy);
-    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dy, p.n_dy * CD * 4);          // rows past the end stage as zeros
-    const int xvo = NX * i16 * 4, q16 = q * 16;
-    int ks[WSY_SLOTS];
-#pragma unroll
-    for (int s = 0; s < WSY_SLOTS; ++s) ks[s] = __builtin_amdgcn_readfirstlane((int)WSY_KTAB[wave][s]);
-    f32x4 acc[WSY_SLOTS][NG][NX];
-#pragma unroll
-    for (int s = 0; s < WSY_SLOTS; ++s)
-#pragma unroll
-        for (int a = 0; a < NG; ++a)
-#pragma unroll
-            for (int b = 0; b < NX; ++b) acc[s][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 st[F4];
-    auto stage_load = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < F4; ++j) st[j] = bload128(rs_dy, (tid + j * 512) * 16, c * (WSY_CHUNK * CD * 4));
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < F4; ++j) *reinterpret_cast<f32x4*>(&dyt[buf][(tid + j * 512) * 4]) = st[j];
-    };
-    if (c0 < c1) {
-        stage_load(c0);
-        stage_store(0);
-    }
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-        const int buf = (c - c0) & 1;
-        if (c + 1 < c1) stage_load(c + 1);                       // lands while this chunk is walked
-        const float* tile = dyt[buf] + NG * i16 - (int64_t)c * (WSY_CHUNK * CD);        // + dy_row * CD = this lane's channels of a staged row
-        // this wave's segments of the chunk: slot s = pairs [lo_[s], hi_[s]) of offset ks[s]
-        int lo_[WSY_SLOTS], hi_[WSY_SLOTS], kso[WSY_SLOTS];
-#pragma unroll
-        for (int s = 0; s < WSY_SLOTS; ++s) {
-            const int k = ks[s];
-            lo_[s] = k < 0 ? 0 : p.cs[(int64_t)k * (p.n_chunks + 1) + c];
-            hi_[s] = k < 0 ? 0 : p.cs[(int64_t)k * (p.n_chunks + 1) + c + 1];
-            kso[s] = k < 0 ? 0 : (int)(k * p.cap) * 4;
-        }
-        auto sel = [&](const int (&v)[WSY_SLOTS], int s) { return s == 0 ? v[0] : (s == 1 ? v[1] : (s == 2 ? v[2] : v[3])); };
-        // The trips (16 pairs: lane group q takes pairs 4q .. 4q+3) of all segments form ONE stream, software-pipelined three deep like
-        // spconv_wgrad_k's walk: while the MFMAs of trip t run, the x rows of trip t+1 and the pair indices of trip t+2 are in flight.
-        int ns = 0, nb = lo_[0];                                 // next trip to fetch indices for (ns == WSY_SLOTS: none left)
-        while (ns < WSY_SLOTS && nb >= sel(hi_, ns)) { ++ns; nb = ns < WSY_SLOTS ? sel(lo_, ns) : 0; }
-        auto fetch_idx = [&](int (&io)[4], int (&ix)[4], int& s_out, int& b_out) {
-            s_out = ns;
-            b_out = nb;
-            if (ns >= WSY_SLOTS) return;
-            const int hi = sel(hi_, ns), so = sel(kso, ns);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                        // indices clamped into the segment; pairs past its end are masked in load_rows
-                const int pi = min(nb + 4 * q + u, hi - 1);
-                io[u] = bload32(rs_rg, pi * 4, so);
-                ix[u] = bload32(rs_rx, pi * 4, so);
-            }
-            nb += 16;
-            while (ns < WSY_SLOTS && nb >= sel(hi_, ns)) { ++ns; nb = ns < WSY_SLOTS ? sel(lo_, ns) : 0; }
-        };
-        auto load_rows = [&](float (&gv)[4][NG], float (&xv)[4][NX], const int (&io)[4], const int (&ix)[4], int s_, int b_) {
-            const int hi = sel(hi_, s_);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                load_row_part<NX>(xv[u], rs_x, (int)__umul24(ix[u], CS * 4) + xvo);
-                const float* g = tile + (int64_t)io[u] * CD;
-                const unsigned live = b_ + 4 * q + u < hi ? 0xffffffffu : 0u;         // pairs past the segment's end contribute exact zeros
-#pragma unroll
-                for (int a = 0; a < NG; ++a) gv[u][a] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, g[a]) & live);
-            }
-        };
-        auto mfmas = [&](const float (&gv)[4][NG], const float (&xv)[4][NX], int s_) {
-#pragma unroll
-            for (int s = 0; s < WSY_SLOTS; ++s) {
-                if (s_ != s) continue;                           // wave-uniform: the segment's own accumulators
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int a = 0; a < NG; ++a)
-#pragma unroll
-                        for (int b = 0; b < NX; ++b) acc[s][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[u][a], xv[u][b], acc[s][a][b], 0, 0, 0);
-            }
-        };
-        int ioA[4], ixA[4], ioB[4], ixB[4], sA, bA, sB, bB;
-        float gA[4][NG], xA[4][NX], gB[4][NG], xB[4][NX];
-        fetch_idx(ioA, ixA, sA, bA);
-        fetch_idx(ioB, ixB, sB, bB);
-        if (sA < WSY_SLOTS) load_rows(gA, xA, ioA, ixA, sA, bA);
-        while (sA < WSY_SLOTS) {
-            int sA2, bA2, sB2, bB2;
-            if (sB < WSY_SLOTS) load_rows(gB, xB, ioB, ixB, sB, bB);       // trip t+1
-            fetch_idx(ioA, ixA, sA2, bA2);                                  // indices of trip t+2
-            mfmas(gA, xA, sA);                                              // trip t
-            if (sB >= WSY_SLOTS) break;
-            if (sA2 < WSY_SLOTS) load_rows(gA, xA, ioA, ixA, sA2, bA2);     // trip t+2
-            fetch_idx(ioB, ixB, sB2, bB2);                                  // indices of trip t+3
-            mfmas(gB, xB, sB);                                              // trip t+1
-            sA = sA2; bA = bA2; sB = sB2; bB = bB2;
-        }
-        if (c + 1 < c1) stage_store(buf ^ 1);                    // the other buffer was last read before the previous barrier
-        __syncthreads();
-    }
-#pragma unroll
-    for (int s = 0; s < WSY_SLOTS; ++s) {
-        const int k = ks[s];
-        if (k < 0) continue;
-        float* out = p.partial + ((int64_t)k * p.n_wg + wg) * (CD * CS) + lane;
-#pragma unroll
-        for (int a = 0; a < NG; ++a)
-#pragma unroll
-            for (int b = 0; b < NX; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) out[((a * NX + b) * 4 + r) * 64] = acc[s][a][b][r];
-    }
-}
-
-static int wsy_n_wg(int64_t n_chunks) {
-    static const int64_t target = [] { const char* e = getenv("U3D_WGRAD_SYNC_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)512; }();
-    const int64_t per = ceil_div(n_chunks, target < n_chunks ? target : n_chunks);
-    return (int)ceil_div(n_chunks, per);                         // every workgroup has at least one chunk
-}
-
 // wp[(((slice*K + k)*CS16 + j)*2 + nb)*256 + lane*4 + t] = W(n = slice*32 + nb*16 + (lane&15), k, c = j*16 + (lane>>4)*4 + t)
 // i.e. the B fragments of spconv_gmm_k in the order the kernel reads them (one contiguous 1 KB block per wave load).
 // transposed = 0: W(n,k,c) = w[(n*K + k)*Cs + c]  (forward, w = [Cd][K][Cs]);
@@ -1353,37 +1193,6 @@ int u3d_spconv_wgrad_bf16(const float* x, int64_t n_rows_x, const float* dy, con
                           const int32_t* tile_starts, int K, int64_t cap, int64_t n_rows_dy, int tile_rows, int Cs, int Cd,
                           float* dW, void* ws, double flops_hint, u3d_stream_t stream) {
     return spconv_wgrad_impl(x, n_rows_x, dy, rows_x, rows_dy, tile_starts, K, cap, n_rows_dy, tile_rows, Cs, Cd, dW, ws, flops_hint, stream, true);
-}
-
-int u3d_spconv_wgrad_sync_supported(int K, int Cs, int Cd) {
-    static const bool on = [] { const char* e = getenv("U3D_WGRAD_SYNC"); return !e || atoi(e) != 0; }();
-    return on && K == 27 && Cs == 32 && Cd == 32 ? 1 : 0;
-}
-int u3d_spconv_wgrad_sync_chunk_rows(void) { return WSY_CHUNK; }
-int64_t u3d_spconv_wgrad_sync_ws_bytes(int K, int64_t n_rows_dy, int Cs, int Cd) {
-    if (!u3d_spconv_wgrad_sync_supported(K, Cs, Cd) || n_rows_dy <= 0) return 0;
-    return (int64_t)K * wsy_n_wg(ceil_div(n_rows_dy, WSY_CHUNK)) * Cs * Cd * 4 + 256;
-}
-int u3d_spconv_wgrad_sync(const float* x, int64_t n_rows_x, const float* dy, const int32_t* rows_x, const int32_t* rows_dy,
-                          const int32_t* chunk_starts, int K, int64_t cap, int64_t n_rows_dy, int Cs, int Cd, float* dW, void* ws,
-                          double flops_hint, u3d_stream_t stream) {
-    if (!x || !dy || !rows_x || !rows_dy || !chunk_starts || !dW || !ws || cap <= 0 || n_rows_dy <= 0 || n_rows_x <= 0) return U3D_EINVAL;
-    if (!u3d_spconv_wgrad_sync_supported(K, Cs, Cd)) { set_error("spconv_wgrad_sync: K=%d Cs=%d Cd=%d not instantiated (27 offsets, 32 -> 32 channels)", K, Cs, Cd); return U3D_EUNSUPPORTED; }
-    if (n_rows_x >= (1 << 24) || n_rows_dy >= (1 << 24) || n_rows_x * Cs * 4 >= 0x7fffffffLL || (n_rows_dy + WSY_CHUNK) * Cd * 4 >= 0x7fffffffLL ||
-        (int64_t)K * cap * 4 >= 0x7fffffffLL) {
-        set_error("spconv_wgrad_sync: %lld / %lld rows exceed the kernel's 32-bit addressing", (long long)n_rows_x, (long long)n_rows_dy);
-        return U3D_EUNSUPPORTED;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(U3D_K_CONV_WGRAD, s, flops_hint);
-    WsyParams p;
-    p.x = x; p.dy = dy; p.rows_x = rows_x; p.rows_dy = rows_dy; p.cs = chunk_starts; p.partial = (float*)ws; p.cap = cap; p.n_dy = n_rows_dy;
-    p.n_chunks = (int)ceil_div(n_rows_dy, WSY_CHUNK);
-    p.n_wg = wsy_n_wg(p.n_chunks);
-    p.per_wg = (int)ceil_div(p.n_chunks, p.n_wg);
-    hipLaunchKernelGGL((spconv_wgrad_sync_k<2, 2>), dim3((unsigned)p.n_wg), dim3(512), 0, s, p);
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(2 * 2, K), dim3(256), 0, s, (const float*)p.partial, p.n_wg, K, 2, 2, 1, 1, dW);
-    return check_launch("spconv_wgrad_sync");
 }
 
 int u3d_weight_pack_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream) {

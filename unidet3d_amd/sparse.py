@@ -507,6 +507,9 @@ class _SparseConvFn(torch.autograd.Function):
                 rx, rg, role, n_dy = rb.pair_out, rb.pair_in, 'in', rb.n_in
             if _PROFILE_FLOPS:
                 account.add('conv_wgrad', flops, 4.0 * (src.shape[0] * cin + n_dy * cout) + 8.0 * rb.total_pairs + 4.0 * rb.K * cin * cout)
+            Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
+            ws_bytes = L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout)
+            ts = rb.tile_starts(role, Tw, wgrad=(cin, cout))
             # the weight-gradient walk is bound by its row gathers: bf16 operands pay off only where the matrix
             # work is a visible share -- measured (tools/prof_wgrad.py): 32x32 channels 179 us fp32 vs 221 us bf16, 64x64 150 vs 104
             wg = 'u3d_spconv_wgrad_bf16' if ctx.bf == P.FMT_BF16 and cin * cout >= 64 * 64 else 'u3d_spconv_wgrad'
@@ -514,18 +517,6 @@ class _SparseConvFn(torch.autograd.Function):
             if ctx.src_shadow is not None and dout_shadow is not None and L.lib().u3d_spconv_wgrad_rows_supported(cin, cout):
                 # both operands exist as bf16 rows: whole-row gathers, LDS transpose reads, bf16 MFMAs over 32 pairs (spconv_wgrad_rows.hip)
                 wg, xw, gw = 'u3d_spconv_wgrad_rows', ctx.src_shadow, dout_shadow
-            if wg == 'u3d_spconv_wgrad' and L.lib().u3d_spconv_wgrad_sync_supported(rb.K, cin, cout):
-                # level 1 (27 offsets, 32 -> 32 channels): row-synchronous walk, dy chunks staged in LDS (spconv_wgrad_sync_k)
-                wg = 'u3d_spconv_wgrad_sync'
-                Tw = L.lib().u3d_spconv_wgrad_sync_chunk_rows()
-                ws_bytes = L.lib().u3d_spconv_wgrad_sync_ws_bytes(rb.K, n_dy, cin, cout)
-                ts = rb.tile_starts(role, Tw)
-                wg_args = (rb.K, rb.cap, n_dy, cin, cout)
-            else:
-                Tw = L.lib().u3d_spconv_wgrad_tile_rows(rb.K, n_dy, cin, cout)
-                ws_bytes = L.lib().u3d_spconv_wgrad_ws_bytes(rb.K, n_dy, cin, cout)
-                ts = rb.tile_starts(role, Tw, wgrad=(cin, cout))
-                wg_args = (rb.K, rb.cap, n_dy, Tw, cin, cout)
 
             overlap = _WGRAD_OVERLAP if ctx.needs_input_grad[0] else 0       # (the first convolution has no input gradient to run next to)
             if overlap == 2 and not (weight.is_leaf and weight.grad is None):
@@ -536,7 +527,7 @@ class _SparseConvFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     ws = L.scratch(ws_bytes, weight.device)                   # the side stream's own workspace (keyed by stream)
                     L.call(wg, L.ptr(xw), xw.shape[0], L.ptr(gw), L.ptr(rx), L.ptr(rg), L.ptr(ts),
-                           *wg_args, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
+                           rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
                 for t in (xw, gw, dw, ts, rx, rg):                             # blocks must not be recycled while the side kernel uses them
                     t.record_stream(side)
                 if overlap == 2:
@@ -545,7 +536,7 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 ws = L.scratch(ws_bytes, weight.device)
                 L.call(wg, L.ptr(xw), xw.shape[0], L.ptr(gw), L.ptr(rx), L.ptr(rg), L.ptr(ts),
-                       *wg_args, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
+                       rb.K, rb.cap, n_dy, Tw, cin, cout, L.ptr(dw), L.ptr(ws), float(flops), L.stream())
         if ctx.needs_input_grad[0]:
             if mode == 'fwd':
                 g, s, role, n_dst = rb.pair_out, rb.pair_in, 'in', rb.n_in

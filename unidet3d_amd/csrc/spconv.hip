@@ -843,9 +843,14 @@ static int plan_wgrad_rows(int K, int64_t n_rows, int Cs, int Cd) {
     static const int64_t cap = [] { const char* e = getenv("U3D_WGRAD_TILES"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)256; }();
     static const int64_t budget = [] { const char* e = getenv("U3D_WGRAD_PARTIAL_MB"); const int64_t v = e ? atoll(e) : 0; return (v > 0 ? v : (int64_t)64) << 20; }();
     int64_t nt = budget / ((int64_t)K * Cs * Cd * 4);
-    // 256 tiles, more for levels beyond ~330 k rows so that a tile stays near 1300 rows (round 4, 16 scenes = 699 k rows at level 1:
-    // 512 tiles 283 us against 313 for the fp32-row walk, 116 against 125 for the bf16-row kernel; level 2 prefers its 151)
-    const int64_t cap_n = cap > n_rows / 1300 ? cap : n_rows / 1300;
+    // 256 tiles, more for levels beyond ~330 k rows so that a tile stays near 1300 rows -- near 520 rows for the 27-offset 32 -> 32
+    // layers of level 1, up to what the partial budget allows (606 tiles there).  Round 5 sweep on the pipelined + LDS-pre-reduced walk (profiles/round5_wgrad_tile_sweep.txt), level 1, 8 scenes
+    // (356 k rows): 273 tiles 153 us, 384: 144, 512: 141, 606: 139, 767: 139, 1023: 146, 1534: 161; level 2 (81 k rows) keeps its 151
+    // (256: 126 us, 512: 128, 768: 139 against 123), level 3 its 67 (254: 142 us against 85).  (Round 4, 16 scenes = 699 k rows at
+    // level 1: 512 tiles 283 us against 313 at 256 for the fp32-row walk, 116 against 125 for the bf16-row kernel.)
+    // (only the measured shape moves: the other level-1 layers -- 16 -> 32, 64 -> 32, the 8-offset strided / inverse pair -- keep 1300 rows)
+    const int64_t rows_per = (K >= 27 && Cs == 32 && Cd == 32) ? 520 : 1300;
+    const int64_t cap_n = cap > n_rows / rows_per ? cap : n_rows / rows_per;
     nt = nt > cap_n ? cap_n : (nt < 1 ? 1 : nt);
     const int64_t by_len = ceil_div(n_rows, 64);
     if (nt > by_len) nt = by_len;

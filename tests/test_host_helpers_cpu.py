@@ -1,0 +1,78 @@
+"""Host-side helpers added in round 5, on CPU tensors (no kernel involved): the no-copy concatenation of row views, batched id offsets,
+the packed host->device copy, the per-batch ground-truth rows, the GPU test order."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_cat_views_returns_the_base_only_for_a_full_consecutive_cover():
+    from unidet3d_amd.ops import cat_views
+    base = torch.arange(40.).reshape(10, 4).requires_grad_()
+    y = base * 2                                                    # a non-leaf the views hang off (autograd must flow through it)
+    parts = [y[0:3], y[3:3], y[3:7], y[7:10]]                       # incl. an empty slice
+    out = cat_views(parts)
+    assert out is y
+    assert cat_views([y[0:3]]) is not y and torch.equal(cat_views([y[0:3]]), y[0:3])          # single element: returned as is
+    for bad in ([y[0:3], y[4:10]], [y[3:7], y[0:3], y[7:10]], [y[0:5], y[5:9]], [y[:, :2][0:5], y[:, :2][5:10]], [y[0:5], (base * 3)[5:10]]):
+        got = cat_views(bad)
+        assert got is not y and torch.equal(got, torch.cat(bad))
+    out.sum().backward()
+    assert torch.equal(base.grad, torch.full_like(base, 2.0))
+    assert torch.equal(cat_views([torch.ones(2, 3), torch.zeros(1, 3)]), torch.tensor([[1., 1, 1], [1, 1, 1], [0, 0, 0]]))   # plain tensors: cat
+
+
+def test_offset_ids_matches_the_per_scene_loop():
+    from unidet3d_amd.ops import offset_ids
+    g = torch.Generator().manual_seed(3)
+    ids = [torch.randint(-1, 5, (n,), generator=g) for n in (7, 1, 12)]
+    biases = [0, 5, 9]
+    ref_keep = torch.cat([torch.where(t >= 0, t + b, t) for t, b in zip(ids, biases)])
+    ref_plain = torch.cat([t + b for t, b in zip(ids, biases)])
+    assert torch.equal(offset_ids(ids, biases, keep_negative=True), ref_keep)
+    assert torch.equal(offset_ids(ids, biases), ref_plain)
+    assert torch.equal(offset_ids([ids[0]], [4], keep_negative=True), torch.where(ids[0] >= 0, ids[0] + 4, ids[0]))
+    assert all(torch.equal(a, b) for a, b in zip(ids, [t.clone() for t in ids]))              # inputs untouched
+
+
+def test_h2d_pack_round_trips_mixed_dtypes_and_empty_lists():
+    from unidet3d_amd._lib import h2d_pack
+    specs = [([0, 3, 7], torch.int32), ([1, 2, 3, 4, 5], torch.int64), ([[1, 2, 3, 4], [5, 6, 7, 8]], torch.int32), ([0.5, 1.5], torch.float32),
+             ([], torch.int32), ([9], torch.int64)]
+    out = h2d_pack(specs, 'cpu')
+    assert [o.dtype for o in out] == [d for _, d in specs]
+    for o, (v, d) in zip(out, specs):
+        assert torch.equal(o, torch.tensor(v, dtype=d).reshape(-1))
+        assert o.numel() == 0 or o.data_ptr() % 16 == 0
+
+
+def test_batch_box_object_hands_row_views_of_its_cached_rows():
+    from unidet3d_amd.criterion import _gt_boxes
+    from unidet3d_amd.structures import DepthInstance3DBoxes
+    g = torch.Generator().manual_seed(5)
+    raw = torch.rand(9, 6, generator=g) + 0.5
+    whole = DepthInstance3DBoxes(raw, with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5))
+    whole.cache_gt_rows()
+    per_scene = [DepthInstance3DBoxes(raw[a:b], with_yaw=False, box_dim=6, origin=(0.5, 0.5, 0.5)) for a, b in ((0, 4), (4, 4), (4, 9))]
+    for (a, b), ref in zip(((0, 4), (4, 4), (4, 9)), per_scene):
+        part = whole[a:b]
+        assert torch.equal(part.tensor, ref.tensor)                                          # element-wise round trip: same bits batched or not
+        assert part.gt_rows is not None and part.gt_rows.data_ptr() == whole.gt_rows[a:b].data_ptr()
+        assert torch.equal(_gt_boxes(part), _gt_boxes(ref))
+    assert whole[torch.tensor([1, 3])].gt_rows is None                                       # fancy indexing: no stale cache
+    assert whole.to('cpu').gt_rows is None
+
+
+def test_gpu_files_are_collected_parity_first_infrastructure_last():
+    import conftest
+    class It:                                                    # noqa: E306
+        def __init__(self, f): self.fspath = f
+    files = ['tests/test_gpu_dist.py', 'tests/test_gpu_bf16.py', 'tests/test_cabi.py', 'tests/test_gpu_eval.py', 'tests/test_gpu_kernels.py',
+             'tests/test_gpu_model.py', 'tests/test_gpu_postproc.py', 'tests/test_gpu_ref_golden.py', 'tests/test_gpu_full_size.py',
+             'tests/test_gpu_gradients.py']
+    order = [os.path.basename(i.fspath) for i in sorted((It(f) for f in files), key=conftest._file_rank)]
+    assert order == ['test_gpu_kernels.py', 'test_gpu_model.py', 'test_gpu_ref_golden.py', 'test_gpu_full_size.py', 'test_gpu_gradients.py',
+                     'test_gpu_postproc.py', 'test_gpu_eval.py', 'test_cabi.py', 'test_gpu_bf16.py', 'test_gpu_dist.py']

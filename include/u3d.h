@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 111
+#define U3D_ABI_VERSION 112
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -212,6 +212,25 @@ int u3d_weight_pack_batch(const void* desc, int n_desc, int64_t total_blocks, u3
 int u3d_spconv_plan(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups);
 /* the plan u3d_spconv_gmm_bf16a wants (its light items prefer 32-row tiles and fewer offset groups at the small levels) */
 int u3d_spconv_plan_bf16a(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, int* k_groups);
+/* ---- tile-stationary SubMConv3d(k=3) (csrc/spconv_ts.hip; unidet3d/spconv_unet.py:43-56): accumulators of a row tile in registers
+ * for all 27 offsets and all C_out columns, every source row of a tile fetched once.
+ * u3d_subm_halo builds, per tile of tile_rows consecutive rows (64 / 128 / 256) of a level, from the same occupancy index the
+ * rulebook uses:  nhalo int32 [n_tiles]; halo int32 [n_tiles][27*tile_rows] -- the sorted unique source rows of the tile's
+ * (row, offset) neighbours, the first nhalo[t] entries valid;  loc uint16 [n_tiles][27][tile_rows] -- position of neighbour k of
+ * row r in that list, 0xFFFF = none;  pmask uint32 [n_tiles][pmax] -- bit k of word p: offset k has a neighbour among entries
+ * [p*halo_rows, (p+1)*halo_rows) of the list (pmax = u3d_subm_halo_pmax(tile_rows, halo_rows) <= 64).  Integer-only, deterministic.
+ * u3d_spconv_ts_x3: dst[r] = addend[r] + sum_k W_k' . src[neighbour_k(r)] with fp32 products from three bf16 planes (weights from
+ * u3d_weight_pack_x3, K = 27); flip = 0: k' = k (forward); flip = 1: k' = 26 - k with the TRANSPOSED pack -- the input gradient
+ * (SubM pairs are symmetric).  tile_rows / halo_rows must be the pair the tables were built for (u3d_spconv_ts_plan gives the
+ * measured choice per shape, U3D_EUNSUPPORTED for shapes the kernel is not instantiated for -- the caller then uses u3d_spconv_gmm_x3). */
+int u3d_spconv_ts_plan(int Cs, int Cd, int64_t n, int* tile_rows, int* halo_rows);
+int u3d_subm_halo_pmax(int tile_rows, int halo_rows);
+int u3d_subm_halo(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots, int B,
+                  int X, int Y, int Z, int tile_rows, int halo_rows, int32_t* nhalo, int32_t* halo, uint16_t* loc, uint32_t* pmask,
+                  u3d_stream_t stream);
+int u3d_spconv_ts_x3(const float* src, int64_t n, const void* w_rows_x3, const int32_t* nhalo, const int32_t* halo, const uint16_t* loc,
+                     const uint32_t* pmask, int tile_rows, int halo_rows, int flip, int Cs, int Cd, const float* addend, float* dst,
+                     double flops_hint, u3d_stream_t stream);
 /* dW[(n*K+k)*Cs + c] = sum_p dy[rows_dy[k][p]][n] * x[rows_x[k][p]][c]   (dW is overwritten).
  * The pairs of offset k are processed per tile of dy rows: tile_starts = u3d_tile_starts(rows_dy, ..., tile_rows =
  * u3d_spconv_wgrad_tile_rows(...)); per-tile partial blocks go through ws and are summed in a fixed order

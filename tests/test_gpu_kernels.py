@@ -104,13 +104,16 @@ def _level_geometry(n_points=12_000, vs=0.05):
     return vb, oc, oshape
 
 
-@pytest.fixture(params=['bf16x3', 'bf16x3-wavetile', 'mfma'])
+@pytest.fixture(params=['bf16x3', 'bf16x3-pairs', 'bf16x3-wavetile', 'mfma'])
 def math_mode(request):
     """both ways of forming fp32 products (precision.fp32_math): three exact bf16 planes per operand on the bf16 matrix pipe
-    (the default; sparse convolutions through the workgroup-tile kernel and, '-wavetile', the wave-tile kernel) and the
-    native fp32 MFMAs"""
+    (the default: SubM convolutions through the tile-stationary kernel where it is instantiated, the rest through the
+    workgroup-tile pair kernel; '-pairs': every convolution through the workgroup-tile pair kernel; '-wavetile': the wave-tile
+    pair kernel) and the native fp32 MFMAs"""
     from unidet3d_amd import precision as P
-    with P.fp32_math(request.param.split('-')[0]), P.conv_kernel('wave' if request.param.endswith('wavetile') else 'workgroup'):
+    from unidet3d_amd import sparse
+    with P.fp32_math(request.param.split('-')[0]), P.conv_kernel('wave' if request.param.endswith('wavetile') else 'workgroup'), \
+            sparse.conv_ts(request.param == 'bf16x3'):
         yield request.param
 
 
@@ -170,7 +173,7 @@ def test_workgroup_tile_conv_equals_wave_tile_conv_bit_for_bit(cin, cout, tile_r
     out = {}
     try:
         for kind in ('wave', 'workgroup-all'):
-            with P.conv_kernel(kind), (P.operands('bf16') if operands == 'bf16' else P.fp32_math('bf16x3')):
+            with P.conv_kernel(kind), (P.operands('bf16') if operands == 'bf16' else P.fp32_math('bf16x3')), sparse.conv_ts(False):
                 xg = x.clone().requires_grad_()
                 y = sparse.sparse_conv(xg, w3, rb, 'fwd', add); y.backward(go)
                 xd = x.clone().requires_grad_()

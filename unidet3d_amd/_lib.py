@@ -53,6 +53,10 @@ PROTOTYPES = {
     'u3d_weight_pack_bf16': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_spconv_gmm_x3': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
     'u3d_weight_pack_x3': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'u3d_spconv_ts_plan': (_i32, [_i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
+    'u3d_subm_halo_pmax': (_i32, [_i32, _i32]),
+    'u3d_subm_halo': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_spconv_ts_x3': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
     'u3d_spconv_plan': (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
     'u3d_spconv_plan_bf16a': (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
     'u3d_spconv_wgrad': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _f64, _vp]),
@@ -111,7 +115,7 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 111         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 112         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

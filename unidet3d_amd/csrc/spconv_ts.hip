@@ -1,0 +1,474 @@
+// Tile-stationary submanifold convolution (round 6): forward and input gradient of SubMConv3d(k = 3) with the accumulators of a
+// row tile in REGISTERS for all 27 offsets and all output columns, and every source row a tile needs fetched ONCE.
+//
+// The pair-list kernels (spconv.hip wave tiles, spconv_wg.hip workgroup tiles) walk an offset's (in, out) pairs: every pair gathers
+// its source row again (11.9 gathers per row at cfg2 level 1, once more per 32-column slice of C_out), splits it into the three bf16
+// planes again, turns it through an LDS image, and adds the product into an LDS accumulator tile by read-modify-write.  Measured
+// (DESIGN.md 4.12): the texture path (14.5 cycles per gathered line that misses L1), the split's VALU time, the LDS staging and the
+// accumulator traffic each cost 10-20 % and add up.
+//
+// Here a workgroup (four waves) owns T = 64 RT consecutive rows of the canonical order.  The rulebook side (subm_halo_k below, once
+// per level and step, reused by the ~17 launches of that level) gives per tile
+//   * halo[tile][..]  : the sorted UNIQUE source rows of the tile's 27 T (row, offset) neighbours -- 2.9-3.8 T rows, not 11.9 T;
+//   * loc[tile][k][r] : the position of neighbour k of row r in that list (uint16, 0xFFFF = no neighbour);
+//   * pmask[tile][p]  : the offsets that have a neighbour among the p-th H entries of the list.
+// The kernel streams the halo through LDS in passes of H rows: each row is loaded once (whole 128-byte lines), split once into
+// its three bf16 planes (u3d_common.h "bf16x3") and stored in MFMA fragment order; then, offset by offset, every wave forms the B
+// operand of its 16-row sub-tiles by one indexed ds_read_b128 per plane (rows without a neighbour in this pass read a zero row),
+// the A operand -- the offset's packed weights, staged once per workgroup in LDS as in spconv_wg.hip -- by ds_read_b128, and issues
+// six v_mfma_f32_16x16x32_bf16 per (16 rows x 16 columns x 32 channels) straight into the tile's accumulators (h.h into the running
+// tile, the five low-order plane products into a second one: the bf16 MFMA truncates products against C).  A 16-row
+// sub-tile without any neighbour for the offset (wave ballot) is skipped.  No pair lists, no scatter index, no accumulator tile in
+// LDS, no per-pair split, no offset-group partial buffers and no reduce launch.  The price is matrix work on the zero rows: 1.7-2x
+// the pair count at cfg2 (tools/halo_stats.py) on a matrix pipe the pair kernels leave ~85 % idle.
+//
+// The input gradient is the same launch with the offsets mirrored (SubM pairs are symmetric: in = out + d_k  <=>  the source of
+// gradient row i at offset k is its neighbour 26 - k) and the transposed weight pack.
+// Replaces spconv's implicit-GEMM SubMConv3d behind unidet3d/spconv_unet.py:43-56 (reference); results differ from the pair kernels
+// only in fp32 summation order (offsets ascending per pass instead of ascending overall).
+#include <limits.h>
+#include <stdlib.h>
+
+#include "u3d_common.h"
+
+// -DU3D_TS_ABL=<mask>: timing ablations (tools/build_variant.sh), WRONG results by construction.  1: no MFMAs, 2: no halo row loads /
+// split / LDS writes, 4: no weight staging, 8: no barriers inside the offset loop, 16: no split arithmetic, 32: no fragment reads
+#ifndef U3D_TS_ABL
+#define U3D_TS_ABL 0
+#endif
+
+namespace u3d {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ts_bf16x8;
+
+__device__ __forceinline__ f32x4 ts_mfma(const f32x4& a, const ts_bf16x8& b, const f32x4& c) {
+#if U3D_TS_ABL & 1
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ts_bf16x8, a), b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ void ts_barrier() {      // this wave's LDS traffic done, then the workgroup barrier; vmcnt is NOT drained
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ---- rulebook side: per-tile unique source rows + local positions -------------------------------------------------------------
+__device__ __forceinline__ int ts_lookup(const int32_t* __restrict__ coords, int64_t o, int k, const Index& ix) {
+    const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+    const int4 c = *reinterpret_cast<const int4*>(coords + o * 4);
+    return index_lookup(ix, c.x, c.y + dx, c.z + dy, c.w + dz);
+}
+
+// One workgroup per tile of T rows.  NS: power of two >= 27 T (bitonic sort of the candidates in LDS).
+template <int T, int NS>
+__global__ __launch_bounds__(256) void subm_halo_k(const int32_t* __restrict__ coords, int64_t n, Index ix, int H, int pmax,
+                                                   int32_t* __restrict__ nhalo, int32_t* __restrict__ halo, uint16_t* __restrict__ loc,
+                                                   uint32_t* __restrict__ pmask) {
+    constexpr int NC = 27 * T, CPT = (NC + 255) / 256, EP = NS / 256;
+    static_assert(NS >= NC && EP <= 32, "sort size");
+    __shared__ int srt[NS];
+    __shared__ int ubuf[NC];
+    __shared__ int wsum[4];
+    __shared__ unsigned pm[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = blockIdx.x, r0 = tile * T;
+    int cand[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int idx = tid + 256 * j;
+        int v = -1;
+        if (idx < NC) {
+            const int k = idx / T, r = idx - k * T;
+            const int64_t row = r0 + r;
+            if (row < n) v = ts_lookup(coords, row, k, ix);
+            srt[idx] = v >= 0 ? v : INT_MAX;
+        }
+        cand[j] = v;
+    }
+    for (int idx = NC + tid; idx < NS; idx += 256) srt[idx] = INT_MAX;
+    if (tid < 64) pm[tid] = 0u;
+    __syncthreads();
+    for (int k = 2; k <= NS; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int pi = tid; pi < NS / 2; pi += 256) {
+                const int i = ((pi & ~(j - 1)) << 1) | (pi & (j - 1));
+                const int l = i | j;
+                const int a = srt[i], b = srt[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { srt[i] = b; srt[l] = a; }
+            }
+            __syncthreads();
+        }
+    // unique: every thread flags its EP consecutive entries, block scan of the counts, compaction into ubuf
+    const int i0 = tid * EP;
+    int prev = i0 ? srt[i0 - 1] : -1;
+    unsigned flags = 0u;
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+        const int v = srt[i0 + e];
+        const bool f = v != INT_MAX && v != prev;
+        flags |= (f ? 1u : 0u) << e;
+        cnt += f ? 1 : 0;
+        prev = v;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, nh = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int t = wsum[w]; if (w < wave) woff += t; nh += t; }
+    int pos = woff + incl - cnt;
+#pragma unroll
+    for (int e = 0; e < EP; ++e)
+        if ((flags >> e) & 1u) ubuf[pos++] = srt[i0 + e];
+    __syncthreads();
+    for (int i = tid; i < nh; i += 256) halo[tile * NC + i] = ubuf[i];
+    if (tid == 0) nhalo[tile] = nh;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < NC) {
+            const int k = idx / T, r = idx - k * T;
+            const int v = cand[j];
+            unsigned short o = 0xFFFFu;
+            if (v >= 0) {
+                int lo = 0, hi = nh;            // first entry >= v (v is in the list)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ubuf[mid] < v) lo = mid + 1; else hi = mid;
+                }
+                o = (unsigned short)lo;
+                atomicOr(&pm[lo / H], 1u << k);
+            }
+            loc[(tile * 27 + k) * T + r] = o;
+        }
+    }
+    __syncthreads();
+    if (tid < pmax) pmask[tile * pmax + tid] = pm[tid];
+}
+
+// ---- the convolution ---------------------------------------------------------------------------------------------------------------
+struct TsParams {
+    const float* src;
+    const void* w;             // u3d_weight_pack_x3 layout: [slice][k][unit][column block][plane][lane] 16-byte vectors
+    const int32_t* nhalo;
+    const int32_t* halo;
+    const uint16_t* loc;
+    const uint32_t* pmask;
+    const float* addend;
+    float* out;
+    int64_t n;
+    int Cs, Cd;
+    int n_tiles, pmax, flip;
+};
+
+constexpr int ts_halo_bytes(int cs32, int h) { return cs32 * 3 * (h + 1) * 64; }
+constexpr int ts_wslot_bytes(int cs32, int cd16) { return (cd16 / 2) * cs32 * 6144; }
+constexpr int ts_lds_bytes(int cs32, int cd16, int h, int nslot) { return ts_halo_bytes(cs32, h) + nslot * ts_wslot_bytes(cs32, cd16); }
+constexpr int ts_per_cu(int bytes) { return 160 * 1024 / bytes > 4 ? 4 : 160 * 1024 / bytes; }      // (registers allow four workgroups per CU at most)
+// two weight slots (one barrier per offset) unless the second slot costs a workgroup per CU (then one slot, two barriers)
+constexpr int ts_nslot(int cs32, int cd16, int h) {
+    return ts_per_cu(ts_lds_bytes(cs32, cd16, h, 2)) >= ts_per_cu(ts_lds_bytes(cs32, cd16, h, 1)) ? 2 : 1;
+}
+
+// byte offset of 16-byte chunk q of slot s inside a (unit, plane) image: 64-byte rows, chunk stored at q ^ ((-(s >> 2)) & 3) -- with
+// ds_read_b128's lane groups ({0-3, 12-15, 20-27}, ...) sixteen consecutive slots are then conflict-free (MI355X_MICROARCH.md LDS)
+__device__ __forceinline__ int ts_slot_off(int s, int q) { return (s << 6) | ((q ^ ((0 - (s >> 2)) & 3)) << 4); }
+
+// CS32: 32-channel units of the source rows; CD16: 16-column blocks of the output; RT: 16-row sub-tiles per wave (T = 64 RT rows per
+// workgroup); H: halo rows per pass; NSLOT: LDS copies of an offset's weights (2: one barrier per offset, 1: two)
+template <int CS32, int CD16, int RT, int H, int NSLOT>
+__global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+    constexpr int T = 64 * RT, NC = 27 * T, NSL = CD16 / 2;
+    constexpr int PLANE = (H + 1) * 64, HALO = ts_halo_bytes(CS32, H), WSLOT = ts_wslot_bytes(CS32, CD16);
+    constexpr int NPIECE = WSLOT / 16, NP = (NPIECE + 255) / 256;
+    constexpr int ROUNDS = H / 32;
+    static_assert(H % 32 == 0 && NPIECE % 64 == 0, "tile shapes");
+    char* const hl = ts_smem;
+    char* const wl = ts_smem + HALO;
+    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (int)xcd_swizzle(blockIdx.x, gridDim.x);      // neighbouring tiles (shared halo rows) on one XCD / L2
+    const int64_t r0 = (int64_t)tile * T;
+
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(p.src, p.n * p.Cs * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w);
+    const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(p.halo + (int64_t)tile * NC, (int64_t)NC * 4);
+    const __amdgpu_buffer_rsrc_t rs_l = make_rsrc(p.loc + (int64_t)tile * NC, (int64_t)NC * 2);
+    const int cs4 = p.Cs * 4;
+    const int nh = __builtin_amdgcn_readfirstlane(p.nhalo[tile]);
+    const int npass = (nh + H - 1) / H;
+    const uint32_t* pmk = p.pmask + (int64_t)tile * p.pmax;
+
+    f32x4 hi[RT][CD16], lo[RT][CD16];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nb = 0; nb < CD16; ++nb) { hi[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (tid < CS32 * 3 * 4) *reinterpret_cast<f32x4*>(hl + (tid >> 2) * PLANE + H * 64 + (tid & 3) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};      // the zero row
+
+    const int loc_lane = (wave * 16 * RT + i16) * 2;              // byte offset of this lane's entry for (table offset 0, sub-tile 0)
+    const int pc = tid & 7, prow = tid >> 3;                      // load phase: 16-byte piece of the row, row within a round of 32
+    const int w_wr = tid * 16, w_rd = lane * 16;
+
+    f32x4 wreg[NP];
+    auto wk_of = [&](int kk) { return p.flip ? 26 - kk : kk; };
+    auto load_w = [&](int kk) {        // weights of table offset kk -> registers (NSL slices x CS32 units x 6 KB, contiguous per slice)
+        const int k = wk_of(kk);
+        if (U3D_TS_ABL & 4) return;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int piece = tid + i * 256;                      // 16-byte piece of the slot
+            if ((i + 1) * 256 <= NPIECE || piece < NPIECE) {
+                const int sl = piece / (CS32 * 384), rem = piece - sl * (CS32 * 384);
+                wreg[i] = bload128(rs_w, rem * 16 + ((sl * 27 + k) * CS32) * 6144, 0);
+            }
+        }
+    };
+    auto write_w = [&](int slot) {
+        if (U3D_TS_ABL & 4) return;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if ((i + 1) * 256 <= NPIECE || tid + i * 256 < NPIECE) *reinterpret_cast<f32x4*>(wl + slot * WSLOT + w_wr + i * 4096) = wreg[i];
+    };
+    auto next_k = [](unsigned mask, int after) -> int {           // lowest set bit above `after` (32: none)
+        const unsigned rest = after >= 31 ? 0u : mask & (~1u << after);
+        return rest ? __builtin_ctz(rest) : 32;
+    };
+
+    for (int ps = 0; ps < npass; ++ps) {
+        const unsigned km = __builtin_amdgcn_readfirstlane(pmk[ps]);
+        const int cnt = min(H, nh - ps * H);
+        if (ps) ts_barrier();                                     // every wave is done with the previous pass's rows and weight slots
+        int kk = km ? __builtin_ctz(km) : 32;
+        if (kk < 32) load_w(kk);
+        // ---- halo rows of this pass: global -> three bf16 planes in LDS (fragment order) ----
+        int hrow[ROUNDS];
+#if !(U3D_TS_ABL & 2)
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) hrow[j] = bload32(rs_h, (ps * H + j * 32 + prow) * 4, 0);
+#pragma unroll
+        for (int j0 = 0; j0 < ROUNDS; j0 += 4) {
+            f32x4 v[4][CS32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j0 + j < ROUNDS) {
+                    const bool ok = (j0 + j) * 32 + prow < cnt;
+                    const int ro = ok ? (int)__umul24(hrow[j0 + j], cs4) + pc * 16 : 0x7ffffff0;      // past the end: the load returns zeros
+#pragma unroll
+                    for (int u = 0; u < CS32; ++u) v[j][u] = bload128(rs_src, ro, u * 128);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j0 + j < ROUNDS) {
+                    const int s = (j0 + j) * 32 + prow;
+                    const int off = ts_slot_off(s, pc & 3) + (pc >> 2) * 8;
+#pragma unroll
+                    for (int u = 0; u < CS32; ++u) {
+                        unsigned h0, m0, l0, h1, m1, l1;
+#if U3D_TS_ABL & 16
+                        h0 = m0 = __builtin_bit_cast(unsigned, v[j][u][0]); l0 = h1 = __builtin_bit_cast(unsigned, v[j][u][1]);
+                        m1 = __builtin_bit_cast(unsigned, v[j][u][2]); l1 = __builtin_bit_cast(unsigned, v[j][u][3]);
+#else
+                        split3_pair(v[j][u][0], v[j][u][1], h0, m0, l0);
+                        split3_pair(v[j][u][2], v[j][u][3], h1, m1, l1);
+#endif
+                        char* const b = hl + u * 3 * PLANE + off;
+                        *reinterpret_cast<uint2*>(b) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(b + PLANE) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2*>(b + 2 * PLANE) = make_uint2(l0, l1);
+                    }
+                }
+        }
+#endif
+        int lcur[RT], lnxt[RT];
+        if (kk < 32) {
+            write_w(0);
+            const int kn = next_k(km, kk);
+            if (kn < 32) load_w(kn);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) lcur[rt] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_l, loc_lane + rt * 32, kk * (T * 2), 0);
+        }
+        ts_barrier();
+        int step = 0;
+        while (kk < 32) {
+            const int kn = next_k(km, kk);
+            if (kn < 32) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) lnxt[rt] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_l, loc_lane + rt * 32, kn * (T * 2), 0);
+            }
+            const char* const wsl = wl + (NSLOT == 2 ? (step & 1) * WSLOT : 0) + w_rd;
+            bool any[RT];
+            ts_bf16x8 x[RT][CS32][3];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int s0 = lcur[rt] - ps * H;
+                const bool ok = (unsigned)s0 < (unsigned)cnt;
+                any[rt] = __ballot(ok) != 0ull;
+                if (any[rt]) {
+                    const int a0 = ts_slot_off(ok ? s0 : H, q);
+#pragma unroll
+                    for (int u = 0; u < CS32; ++u)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            if (U3D_TS_ABL & 32) x[rt][u][pl] = __builtin_bit_cast(ts_bf16x8, f32x4{(float)a0, 1.f, 2.f, (float)pl});
+                            else x[rt][u][pl] = *reinterpret_cast<const ts_bf16x8*>(hl + (u * 3 + pl) * PLANE + a0);
+                        }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CS32; ++u)
+#pragma unroll
+                for (int nb = 0; nb < CD16; ++nb) {
+                    f32x4 wf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        if (U3D_TS_ABL & 32) wf[pl] = f32x4{(float)lane, 1.f, (float)nb, (float)pl};
+                        else wf[pl] = *reinterpret_cast<const f32x4*>(wsl + ((((nb >> 1) * CS32 + u) * 2 + (nb & 1)) * 3 + pl) * 1024);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        if (any[rt]) {
+                            f32x4 c = lo[rt][nb];
+                            c = ts_mfma(wf[0], x[rt][u][2], c);
+                            c = ts_mfma(wf[1], x[rt][u][1], c);
+                            c = ts_mfma(wf[2], x[rt][u][0], c);
+                            c = ts_mfma(wf[0], x[rt][u][1], c);
+                            c = ts_mfma(wf[1], x[rt][u][0], c);
+                            lo[rt][nb] = c;
+                            hi[rt][nb] = ts_mfma(wf[0], x[rt][u][0], hi[rt][nb]);
+                        }
+                }
+            // ---- hand over to the next offset of this pass ----
+            if (kn < 32) {
+                if constexpr (NSLOT == 1 && !(U3D_TS_ABL & 8)) ts_barrier();           // every wave has read the slot for the last time
+                write_w(NSLOT == 2 ? ((step + 1) & 1) : 0);
+                const int kn2 = next_k(km, kn);
+                if (kn2 < 32) load_w(kn2);
+                if (!(U3D_TS_ABL & 8)) ts_barrier();
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) lcur[rt] = lnxt[rt];
+            }
+            kk = kn;
+            ++step;
+        }
+    }
+
+    // ---- write-out: lane (i16, q) holds columns 16 nb + 4 q .. + 3 of row i16 of each sub-tile ----
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t row = r0 + wave * (16 * RT) + rt * 16 + i16;
+        if (row < p.n) {
+#pragma unroll
+            for (int nb = 0; nb < CD16; ++nb) {
+                f32x4 v = hi[rt][nb] + lo[rt][nb];
+                const int64_t o = row * p.Cd + nb * 16 + q * 4;
+                if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + o);
+                *reinterpret_cast<f32x4*>(p.out + o) = v;
+            }
+        }
+    }
+}
+
+template <int CS32, int CD16, int RT, int H>
+static int launch_ts(const TsParams& p, hipStream_t s) {
+    constexpr int NSLOT = ts_nslot(CS32, CD16, H);
+    constexpr int lds = ts_lds_bytes(CS32, CD16, H, NSLOT);
+    static_assert(lds <= 160 * 1024, "tile exceeds the LDS");
+    // the attribute is per device and cheap to set: no cache keyed by ordinal (a 64-entry table aliased devices >= 64)
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_ts_k<CS32, CD16, RT, H, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((spconv_ts_k<CS32, CD16, RT, H, NSLOT>), dim3((unsigned)p.n_tiles), dim3(256), lds, s, p);
+    return check_launch("spconv_ts");
+}
+
+// launch plan: rows per tile T and halo rows per pass H by shape (tools/prof_ts.py sweeps; U3D_TS_T / U3D_TS_H override for A/B runs)
+static bool ts_plan(int Cs, int Cd, int64_t n, int* T, int* H) {
+    if (Cs % 32 || Cd % 32 || n <= 0) return false;
+    const int cs32 = Cs / 32, cd16 = Cd / 16;
+    int t = 0, h = 0;
+    if (cs32 == 1 && cd16 == 2) { t = 128; h = 192; }
+    else if (cs32 == 2 && cd16 == 2) { t = 128; h = 128; }
+    else if (cs32 == 1 && cd16 == 4) { t = 128; h = 192; }
+    else if (cs32 == 2 && cd16 == 4) { t = 128; h = 128; }
+    else return false;
+    const char* et = getenv("U3D_TS_T");      // read per call: tools/prof_ts.py sweeps the plan inside one process
+    const char* eh = getenv("U3D_TS_H");
+    if (et && atoi(et) > 0) t = atoi(et);
+    if (eh && atoi(eh) > 0) h = atoi(eh);
+    *T = t; *H = h;
+    return true;
+}
+
+}  // namespace u3d
+
+using namespace u3d;
+
+extern "C" {
+
+int u3d_spconv_ts_plan(int Cs, int Cd, int64_t n, int* tile_rows, int* halo_rows) {
+    if (!tile_rows || !halo_rows || !ts_plan(Cs, Cd, n, tile_rows, halo_rows)) return U3D_EUNSUPPORTED;
+    return U3D_OK;
+}
+
+int u3d_subm_halo_pmax(int tile_rows, int halo_rows) {
+    if (tile_rows <= 0 || halo_rows <= 0) return U3D_EINVAL;
+    return (27 * tile_rows + halo_rows - 1) / halo_rows;
+}
+
+int u3d_subm_halo(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots, int B,
+                  int X, int Y, int Z, int tile_rows, int halo_rows, int32_t* nhalo, int32_t* halo, uint16_t* loc, uint32_t* pmask,
+                  u3d_stream_t stream) {
+    if (!coords || !bitmap || !word_rank || !nhalo || !halo || !loc || !pmask || n <= 0 || halo_rows <= 0) return U3D_EINVAL;
+    if (n >= (1 << 24)) { set_error("subm_halo: %lld rows exceed the kernels' 24-bit row indices", (long long)n); return U3D_EUNSUPPORTED; }
+    const int pmax = u3d_subm_halo_pmax(tile_rows, halo_rows);
+    if (pmax > 64) { set_error("subm_halo: %d passes per tile (tile %d, halo %d) exceed 64", pmax, tile_rows, halo_rows); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_RULEBOOK, s, 0.0);
+    const Index ix = make_index(bitmap, word_rank, B, X, Y, Z, hash_slots);
+    const unsigned nt = (unsigned)ceil_div(n, tile_rows);
+    if (tile_rows == 64) hipLaunchKernelGGL((subm_halo_k<64, 2048>), dim3(nt), dim3(256), 0, s, coords, n, ix, halo_rows, pmax, nhalo, halo, loc, pmask);
+    else if (tile_rows == 128) hipLaunchKernelGGL((subm_halo_k<128, 4096>), dim3(nt), dim3(256), 0, s, coords, n, ix, halo_rows, pmax, nhalo, halo, loc, pmask);
+    else if (tile_rows == 256) hipLaunchKernelGGL((subm_halo_k<256, 8192>), dim3(nt), dim3(256), 0, s, coords, n, ix, halo_rows, pmax, nhalo, halo, loc, pmask);
+    else { set_error("subm_halo: tile_rows %d not in {64, 128, 256}", tile_rows); return U3D_EUNSUPPORTED; }
+    return check_launch("subm_halo");
+}
+
+int u3d_spconv_ts_x3(const float* src, int64_t n, const void* w_rows_x3, const int32_t* nhalo, const int32_t* halo, const uint16_t* loc,
+                     const uint32_t* pmask, int tile_rows, int halo_rows, int flip, int Cs, int Cd, const float* addend, float* dst,
+                     double flops_hint, u3d_stream_t stream) {
+    if (!src || !w_rows_x3 || !nhalo || !halo || !loc || !pmask || !dst || n <= 0) return U3D_EINVAL;
+    if (n >= (1 << 24) || n * Cs * 4 >= 0x7fffffffLL) {
+        set_error("spconv_ts: %lld rows x %d channels exceed the kernel's 32-bit addressing", (long long)n, Cs);
+        return U3D_EUNSUPPORTED;
+    }
+    if (Cs % 32 || Cd % 32) { set_error("spconv_ts: Cs=%d Cd=%d must be multiples of 32", Cs, Cd); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_CONV_FWD, s, flops_hint);
+    TsParams p;
+    p.src = src; p.w = w_rows_x3; p.nhalo = nhalo; p.halo = halo; p.loc = loc; p.pmask = pmask; p.addend = addend; p.out = dst;
+    p.n = n; p.Cs = Cs; p.Cd = Cd; p.n_tiles = (int)ceil_div(n, tile_rows); p.pmax = u3d_subm_halo_pmax(tile_rows, halo_rows); p.flip = flip ? 1 : 0;
+    const int cs32 = Cs / 32, cd16 = Cd / 16;
+#define U3D_TS_CASE(cs, cd, rt, h) if (cs32 == cs && cd16 == cd && tile_rows == 64 * rt && halo_rows == h) return launch_ts<cs, cd, rt, h>(p, s);
+    U3D_TS_CASE(1, 2, 2, 128) U3D_TS_CASE(1, 2, 2, 192) U3D_TS_CASE(1, 2, 2, 256)
+    U3D_TS_CASE(1, 2, 4, 128) U3D_TS_CASE(1, 2, 4, 192) U3D_TS_CASE(1, 2, 4, 256)
+    U3D_TS_CASE(1, 2, 1, 128)
+    U3D_TS_CASE(2, 2, 2, 128) U3D_TS_CASE(2, 2, 2, 192) U3D_TS_CASE(2, 2, 4, 128)
+    U3D_TS_CASE(1, 4, 2, 128) U3D_TS_CASE(1, 4, 2, 192) U3D_TS_CASE(1, 4, 4, 128)
+    U3D_TS_CASE(2, 4, 2, 128) U3D_TS_CASE(2, 4, 1, 128) U3D_TS_CASE(2, 4, 2, 192) U3D_TS_CASE(2, 4, 4, 128)
+#undef U3D_TS_CASE
+    set_error("spconv_ts: no instantiation for Cs=%d Cd=%d tile %d halo %d", Cs, Cd, tile_rows, halo_rows);
+    return U3D_EUNSUPPORTED;
+}
+
+}  // extern "C"

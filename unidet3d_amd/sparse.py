@@ -16,6 +16,7 @@ produce.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Dict, Optional
 
@@ -140,6 +141,8 @@ class Rulebook:
         self._tiles: Dict = {}
         self._total = None
         self.tag = None             # set by the layer that caches it (indice_key): lets the tile lists follow last step's use
+        self.coords = self.index = None      # SubM rulebooks: the level's voxels and occupancy index (tile-stationary kernel's tables)
+        self._halo: Dict = {}
 
     def _tile_starts(self, role: str, T: int) -> torch.Tensor:
         key = (role, T)
@@ -159,6 +162,31 @@ class Rulebook:
             _TILE_HISTORY.setdefault(self.tag, set()).add((role, T) if wgrad is None else (role, 'wgrad', int(wgrad[0]), int(wgrad[1])))
         return self._tile_starts(role, T)
 
+    def halo(self, T: int, H: int):
+        """Tables of the tile-stationary SubM kernel (csrc/spconv_ts.hip, u3d_subm_halo) for tiles of T rows and passes of H halo
+        rows: (nhalo, halo, loc, pmask).  Built once per rulebook and (T, H); remembered like the tile lists so that the next step's
+        rulebook builds them on the side stream."""
+        if self.tag is not None:
+            _TILE_HISTORY.setdefault(self.tag, set()).add(('halo', int(T), int(H)))
+        return self._halo_tables(int(T), int(H))
+
+    def _halo_tables(self, T: int, H: int):
+        key = (T, H)
+        if key not in self._halo:
+            if self.coords is None:
+                raise L.U3DError('halo tables need a SubM rulebook built by build_subm_rulebook')
+            n, dev = self.n_out, self.coords.device
+            nt = (n + T - 1) // T
+            pmax = L.lib().u3d_subm_halo_pmax(T, H)
+            nhalo = torch.empty(nt, dtype=torch.int32, device=dev)
+            halo = torch.empty(nt, 27 * T, dtype=torch.int32, device=dev)
+            loc = torch.empty(nt, 27, T, dtype=torch.int16, device=dev)
+            pmask = torch.empty(nt, pmax, dtype=torch.int32, device=dev)
+            L.call('u3d_subm_halo', L.ptr(self.coords), n, *self.index.table(), self.index.B, *self.index.shape, T, H,
+                   L.ptr(nhalo), L.ptr(halo), L.ptr(loc), L.ptr(pmask), L.stream())
+            self._halo[key] = (nhalo, halo, loc, pmask)
+        return self._halo[key]
+
     def precompute_tiles(self):
         """Build the tile lists the PREVIOUS rulebook with this tag was asked for: fixed heights (the forward / input-gradient kernels'
         32 / 64 rows) as they were, weight-gradient heights recomputed for THIS rulebook's row count.  Only this step's real requests
@@ -166,7 +194,10 @@ class Rulebook:
         if self.tag is None or not _TILE_PRECOMPUTE:
             return
         for key in sorted(_TILE_HISTORY.pop(self.tag, ()), key=str):
-            if len(key) == 2:
+            if key[0] == 'halo':
+                if self.coords is not None and self.n_out > 0:
+                    self._halo_tables(key[1], key[2])
+            elif len(key) == 2:
                 self._tile_starts(*key)
             else:
                 role, _, cin, cout = key
@@ -201,7 +232,9 @@ def build_subm_rulebook(coords: torch.Tensor, index: OccupancyIndex) -> Rulebook
     w = L.ws(L.lib().u3d_subm_rulebook_ws_bytes(n), dev)
     L.call('u3d_subm_rulebook', L.ptr(coords), n, *index.table(), index.B, *index.shape,
            L.ptr(pin), L.ptr(pout), L.ptr(cnt), L.ptr(w), L.stream())
-    return Rulebook(pin, pout, cnt, 27, n, n)
+    rb = Rulebook(pin, pout, cnt, 27, n, n)
+    rb.coords, rb.index = coords, index
+    return rb
 
 
 def build_down_rulebook(coords: torch.Tensor, B: int, shape):
@@ -352,6 +385,34 @@ def _pack_floats(numel: int, fmt: int) -> int:
     return {0: numel, 1: numel // 2, 2: numel * 3 // 2}[fmt]
 
 
+# Tile-stationary SubM kernel (csrc/spconv_ts.hip) for the three-plane fp32 path wherever u3d_spconv_ts_plan has a shape for it;
+# U3D_CONV_TS=0 / set_conv_ts(False) keeps every convolution on the pair-list kernels (A/B runs, tests).
+_CONV_TS = os.environ.get('U3D_CONV_TS', '1') != '0'
+
+
+def set_conv_ts(on: bool) -> bool:
+    global _CONV_TS
+    prev, _CONV_TS = _CONV_TS, bool(on)
+    return prev
+
+
+@contextlib.contextmanager
+def conv_ts(on: bool):
+    prev = set_conv_ts(on)
+    try:
+        yield
+    finally:
+        set_conv_ts(prev)
+
+
+def _ts_plan(Cs, Cd, n):
+    import ctypes
+    T, H = ctypes.c_int(0), ctypes.c_int(0)
+    if L.lib().u3d_spconv_ts_plan(Cs, Cd, n, ctypes.byref(T), ctypes.byref(H)) != 0:
+        return None
+    return T.value, H.value
+
+
 def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flops, bf=0, stats_out=None, src_rows_bf16=None):
     """weight: the layer's [C_out, K, C_in] tensor; transposed=True runs the input-gradient (dst channels = C_in).
     ``stats_out`` (a dict, or None): asks the kernel's epilogue for the per-tile column sums of dst that the batch norm behind
@@ -362,7 +423,22 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
     ``src_rows_bf16``: the bf16 shadow of ``src`` (``shadow_of``) -- the launch then gathers those rows (u3d_spconv_gmm_bf16a)."""
     Cs, Cd = src.shape[1], (weight.shape[2] if transposed else weight.shape[0])
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
-    if n_dst:
+    ts = _ts_plan(Cs, Cd, n_dst) if (_CONV_TS and n_dst and rb.coords is not None and int(bf) == P.FMT_X3 and Cs % 32 == 0
+                                       and not (stats_out is not None and _EPILOGUE_STATS)) else None
+    if ts is not None:
+        T, H = ts
+        if _PROFILE_FLOPS:
+            account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)
+        nhalo, halo, loc, pmask = rb.halo(T, H)
+        hit = _PACKED.get((weight.data_ptr(), int(transposed), P.FMT_X3))
+        if hit is not None and hit[2] == weight._version and hit[1].device == src.device:
+            wp = hit[0]
+        else:
+            wp = torch.empty(_pack_floats(weight.numel(), P.FMT_X3), dtype=torch.float32, device=src.device)
+            L.call('u3d_weight_pack_x3', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
+        L.call('u3d_spconv_ts_x3', L.ptr(src), n_dst, L.ptr(wp), L.ptr(nhalo), L.ptr(halo), L.ptr(loc), L.ptr(pmask), T, H, int(transposed),
+               Cs, Cd, L.ptr(addend), L.ptr(dst), float(flops), L.stream())
+    elif n_dst:
         R, G = _plan(Cs, Cd, rb.K, n_dst, src_rows_bf16 is not None and int(bf) == P.FMT_BF16 and Cs % 32 == 0)
         if _PROFILE_FLOPS:      # BASELINE.md section 3: N(Cs+Cd)s + 2P*idx + K*Cs*Cd*s  (s = 4 B, idx = 4 B)
             account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)

@@ -104,16 +104,16 @@ def _level_geometry(n_points=12_000, vs=0.05):
     return vb, oc, oshape
 
 
-@pytest.fixture(params=['bf16x3', 'bf16x3-pairs', 'bf16x3-wavetile', 'mfma'])
+@pytest.fixture(params=['bf16x3', 'bf16x3-ts', 'bf16x3-wavetile', 'mfma'])
 def math_mode(request):
     """both ways of forming fp32 products (precision.fp32_math): three exact bf16 planes per operand on the bf16 matrix pipe
-    (the default: SubM convolutions through the tile-stationary kernel where it is instantiated, the rest through the
-    workgroup-tile pair kernel; '-pairs': every convolution through the workgroup-tile pair kernel; '-wavetile': the wave-tile
+    (the default: sparse convolutions through the workgroup-tile pair kernel; '-ts': SubM convolutions through the tile-stationary
+    kernel of csrc/spconv_ts.hip where it is instantiated (32 / 64 channels), the rest as the default; '-wavetile': the wave-tile
     pair kernel) and the native fp32 MFMAs"""
     from unidet3d_amd import precision as P
     from unidet3d_amd import sparse
     with P.fp32_math(request.param.split('-')[0]), P.conv_kernel('wave' if request.param.endswith('wavetile') else 'workgroup'), \
-            sparse.conv_ts(request.param == 'bf16x3'):
+            sparse.conv_ts(request.param.endswith('-ts')):
         yield request.param
 
 
@@ -142,6 +142,63 @@ def test_subm_conv_fwd_bwd(cin, cout, math_mode):
         assert _rel(xg.grad, xo.grad) < 1e-4
     assert _rel(wg.grad, wo.grad) < 1e-4
     assert _rel(ag.grad, ao.grad) < 1e-6
+
+
+@pytest.mark.parametrize('T,H', [(128, 128), (128, 192), (256, 256), (64, 128)])
+def test_tile_stationary_tables_bit_exact_and_conv_matches_pair_kernel(T, H):
+    """csrc/spconv_ts.hip: (i) u3d_subm_halo's per-tile tables (sorted unique source rows, local positions, per-pass offset masks)
+    against numpy on the rulebook's own pair lists -- integers, bit-exact; (ii) forward (+ residual addend) and input gradient of
+    the tile-stationary kernel against the fp64 oracle and within fp32 rounding of the pair-list kernel, 32 / 64 channels."""
+    import os
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    vb, oc, oshape = _level_geometry(n_points=20_000, vs=0.04)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    n = rb.n_out
+    nbr = np.full((27, n), -1, np.int64)
+    for k, (i, o) in enumerate(rb.lists()):
+        nbr[k, o] = i
+    nhalo, halo, loc, pmask = [t.cpu().numpy() for t in rb.halo(T, H)]
+    loc, pmask = loc.view(np.uint16), pmask.view(np.uint32)
+    for t in range((n + T - 1) // T):
+        blk = nbr[:, t * T:(t + 1) * T]
+        u = np.unique(blk[blk >= 0])
+        assert nhalo[t] == len(u) and np.array_equal(halo[t, :len(u)], u), f'tile {t}: halo rows'
+        ref = np.full((27, T), 0xFFFF, np.int64)
+        pos = np.searchsorted(u, blk)
+        ref[:, :blk.shape[1]] = np.where(blk >= 0, pos, 0xFFFF)
+        assert np.array_equal(loc[t].astype(np.int64), ref), f'tile {t}: loc'
+        pm = np.zeros(pmask.shape[1], np.uint32)
+        kk, rr = np.nonzero(blk >= 0)
+        np.bitwise_or.at(pm, pos[kk, rr] // H, np.uint32(1) << kk.astype(np.uint32))
+        assert np.array_equal(pmask[t], pm), f'tile {t}: pmask'
+    if T == 64:
+        return                       # (tables only: the kernel is instantiated for 128- and 256-row tiles)
+    pairs = so.build_subm_rulebook(oc, oshape)
+    prev = os.environ.get('U3D_TS_T'), os.environ.get('U3D_TS_H')
+    os.environ['U3D_TS_T'], os.environ['U3D_TS_H'] = str(T), str(H)
+    try:
+        for cin, cout in ((32, 32), (64, 32), (32, 64), (64, 64)):
+            if sparse._ts_plan(cin, cout, n) is None or (T == 256 and (cin, cout) != (32, 32)) or (H == 256 and (cin, cout) != (32, 32)):
+                continue
+            g = torch.Generator().manual_seed(cin * 13 + cout)
+            x, w = torch.randn(n, cin, generator=g), torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1
+            add, go = torch.randn(n, cout, generator=g), torch.randn(n, cout, generator=g)
+            xo = x.double().requires_grad_()
+            yo = so.sparse_conv(xo, w.double(), pairs, n) + add.double()
+            yo.backward(go.double())
+            res = {}
+            for ts in (True, False):
+                with P.fp32_math('bf16x3'), sparse.conv_ts(ts):
+                    xg = x.to(_dev()).requires_grad_()
+                    y = sparse.sparse_conv(xg, w.to(_dev()), rb, 'fwd', add.to(_dev()))
+                    y.backward(go.to(_dev()))
+                    res[ts] = (y.detach(), xg.grad)
+            assert _rel(res[True][0], yo) < 2e-6 and _rel(res[True][1], xo.grad) < 2e-6, (cin, cout)
+            assert _rel(res[True][0], res[False][0]) < 2e-6 and _rel(res[True][1], res[False][1]) < 2e-6, (cin, cout)
+    finally:
+        for k, v in zip(('U3D_TS_T', 'U3D_TS_H'), prev):
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
 
 @pytest.mark.parametrize('operands', ['bf16x3', 'bf16'])

@@ -170,15 +170,19 @@ struct TsParams {
     int64_t n;
     int Cs, Cd;
     int n_tiles, pmax, flip;
+    unsigned long long* trace;   // -DU3D_TS_TRACE builds: [n_tiles][32] cycle stamps of wave 0 (tools/ts_trace.py), else unused
 };
 
 constexpr int ts_halo_bytes(int cs32, int h) { return cs32 * 3 * (h + 1) * 64; }
-constexpr int ts_wslot_bytes(int cs32, int cd16) { return (cd16 / 2) * cs32 * 6144; }
-constexpr int ts_lds_bytes(int cs32, int cd16, int h, int nslot) { return ts_halo_bytes(cs32, h) + nslot * ts_wslot_bytes(cs32, cd16); }
+constexpr int ts_wslot_bytes(int cs32, int cd16, int kg) { return kg * (cd16 / 2) * cs32 * 6144; }
+constexpr int ts_loc_bytes(int rt) { return 27 * 64 * rt * 2; }      // the tile's loc table (uint16 [27][T])
+constexpr int ts_lds_bytes(int cs32, int cd16, int rt, int h, int kg, int nslot) {
+    return ts_halo_bytes(cs32, h) + ts_loc_bytes(rt) + nslot * ts_wslot_bytes(cs32, cd16, kg);
+}
 constexpr int ts_per_cu(int bytes) { return 160 * 1024 / bytes > 4 ? 4 : 160 * 1024 / bytes; }      // (registers allow four workgroups per CU at most)
-// two weight slots (one barrier per offset) unless the second slot costs a workgroup per CU (then one slot, two barriers)
-constexpr int ts_nslot(int cs32, int cd16, int h) {
-    return ts_per_cu(ts_lds_bytes(cs32, cd16, h, 2)) >= ts_per_cu(ts_lds_bytes(cs32, cd16, h, 1)) ? 2 : 1;
+// two weight slots (one barrier per step) unless the second slot costs a workgroup per CU (then one slot, two barriers)
+constexpr int ts_nslot(int cs32, int cd16, int rt, int h, int kg) {
+    return ts_per_cu(ts_lds_bytes(cs32, cd16, rt, h, kg, 2)) >= ts_per_cu(ts_lds_bytes(cs32, cd16, rt, h, kg, 1)) ? 2 : 1;
 }
 
 // byte offset of 16-byte chunk q of slot s inside a (unit, plane) image: 64-byte rows, chunk stored at q ^ ((-(s >> 2)) & 3) -- with
@@ -186,17 +190,21 @@ constexpr int ts_nslot(int cs32, int cd16, int h) {
 __device__ __forceinline__ int ts_slot_off(int s, int q) { return (s << 6) | ((q ^ ((0 - (s >> 2)) & 3)) << 4); }
 
 // CS32: 32-channel units of the source rows; CD16: 16-column blocks of the output; RT: 16-row sub-tiles per wave (T = 64 RT rows per
-// workgroup); H: halo rows per pass; NSLOT: LDS copies of an offset's weights (2: one barrier per offset, 1: two)
-template <int CS32, int CD16, int RT, int H, int NSLOT>
+// workgroup); H: halo rows per pass; KG: consecutive offsets per step (1, or 3 = the dz triple of one (dx, dy): a third of the
+// barriers and weight hand-overs); NSLOT: LDS copies of a step's weights (2: one barrier per step, 1: two)
+template <int CS32, int CD16, int RT, int H, int KG, int NSLOT>
 __global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
     extern __shared__ __attribute__((aligned(16))) char ts_smem[];
-    constexpr int T = 64 * RT, NC = 27 * T, NSL = CD16 / 2;
-    constexpr int PLANE = (H + 1) * 64, HALO = ts_halo_bytes(CS32, H), WSLOT = ts_wslot_bytes(CS32, CD16);
+    constexpr int T = 64 * RT, NC = 27 * T, NSL = CD16 / 2, NG = 27 / KG;
+    constexpr int PLANE = (H + 1) * 64, HALO = ts_halo_bytes(CS32, H), WSLOT = ts_wslot_bytes(CS32, CD16, KG);
+    constexpr int SLICE_P = KG * CS32 * 384;                       // 16-byte pieces of one slice's share of a step (contiguous in the pack)
     constexpr int NPIECE = WSLOT / 16, NP = (NPIECE + 255) / 256;
     constexpr int ROUNDS = H / 32;
-    static_assert(H % 32 == 0 && NPIECE % 64 == 0, "tile shapes");
+    static_assert(H % 32 == 0 && NPIECE % 64 == 0 && 27 % KG == 0, "tile shapes");
+    constexpr int LOCB = ts_loc_bytes(RT);
     char* const hl = ts_smem;
-    char* const wl = ts_smem + HALO;
+    char* const ll = ts_smem + HALO;              // loc table of the tile: global latency must not sit between two offsets
+    char* const wl = ts_smem + HALO + LOCB;
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = (int)xcd_swizzle(blockIdx.x, gridDim.x);      // neighbouring tiles (shared halo rows) on one XCD / L2
@@ -211,6 +219,13 @@ __global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
     const int npass = (nh + H - 1) / H;
     const uint32_t* pmk = p.pmask + (int64_t)tile * p.pmax;
 
+#ifdef U3D_TS_TRACE
+    unsigned long long* const tr = p.trace ? p.trace + (int64_t)blockIdx.x * 32 : nullptr;
+#define TS_STAMP(i) do { if (tr && tid == 0 && (i) < 32) tr[(i)] = clock64(); } while (0)
+#else
+#define TS_STAMP(i) do {} while (0)
+#endif
+    TS_STAMP(0);
     f32x4 hi[RT][CD16], lo[RT][CD16];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -218,21 +233,30 @@ __global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
         for (int nb = 0; nb < CD16; ++nb) { hi[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (tid < CS32 * 3 * 4) *reinterpret_cast<f32x4*>(hl + (tid >> 2) * PLANE + H * 64 + (tid & 3) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};      // the zero row
 
-    const int loc_lane = (wave * 16 * RT + i16) * 2;              // byte offset of this lane's entry for (table offset 0, sub-tile 0)
+    // sub-tile rt of wave w = rows 64 rt + 16 w ..: neighbouring sub-tiles (similar neighbour patterns) go to DIFFERENT waves, so the
+    // waves of a workgroup have about the same work between two barriers
+    const int loc_lane = (wave * 16 + i16) * 2;                   // byte offset of this lane's entry for (table offset 0, sub-tile 0)
+    {
+        constexpr int LP = LOCB / 16;                             // 16-byte pieces of the table
+#pragma unroll
+        for (int i = 0; i < (LP + 255) / 256; ++i)
+            if ((i + 1) * 256 <= LP || tid + i * 256 < LP) *reinterpret_cast<f32x4*>(ll + (tid + i * 256) * 16) = bload128(rs_l, (tid + i * 256) * 16, 0);
+    }
     const int pc = tid & 7, prow = tid >> 3;                      // load phase: 16-byte piece of the row, row within a round of 32
     const int w_wr = tid * 16, w_rd = lane * 16;
 
+    // weights travel global -> registers (one step ahead) -> LDS slot.  Two register sets filled two steps ahead measured SLOWER
+    // (level 1, 32 -> 32: 161 -> 226 us): the steps are not waiting for the weights' latency
     f32x4 wreg[NP];
-    auto wk_of = [&](int kk) { return p.flip ? 26 - kk : kk; };
-    auto load_w = [&](int kk) {        // weights of table offset kk -> registers (NSL slices x CS32 units x 6 KB, contiguous per slice)
-        const int k = wk_of(kk);
+    auto load_w = [&](int g) {         // weights of step g (table offsets KG g .. KG g + KG - 1) -> registers; contiguous per slice in the pack
         if (U3D_TS_ABL & 4) return;
+        const int kbase = p.flip ? 27 - KG * (g + 1) : KG * g;    // mirrored offsets: the same block, walked backwards
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int piece = tid + i * 256;                      // 16-byte piece of the slot
             if ((i + 1) * 256 <= NPIECE || piece < NPIECE) {
-                const int sl = piece / (CS32 * 384), rem = piece - sl * (CS32 * 384);
-                wreg[i] = bload128(rs_w, rem * 16 + ((sl * 27 + k) * CS32) * 6144, 0);
+                const int sl = piece / SLICE_P, rem = piece - sl * SLICE_P;
+                wreg[i] = bload128(rs_w, rem * 16 + ((sl * 27 + kbase) * CS32) * 6144, 0);
             }
         }
     };
@@ -242,22 +266,34 @@ __global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
         for (int i = 0; i < NP; ++i)
             if ((i + 1) * 256 <= NPIECE || tid + i * 256 < NPIECE) *reinterpret_cast<f32x4*>(wl + slot * WSLOT + w_wr + i * 4096) = wreg[i];
     };
-    auto next_k = [](unsigned mask, int after) -> int {           // lowest set bit above `after` (32: none)
+    auto group_mask = [](unsigned km) -> unsigned {               // bit g: some offset of step g has work in this pass
+        if constexpr (KG == 1) return km;
+        unsigned gm = 0u;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gm |= ((km >> (KG * g)) & ((1u << KG) - 1u)) ? 1u << g : 0u;
+        return gm;
+    };
+    auto next_bit = [](unsigned mask, int after) -> int {         // lowest set bit above `after` (32: none)
         const unsigned rest = after >= 31 ? 0u : mask & (~1u << after);
         return rest ? __builtin_ctz(rest) : 32;
     };
 
-    for (int ps = 0; ps < npass; ++ps) {
-        const unsigned km = __builtin_amdgcn_readfirstlane(pmk[ps]);
-        const int cnt = min(H, nh - ps * H);
-        if (ps) ts_barrier();                                     // every wave is done with the previous pass's rows and weight slots
-        int kk = km ? __builtin_ctz(km) : 32;
-        if (kk < 32) load_w(kk);
-        // ---- halo rows of this pass: global -> three bf16 planes in LDS (fragment order) ----
-        int hrow[ROUNDS];
-#if !(U3D_TS_ABL & 2)
+    int hrow[ROUNDS];                                             // source rows of the NEXT pass's halo slots (one pass ahead)
 #pragma unroll
-        for (int j = 0; j < ROUNDS; ++j) hrow[j] = bload32(rs_h, (ps * H + j * 32 + prow) * 4, 0);
+    for (int j = 0; j < ROUNDS; ++j) hrow[j] = bload32(rs_h, (j * 32 + prow) * 4, 0);
+    unsigned km_next = npass ? pmk[0] : 0u;
+    for (int ps = 0; ps < npass; ++ps) {
+        const unsigned km = __builtin_amdgcn_readfirstlane(km_next);
+        const unsigned gm = group_mask(km);
+        if (ps + 1 < npass) km_next = pmk[ps + 1];
+        const int cnt = min(H, nh - ps * H);
+        TS_STAMP(1 + ps * 5);
+        if (ps) ts_barrier();                                     // every wave is done with the previous pass's rows and weight slots
+        TS_STAMP(2 + ps * 5);
+        int g = gm ? __builtin_ctz(gm) : 32;
+        if (g < 32) load_w(g);
+        // ---- halo rows of this pass: global -> three bf16 planes in LDS (fragment order) ----
+#if !(U3D_TS_ABL & 2)
 #pragma unroll
         for (int j0 = 0; j0 < ROUNDS; j0 += 4) {
             f32x4 v[4][CS32];
@@ -268,6 +304,7 @@ __global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
                     const int ro = ok ? (int)__umul24(hrow[j0 + j], cs4) + pc * 16 : 0x7ffffff0;      // past the end: the load returns zeros
 #pragma unroll
                     for (int u = 0; u < CS32; ++u) v[j][u] = bload128(rs_src, ro, u * 128);
+                    if (ps + 1 < npass) hrow[j0 + j] = bload32(rs_h, ((ps + 1) * H + (j0 + j) * 32 + prow) * 4, 0);
                 }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -292,103 +329,138 @@ __global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
                 }
         }
 #endif
-        int lcur[RT], lnxt[RT];
-        if (kk < 32) {
+        if (g < 32) {
             write_w(0);
-            const int kn = next_k(km, kk);
-            if (kn < 32) load_w(kn);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) lcur[rt] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_l, loc_lane + rt * 32, kk * (T * 2), 0);
+            const int gn = next_bit(gm, g);
+            if (gn < 32) load_w(gn);
         }
+        TS_STAMP(3 + ps * 5);
         ts_barrier();
+        TS_STAMP(4 + ps * 5);
+        // ---- offsets of this pass, software-pipelined: while offset kk is multiplied, the fragments of the next offset with work
+        // in the pass (its loc entries were read one offset earlier) are already on their way from the halo image ----
         int step = 0;
-        while (kk < 32) {
-            const int kn = next_k(km, kk);
-            if (kn < 32) {
+        struct Ops { ts_bf16x8 x[RT][CS32][3]; bool any[RT]; };
+        auto read_lc = [&](int kk, int (&lcv)[RT]) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) lnxt[rt] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_l, loc_lane + rt * 32, kn * (T * 2), 0);
-            }
-            const char* const wsl = wl + (NSLOT == 2 ? (step & 1) * WSLOT : 0) + w_rd;
-            bool any[RT];
-            ts_bf16x8 x[RT][CS32][3];
+            for (int rt = 0; rt < RT; ++rt) lcv[rt] = *reinterpret_cast<const unsigned short*>(ll + kk * (T * 2) + loc_lane + rt * 128);
+        };
+        auto fetch = [&](Ops& o, const int (&lcv)[RT]) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int s0 = lcur[rt] - ps * H;
+                const int s0 = lcv[rt] - ps * H;
                 const bool ok = (unsigned)s0 < (unsigned)cnt;
-                any[rt] = __ballot(ok) != 0ull;
-                if (any[rt]) {
+                o.any[rt] = __ballot(ok) != 0ull;
+                if (o.any[rt]) {
                     const int a0 = ts_slot_off(ok ? s0 : H, q);
 #pragma unroll
                     for (int u = 0; u < CS32; ++u)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) {
-                            if (U3D_TS_ABL & 32) x[rt][u][pl] = __builtin_bit_cast(ts_bf16x8, f32x4{(float)a0, 1.f, 2.f, (float)pl});
-                            else x[rt][u][pl] = *reinterpret_cast<const ts_bf16x8*>(hl + (u * 3 + pl) * PLANE + a0);
+                            if (U3D_TS_ABL & 32) o.x[rt][u][pl] = __builtin_bit_cast(ts_bf16x8, f32x4{(float)a0, 1.f, 2.f, (float)pl});
+                            else o.x[rt][u][pl] = *reinterpret_cast<const ts_bf16x8*>(hl + (u * 3 + pl) * PLANE + a0);
                         }
                 }
+            }
+        };
+        // one offset: kk multiplied from `cur`; kn (32: none) fetched into `nxt` from its loc entries `lc_kn`; loc entries of kn2 -> lc_dst
+        auto body = [&](int kk, Ops& cur, int kn, Ops& nxt, const int (&lc_kn)[RT], int kn2, int (&lc_dst)[RT]) {
+            const int gk = kk / KG;
+            const int jj = p.flip ? KG - 1 - (kk - gk * KG) : kk - gk * KG;      // the offset's weights inside the step's block
+            const char* const wsl = wl + (NSLOT == 2 ? (step & 1) * WSLOT : 0) + w_rd;
+            auto wfrag = [&](int u, int nb, f32x4 (&wf)[3]) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (U3D_TS_ABL & 32) wf[pl] = f32x4{(float)lane, 1.f, (float)nb, (float)pl};
+                    else wf[pl] = *reinterpret_cast<const f32x4*>(wsl + ((((((nb >> 1) * KG + jj) * CS32 + u) * 2 + (nb & 1)) * 3 + pl) * 1024));
+                }
+            };
+            f32x4 wf0[3];
+            wfrag(0, 0, wf0);                                      // the first weight fragments are asked for before the next offset's rows
+            if (kn < 32) {
+                fetch(nxt, lc_kn);
+                if (kn2 < 32) read_lc(kn2, lc_dst);
             }
 #pragma unroll
             for (int u = 0; u < CS32; ++u)
 #pragma unroll
                 for (int nb = 0; nb < CD16; ++nb) {
                     f32x4 wf[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        if (U3D_TS_ABL & 32) wf[pl] = f32x4{(float)lane, 1.f, (float)nb, (float)pl};
-                        else wf[pl] = *reinterpret_cast<const f32x4*>(wsl + ((((nb >> 1) * CS32 + u) * 2 + (nb & 1)) * 3 + pl) * 1024);
-                    }
+                    if (u == 0 && nb == 0) { wf[0] = wf0[0]; wf[1] = wf0[1]; wf[2] = wf0[2]; }
+                    else wfrag(u, nb, wf);
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
-                        if (any[rt]) {
+                        if (cur.any[rt]) {
                             f32x4 c = lo[rt][nb];
-                            c = ts_mfma(wf[0], x[rt][u][2], c);
-                            c = ts_mfma(wf[1], x[rt][u][1], c);
-                            c = ts_mfma(wf[2], x[rt][u][0], c);
-                            c = ts_mfma(wf[0], x[rt][u][1], c);
-                            c = ts_mfma(wf[1], x[rt][u][0], c);
+                            c = ts_mfma(wf[0], cur.x[rt][u][2], c);
+                            c = ts_mfma(wf[1], cur.x[rt][u][1], c);
+                            c = ts_mfma(wf[2], cur.x[rt][u][0], c);
+                            c = ts_mfma(wf[0], cur.x[rt][u][1], c);
+                            c = ts_mfma(wf[1], cur.x[rt][u][0], c);
                             lo[rt][nb] = c;
-                            hi[rt][nb] = ts_mfma(wf[0], x[rt][u][0], hi[rt][nb]);
+                            hi[rt][nb] = ts_mfma(wf[0], cur.x[rt][u][0], hi[rt][nb]);
                         }
                 }
-            // ---- hand over to the next offset of this pass ----
-            if (kn < 32) {
+            if (kn < 32 && kn / KG != gk) {                        // hand over to the next step of this pass
+                const int gn = kn / KG;
                 if constexpr (NSLOT == 1 && !(U3D_TS_ABL & 8)) ts_barrier();           // every wave has read the slot for the last time
                 write_w(NSLOT == 2 ? ((step + 1) & 1) : 0);
-                const int kn2 = next_k(km, kn);
-                if (kn2 < 32) load_w(kn2);
+                const int gn2 = next_bit(gm, gn);
+                if (gn2 < 32) load_w(gn2);
                 if (!(U3D_TS_ABL & 8)) ts_barrier();
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) lcur[rt] = lnxt[rt];
+                ++step;
             }
-            kk = kn;
-            ++step;
+        };
+        if (g < 32 && !(U3D_TS_ABL & 128)) {
+            int kk = __builtin_ctz(km), kn = next_bit(km, kk);
+            int lcA[RT], lcB[RT];
+            Ops A, B;
+            read_lc(kk, lcA);
+            if (kn < 32) read_lc(kn, lcB);
+            fetch(A, lcA);
+            while (true) {
+                int kn2 = kn < 32 ? next_bit(km, kn) : 32;
+                body(kk, A, kn, B, lcB, kn2, lcA);
+                if (kn >= 32) break;
+                kk = kn; kn = kn2;
+                kn2 = kn < 32 ? next_bit(km, kn) : 32;
+                body(kk, B, kn, A, lcA, kn2, lcB);
+                if (kn >= 32) break;
+                kk = kn; kn = kn2;
+            }
         }
+        TS_STAMP(5 + ps * 5);
+#ifdef U3D_TS_TRACE
+        if (tr && tid == 0 && ps < 5) tr[26 + ps] = (unsigned long long)__builtin_popcount(km);
+#endif
     }
+    TS_STAMP(31);
 
     // ---- write-out: lane (i16, q) holds columns 16 nb + 4 q .. + 3 of row i16 of each sub-tile ----
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const int64_t row = r0 + wave * (16 * RT) + rt * 16 + i16;
+        const int64_t row = r0 + rt * 64 + wave * 16 + i16;
         if (row < p.n) {
 #pragma unroll
             for (int nb = 0; nb < CD16; ++nb) {
                 f32x4 v = hi[rt][nb] + lo[rt][nb];
                 const int64_t o = row * p.Cd + nb * 16 + q * 4;
                 if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + o);
+                if ((U3D_TS_ABL & 64) && v[0] != 12345.f) continue;      // ablation: (almost) no write-out
                 *reinterpret_cast<f32x4*>(p.out + o) = v;
             }
         }
     }
 }
 
-template <int CS32, int CD16, int RT, int H>
+template <int CS32, int CD16, int RT, int H, int KG>
 static int launch_ts(const TsParams& p, hipStream_t s) {
-    constexpr int NSLOT = ts_nslot(CS32, CD16, H);
-    constexpr int lds = ts_lds_bytes(CS32, CD16, H, NSLOT);
+    constexpr int NSLOT = ts_nslot(CS32, CD16, RT, H, KG);
+    constexpr int lds = ts_lds_bytes(CS32, CD16, RT, H, KG, NSLOT);
     static_assert(lds <= 160 * 1024, "tile exceeds the LDS");
     // the attribute is per device and cheap to set: no cache keyed by ordinal (a 64-entry table aliased devices >= 64)
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_ts_k<CS32, CD16, RT, H, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((spconv_ts_k<CS32, CD16, RT, H, NSLOT>), dim3((unsigned)p.n_tiles), dim3(256), lds, s, p);
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_ts_k<CS32, CD16, RT, H, KG, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((spconv_ts_k<CS32, CD16, RT, H, KG, NSLOT>), dim3((unsigned)p.n_tiles), dim3(256), lds, s, p);
     return check_launch("spconv_ts");
 }
 
@@ -457,9 +529,15 @@ int u3d_spconv_ts_x3(const float* src, int64_t n, const void* w_rows_x3, const i
     ProfScope prof(U3D_K_CONV_FWD, s, flops_hint);
     TsParams p;
     p.src = src; p.w = w_rows_x3; p.nhalo = nhalo; p.halo = halo; p.loc = loc; p.pmask = pmask; p.addend = addend; p.out = dst;
+    p.trace = nullptr;
+#ifdef U3D_TS_TRACE
+    { const char* e = getenv("U3D_TS_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
+#endif
     p.n = n; p.Cs = Cs; p.Cd = Cd; p.n_tiles = (int)ceil_div(n, tile_rows); p.pmax = u3d_subm_halo_pmax(tile_rows, halo_rows); p.flip = flip ? 1 : 0;
     const int cs32 = Cs / 32, cd16 = Cd / 16;
-#define U3D_TS_CASE(cs, cd, rt, h) if (cs32 == cs && cd16 == cd && tile_rows == 64 * rt && halo_rows == h) return launch_ts<cs, cd, rt, h>(p, s);
+    const char* ekg = getenv("U3D_TS_KG");
+    const int kg = ekg && atoi(ekg) == 1 ? 1 : 3;
+#define U3D_TS_CASE(cs, cd, rt, h) if (cs32 == cs && cd16 == cd && tile_rows == 64 * rt && halo_rows == h) return kg == 3 ? launch_ts<cs, cd, rt, h, 3>(p, s) : launch_ts<cs, cd, rt, h, 1>(p, s);
     U3D_TS_CASE(1, 2, 2, 128) U3D_TS_CASE(1, 2, 2, 192) U3D_TS_CASE(1, 2, 2, 256)
     U3D_TS_CASE(1, 2, 4, 128) U3D_TS_CASE(1, 2, 4, 192) U3D_TS_CASE(1, 2, 4, 256)
     U3D_TS_CASE(1, 2, 1, 128)

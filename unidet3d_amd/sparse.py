@@ -385,9 +385,11 @@ def _pack_floats(numel: int, fmt: int) -> int:
     return {0: numel, 1: numel // 2, 2: numel * 3 // 2}[fmt]
 
 
-# Tile-stationary SubM kernel (csrc/spconv_ts.hip) for the three-plane fp32 path wherever u3d_spconv_ts_plan has a shape for it;
-# U3D_CONV_TS=0 / set_conv_ts(False) keeps every convolution on the pair-list kernels (A/B runs, tests).
-_CONV_TS = os.environ.get('U3D_CONV_TS', '1') != '0'
+# Tile-stationary SubM kernel (csrc/spconv_ts.hip; round 6) for the three-plane fp32 path wherever
+# u3d_spconv_ts_plan has a shape for it.  OFF by default: correct (tables bit-exact, fp32-level errors, tests/test_gpu_kernels.py) but
+# measured BEHIND the pair-list kernels at every real layer shape of cfg2 (level 1, 32 -> 32: 148 us against 128; level 2, 64 -> 64:
+# 165 against 112; DESIGN.md 4.15 has the ablations and the cycle trace that say why).  U3D_CONV_TS=1 / set_conv_ts(True) turns it on.
+_CONV_TS = os.environ.get('U3D_CONV_TS', '0') == '1'
 
 
 def set_conv_ts(on: bool) -> bool:

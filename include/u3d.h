@@ -414,12 +414,13 @@ int u3d_transpose_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_
 /* Pre-split W operands for the three-plane ("bf16x3") NT products.  u3d_weight_planes_batch: desc int64 [n_desc][4] = {src ptr (fp32,
  * n8 * 8 values), dst ptr (bf16 [3][n8 * 8]: the three exact planes of every value, 8-element groups split exactly as the GEMM
  * kernels split them in flight), n8, first block}; a matrix takes ceil(n8 / 256) blocks; one launch for every weight (and transposed
- * copy) of a training step.  u3d_gemm_w_planes(p, p2): the NEXT NT entry point called on this host thread (u3d_gemm_nt,
+ * copy) of a training step.  u3d_gemm_w_planes(w, p, w2, p2): the NEXT NT entry point called on this host thread (u3d_gemm_nt,
  * u3d_linear_act, u3d_linear_dact, u3d_gemm_nt_add, u3d_ln_linear; u3d_ffn_fwd takes p for W1 and p2 for W2) reads its W operand from
- * these planes ([3][N][K] bf16, same N, K as its fp32 W, which must still be passed) when it runs the three-plane kernel; consumed by
+ * these planes ([3][N][K] bf16, same N, K as its fp32 W, which must still be passed) when it runs the three-plane kernel AND its W
+ * argument is the pointer w (w2) the planes were registered for -- planes of another matrix are ignored; consumed (cleared) by
  * that call whatever kernel it picks; NULL = none.  Results are bit-identical with and without. */
 int u3d_weight_planes_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream);
-int u3d_gemm_w_planes(const void* planes, const void* planes2);
+int u3d_gemm_w_planes(const void* w, const void* planes, const void* w2, const void* planes2);
 
 /* =====================================================================================
  * K15 LayerNorm of the decoder (unidet3d/encoder.py:21,38-40,61,78-79,140,167) with the preceding residual add fused in.

@@ -260,6 +260,47 @@ def test_weight_gradients_on_the_side_stream_give_the_same_bits(operands):
     assert not bad, ('bucket', len(bad), bad[:5])
 
 
+def test_side_stream_weight_gradients_with_shared_weights_and_hooks():
+    """in mode 2 a weight gradient may stay on the side stream only when autograd's AccumulateGrad is its sole consumer.
+    (i) A Linear weight AND a sparse-convolution weight used by two layers of one graph (autograd sums the two dWs on the main stream),
+    (ii) a parameter with a tensor hook that reads the gradient at once: gradients must equal the single-stream ones bit for bit."""
+    from unidet3d_amd import dense, ops, sparse
+    from unidet3d_amd.synthetic import make_scene
+    torch.manual_seed(0)
+    vb = ops.voxelize([torch.from_numpy(make_scene(60, n_points=30000).points).to(DEV)], 0.02, 128)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    n = vb.coords.shape[0]
+    x0 = torch.randn(n, 32, device=DEV)
+    wc0 = torch.randn(32, 3, 3, 3, 32, device=DEV) * 0.05
+    wl0 = torch.randn(32, 32, device=DEV) * 0.1
+    seen = []
+
+    def run(mode, hook):
+        prev = sparse.set_wgrad_overlap(mode)
+        try:
+            wc, wl = wc0.clone().requires_grad_(), wl0.clone().requires_grad_()
+            if hook:
+                wl.register_hook(lambda g: seen.append(float(g.abs().sum())) or g * 2.0)
+            x = x0.clone().requires_grad_()
+            h = sparse.sparse_conv(x, wc, rb)
+            h = dense.linear(h, wl)
+            h = sparse.sparse_conv(h, wc, rb)           # the same convolution weight a second time
+            h = dense.linear(h, wl)                     # and the same Linear weight
+            (h * h).sum().backward()
+            torch.cuda.synchronize()
+            return wc.grad.clone(), wl.grad.clone(), x.grad.clone()
+        finally:
+            sparse.set_wgrad_overlap(prev)
+
+    for hook in (False, True):
+        ref = run(0, hook)
+        for _ in range(3):
+            got = run(2, hook)
+            for name, a, b in zip(('conv weight', 'linear weight', 'input'), ref, got):
+                assert torch.equal(a, b), (name, hook, float((a - b).abs().max()))
+    assert len(seen) >= 8 and len(set(seen[:2])) <= 2
+
+
 def test_presplit_weight_planes_and_batched_transposes_change_no_bit():
     """dense.transposed_weights(): every Linear weight's [K, N] copy (one u3d_transpose_batch launch) and, for the three-plane fp32
     products, the three bf16 planes of every weight and transposed copy (one u3d_weight_planes_batch launch; the NT kernels then load

@@ -25,6 +25,42 @@ def test_cat_views_returns_the_base_only_for_a_full_consecutive_cover():
     assert torch.equal(cat_views([torch.ones(2, 3), torch.zeros(1, 3)]), torch.tensor([[1., 1, 1], [1, 1, 1], [0, 0, 0]]))   # plain tensors: cat
 
 
+def test_cat_views_keeps_the_autograd_state_of_the_slices():
+    """slices taken under no_grad of a differentiable base are detached -- torch.cat of them is too, so the (differentiable)
+    base must not be returned in their place."""
+    from unidet3d_amd.ops import cat_views
+    y = torch.arange(24.).reshape(6, 4).requires_grad_() * 2
+    with torch.no_grad():
+        parts = [y[0:2], y[2:6]]
+    out = cat_views(parts)
+    ref = torch.cat(parts)
+    assert out.requires_grad == ref.requires_grad and out.dtype == ref.dtype and torch.equal(out.detach(), ref.detach())
+
+
+def test_async_weight_gradient_guard():
+    """sparse.async_dw_ok: a weight gradient may stay on the side stream only for a leaf without .grad / hooks, outside
+    create_graph, used for the first time in the running backward pass."""
+    from unidet3d_amd import sparse
+    w, b = torch.zeros(3, requires_grad=True), torch.zeros(3, requires_grad=True)
+    sparse._ASYNC_DW_SEEN.clear()
+    with torch.no_grad():                      # what a backward pass without create_graph looks like
+        assert sparse.async_dw_ok(w, b)
+        assert not sparse.async_dw_ok(w)       # second use in the same pass: autograd will sum the two gradients
+        assert not sparse.async_dw_ok(b, None)
+        sparse.join_wgrad_stream()             # end of the pass: forgotten
+        assert sparse.async_dw_ok(w, None)
+        sparse.join_wgrad_stream()
+        w.grad = torch.zeros(3)
+        assert not sparse.async_dw_ok(w)       # accumulation into an existing .grad
+        w.grad = None
+        h = w.register_hook(lambda g: g)
+        assert not sparse.async_dw_ok(w)       # a hook reads the gradient at once
+        h.remove()
+        assert not sparse.async_dw_ok((w * 1.0))      # not a leaf
+    assert not sparse.async_dw_ok(b)           # grad mode on inside backward = create_graph
+    sparse._ASYNC_DW_SEEN.clear()
+
+
 def test_offset_ids_matches_the_per_scene_loop():
     from unidet3d_amd.ops import offset_ids
     g = torch.Generator().manual_seed(3)

@@ -108,7 +108,7 @@ PROTOTYPES = {
     'u3d_transpose': (_i32, [_vp, _vp, _i32, _i32, _vp]),
     'u3d_transpose_batch': (_i32, [_vp, _i32, _i64, _vp]),
     'u3d_weight_planes_batch': (_i32, [_vp, _i32, _i64, _vp]),
-    'u3d_gemm_w_planes': (_i32, [_vp, _vp]),
+    'u3d_gemm_w_planes': (_i32, [_vp, _vp, _vp, _vp]),
     'u3d_attn_varlen_fwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_fwd_bf16': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),

@@ -965,10 +965,14 @@ static void launch_nt(const float* A, const float* W, const float* bias, float* 
 // epi: 0..4 (see nt_epilogue); + 8: bf16 MFMA operands (fp32 data in HBM, fp32 accumulation)
 // The pre-split planes of the NEXT launch's W operand (u3d_gemm_w_planes): per host thread, consumed (and cleared) by the next NT
 // entry point called on that thread -- the caller sets them immediately before the call they belong to.
+// Each slot remembers the fp32 matrix the planes were made from: an entry point only uses planes whose owner is the W it was handed
+// (an exception between the hand-over and the launch must not leave planes behind for an unrelated product).
 static thread_local const void* g_wplanes[2] = {nullptr, nullptr};
-static const void* take_wplanes(int i) {
-    const void* p = g_wplanes[i];
+static thread_local const void* g_wowner[2] = {nullptr, nullptr};
+static const void* take_wplanes(int i, const void* W) {
+    const void* p = g_wowner[i] == W ? g_wplanes[i] : nullptr;
     g_wplanes[i] = nullptr;
+    g_wowner[i] = nullptr;
     return p;
 }
 
@@ -1001,8 +1005,8 @@ extern "C" {
 
 int u3d_gemm_nt(const float* A, const float* W, const float* bias, float* C, int64_t M, int N, int K, double flops_hint,
                 u3d_stream_t stream) {
-    const void* wp = take_wplanes(0);
-    take_wplanes(1);
+    const void* wp = take_wplanes(0, W);
+    take_wplanes(1, nullptr);
     return gemm_nt_epi(A, W, bias, C, M, N, K, 0, nullptr, nullptr, flops_hint, (hipStream_t)stream, wp);
 }
 
@@ -1011,8 +1015,8 @@ int u3d_linear_act(const float* X, const float* W, const float* bias, int act, f
                    double flops_hint, u3d_stream_t stream) {
     const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
     act &= ~U3D_BF16_OPERANDS;
-    const void* wp = take_wplanes(0);
-    take_wplanes(1);
+    const void* wp = take_wplanes(0, W);
+    take_wplanes(1, nullptr);
     if (act < 0 || act > 2) return U3D_EINVAL;
     return gemm_nt_epi(X, W, bias, Y, M, N, K, act | bf, nullptr, pre, flops_hint, (hipStream_t)stream, wp);
 }
@@ -1021,35 +1025,36 @@ int u3d_linear_dact(const float* dY, const float* Wt, const float* aux, int act,
                     u3d_stream_t stream) {
     const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
     act &= ~U3D_BF16_OPERANDS;
-    const void* wp = take_wplanes(0);
-    take_wplanes(1);
+    const void* wp = take_wplanes(0, Wt);
+    take_wplanes(1, nullptr);
     if (act < 0 || act > 2) return U3D_EINVAL;
     return gemm_nt_epi(dY, Wt, nullptr, dX, M, N, K, (act == 0 ? 0 : act + 2) | bf, aux, nullptr, flops_hint, (hipStream_t)stream, wp);
 }
 
 int u3d_gemm_nt_add(const float* A, const float* W, const float* addend, int flags, float* C, int64_t M, int N, int K, double flops_hint,
                     u3d_stream_t stream) {
-    const void* wp = take_wplanes(0);
-    take_wplanes(1);
+    const void* wp = take_wplanes(0, W);
+    take_wplanes(1, nullptr);
     return gemm_nt_epi(A, W, nullptr, C, M, N, K, 5 | ((flags & U3D_BF16_OPERANDS) ? 8 : 0), addend, nullptr, flops_hint, (hipStream_t)stream, wp);
 }
 
 int u3d_ln_linear(const float* X, const float* RES, const float* gamma, const float* beta, float eps, float* SUM, float* NQ, float* STATS,
                   const float* W, const float* bias, int act, float* PRE, float* Y, int64_t M, int C, int N, double flops_hint,
                   u3d_stream_t stream) {
-    const void* wp = take_wplanes(0);
-    take_wplanes(1);
+    const void* wp = take_wplanes(0, W);
+    take_wplanes(1, nullptr);
     if (!NQ || !Y || !W) return U3D_EINVAL;
     int rc = u3d_layer_norm_fwd(X, RES, gamma, beta, M, C, eps, SUM, NQ, STATS, stream);
     if (rc || M == 0) return rc;
     g_wplanes[0] = wp;
+    g_wowner[0] = wp ? W : nullptr;
     return u3d_linear_act(NQ, W, bias, act, PRE, Y, M, N, C, flops_hint, stream);
 }
 
 int u3d_ffn_fwd(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, int act, float* H, float* A, float* Z,
                 int64_t M, int d_in, int hid, int d_out, double flops_hint, u3d_stream_t stream) {
-    const void* wp1 = take_wplanes(0);
-    const void* wp2 = take_wplanes(1);
+    const void* wp1 = take_wplanes(0, W1);
+    const void* wp2 = take_wplanes(1, W2);
     const int bf = (act & U3D_BF16_OPERANDS) ? 8 : 0;
     act &= ~U3D_BF16_OPERANDS;
     if (act != 1 && act != 2) return U3D_EINVAL;
@@ -1152,9 +1157,9 @@ int u3d_weight_planes_batch(const void* desc, int n_desc, int64_t total_blocks, 
     return check_launch("weight_planes_batch");
 }
 
-int u3d_gemm_w_planes(const void* planes, const void* planes2) {
-    g_wplanes[0] = planes;
-    g_wplanes[1] = planes2;
+int u3d_gemm_w_planes(const void* w, const void* planes, const void* w2, const void* planes2) {
+    g_wplanes[0] = planes; g_wowner[0] = planes ? w : nullptr;
+    g_wplanes[1] = planes2; g_wowner[1] = planes2 ? w2 : nullptr;
     return U3D_OK;
 }
 

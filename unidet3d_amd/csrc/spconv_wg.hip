@@ -439,12 +439,12 @@ template <int CS16, int R, int PR>
 static int launch_wg(const GmmParams& p, hipStream_t s) {
     constexpr int lds = wg_lds_bytes(CS16, R, PR);
     static_assert(lds <= 160 * 1024, "workgroup tile exceeds the LDS");
-    static bool attr_set[64] = {};          // the attribute is per DEVICE: one flag per device ordinal
+    static DeviceOnce attr_set;              // the attribute is per DEVICE
     int dev = 0;
     hipGetDevice(&dev);
-    if (!attr_set[dev & 63]) {
+    if (attr_set.needed(dev)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_gmm_wg_k<CS16, R, PR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set[dev & 63] = true;
+        attr_set.done(dev);
     }
     const int64_t wgs = ceil_div(p.n_sub, 4) * p.n_slices * p.G;
     hipLaunchKernelGGL((spconv_gmm_wg_k<CS16, R, PR>), dim3((unsigned)wgs), dim3(256), lds, s, p);

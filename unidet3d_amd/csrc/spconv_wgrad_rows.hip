@@ -341,12 +341,12 @@ static int launch_wgrad_rows(const WgRowsParams& p, float* dW, hipStream_t s) {
     constexpr int CD = NG * 16, CS = NX * 16;
     constexpr int tiles = 4 * NP * 32 * (CD + CS) * 2, red = 2 * CD * CS * 4;
     constexpr int lds = tiles > red ? tiles : red;
-    static bool attr_set[64] = {};          // the attribute is per DEVICE: one flag per device ordinal
+    static DeviceOnce attr_set;              // the attribute is per DEVICE
     int dev = 0;
     hipGetDevice(&dev);
-    if (!attr_set[dev & 63]) {
+    if (attr_set.needed(dev)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_wgrad_rows_k<NG, NX, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set[dev & 63] = true;
+        attr_set.done(dev);
     }
     const int64_t groups = ceil_div(ceil_div(p.n_tiles, 4), 8) * 8;
     hipLaunchKernelGGL((spconv_wgrad_rows_k<NG, NX, NP>), dim3((unsigned)(groups * p.K)), dim3(256), lds, s, p);
@@ -359,12 +359,12 @@ template <int NG, int NX>
 static int launch_wgrad_rows_coop(const WgRowsParams& p, float* dW, hipStream_t s) {
     constexpr int CD = NG * 16, CS = NX * 16;
     constexpr int lds = 2 * 32 * (CD + CS) * 2;
-    static bool attr_set[64] = {};          // the attribute is per DEVICE: one flag per device ordinal
+    static DeviceOnce attr_set;              // the attribute is per DEVICE
     int dev = 0;
     hipGetDevice(&dev);
-    if (!attr_set[dev & 63]) {
+    if (attr_set.needed(dev)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_wgrad_rows_coop_k<NG, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set[dev & 63] = true;
+        attr_set.done(dev);
     }
     const int64_t groups = ceil_div(ceil_div(p.n_tiles, 4), 8) * 8;
     hipLaunchKernelGGL((spconv_wgrad_rows_coop_k<NG, NX>), dim3((unsigned)(groups * p.K)), dim3(256), lds, s, p);

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "u3d.h"
 
 namespace u3d {
@@ -31,6 +33,14 @@ inline int check_launch(const char* what) {
 }
 
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// "this kernel's dynamic-LDS attribute is set on device d": one flag per device ordinal, read and written from any host thread
+// (autograd runs a worker per device); ordinals past the table always set the attribute again (`dev & 63` aliased them)
+struct DeviceOnce {
+    std::atomic<bool> flag[64];
+    bool needed(int dev) const { return (unsigned)dev >= 64u || !flag[dev].load(std::memory_order_acquire); }
+    void done(int dev) { if ((unsigned)dev < 64u) flag[dev].store(true, std::memory_order_release); }
+};
 
 // XCD-aware work-id remap (MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8, each XCD has its own
 // 4 MB L2): XCD x gets the CONTIGUOUS chunk of work ids so that neighbouring tiles, which gather the same

@@ -37,7 +37,7 @@ def _gemm_nt(a, w, bias, bf=False, planes=None):
                    _flops(M, N, a.shape[1]), L.stream())
         else:
             K = a.shape[1]
-            _use_planes(planes)
+            _use_planes(w, planes)
             L.call('u3d_gemm_nt', L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(c), M, N, K, _flops(M, N, K), L.stream())
     return c
 
@@ -76,16 +76,18 @@ class transposed_weights:
         if ws:
             dev = ws[0][0].device
             flat = torch.empty(sum(N * K for _, N, K in ws), dtype=torch.float32, device=dev)
-            rows, blocks, off, table = [], 0, 0, {}
+            rows, blocks, off, table, vers = [], 0, 0, {}, {}
             for w, N, K in ws:
                 wt = flat[off:off + N * K].view(K, N)
                 off += N * K
                 rows.append([w.data_ptr(), wt.data_ptr(), N, K, blocks])
                 blocks += ((N + 31) // 32) * ((K + 31) // 32)
                 table[w.data_ptr()] = wt
+                vers[w.data_ptr()] = w._version
             desc = L.h2d(rows, torch.int64, dev)
             L.call('u3d_transpose_batch', L.ptr(desc), len(rows), blocks, L.stream())
             table['_keep'] = (flat, desc)
+            table['_versions'] = vers
             if _W_PLANES and not P.bf16() and P.get_fp32_math() == 'bf16x3':
                 # three-plane products: the planes of every weight AND of its transposed copy, one launch (u3d_weight_planes_batch);
                 # planes[(data_ptr of the fp32 matrix)] -> bf16 [3, rows, cols]
@@ -128,10 +130,11 @@ def _planes_of(mat):
     return _WT_ACTIVE.get('_planes', {}).get(mat.data_ptr())
 
 
-def _use_planes(p1, p2=None):
-    """hand the next NT launch its pre-split W operand(s) (include/u3d.h u3d_gemm_w_planes); no call when there are none"""
+def _use_planes(w1, p1, w2=None, p2=None):
+    """hand the next NT launch its pre-split W operand(s) together with the matrices they belong to (include/u3d.h
+    u3d_gemm_w_planes: the launch ignores planes of any other matrix); no call when there are none"""
     if p1 is not None or p2 is not None:
-        L.lib().u3d_gemm_w_planes(L.ptr(p1), L.ptr(p2))
+        L.lib().u3d_gemm_w_planes(L.ptr(w1) if p1 is not None else None, L.ptr(p1), L.ptr(w2) if p2 is not None else None, L.ptr(p2))
 
 
 def _wt_of(weight):
@@ -139,7 +142,11 @@ def _wt_of(weight):
     if _WT_ACTIVE is None:
         return None
     wt = _WT_ACTIVE.get(weight.data_ptr())
-    return wt if wt is not None and wt.shape == (weight.numel() // weight.shape[0], weight.shape[0]) else None
+    if wt is None or wt.shape != (weight.numel() // weight.shape[0], weight.shape[0]):
+        return None
+    # a parameter modified in place since the context was entered (EMA update, in-forward optimizer step): its copy is
+    # stale -> None, and the op transposes for itself
+    return wt if _WT_ACTIVE.get('_versions', {}).get(weight.data_ptr()) == weight._version else None
 
 
 def _flops(M, N, K, extra_mn=0):
@@ -175,7 +182,7 @@ def _input_grad(dy, weight, act=ACT_NONE, aux=None, bf=False, wt=None, wt_planes
     dx = torch.empty(M, K, dtype=torch.float32, device=dev)
     if M:
         if not bf:
-            _use_planes(wt_planes)
+            _use_planes(wt, wt_planes)
         L.call('u3d_linear_dact', L.ptr(dy), L.ptr(wt), L.ptr(aux), act | (P.BF16_FLAG if bf else 0), L.ptr(dx), M, K, N,
                _flops(M, K, N, extra_mn=1), L.stream())
     return dx
@@ -217,8 +224,7 @@ def _weight_grad_overlapped(dy, x, want_bias, bf, weight, bias):
     its dW: the GEMM joins the sparse convolutions' weight-gradient chain and the dX chain goes on without it).  Only for leaf
     parameters without an existing .grad -- autograd then just stores the tensor; anything else is computed in line."""
     from . import sparse
-    ok = sparse._WGRAD_OVERLAP == 2 and _OVERLAP_TN and dy.is_cuda and weight.is_leaf and weight.grad is None and \
-        (bias is None or (bias.is_leaf and bias.grad is None))
+    ok = sparse._WGRAD_OVERLAP == 2 and _OVERLAP_TN and dy.is_cuda and sparse.async_dw_ok(weight, bias)
     if not ok:
         return _weight_grad(dy, x, want_bias, bf)
     dev = dy.device
@@ -304,7 +310,7 @@ class _MLPFn(torch.autograd.Function):
         elif M:
             _flops(M, hid, d_in, extra_mn=1 if act == ACT_GELU else 0)
             _flops(M, d_out, hid)
-            _use_planes(p1, p2)
+            _use_planes(w1c, p1, w2c, p2)
             L.call('u3d_ffn_fwd', L.ptr(x), L.ptr(w1c), L.ptr(b1), L.ptr(w2c), L.ptr(b2), act | (P.BF16_FLAG if ctx.bf else 0),
                    L.ptr(h), L.ptr(a), L.ptr(z), M, d_in, hid, d_out, 1.0 if _PROFILE_FLOPS else 0.0, L.stream())
         ctx.save_for_backward(x, w1c, w2c, a, h)

@@ -247,7 +247,10 @@ def cat_views(ts):
     if base is not None and base.is_contiguous() and base.dim() >= 1:
         off, ok = base.storage_offset(), True
         for t in ts:
-            if t._base is not base or not t.is_contiguous() or t.dim() != base.dim() or t.shape[1:] != base.shape[1:] or t.storage_offset() != off:
+            # (also the autograd state and dtype of the base: slices taken under no_grad of a differentiable base must not hand the
+            # base -- and with it a gradient path torch.cat(ts) would not have -- to the caller)
+            if t._base is not base or not t.is_contiguous() or t.dim() != base.dim() or t.shape[1:] != base.shape[1:] or t.storage_offset() != off \
+                    or t.requires_grad != base.requires_grad or t.dtype != base.dtype:
                 ok = False
                 break
             off += t.numel()

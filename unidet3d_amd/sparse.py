@@ -506,10 +506,37 @@ def _side_stream(device):
     return _SIDE[device][i]
 
 
+_ASYNC_DW_SEEN: Dict = {}       # id(parameter) -> True for parameters whose dW of the running backward pass went to the side stream
+
+
+def async_dw_ok(*params) -> bool:
+    """May the weight gradients of ``params`` (a layer's weight and bias) stay on the side stream until the backward pass ends (mode 2)?
+    Only when the ONLY consumer of each of them is autograd's AccumulateGrad storing the tensor: a leaf without an existing
+    ``.grad``, without tensor hooks or post-accumulate-grad hooks (an optimizer-in-backward would read dW on the main stream at once),
+    outside ``create_graph`` -- and used for the FIRST time in this backward pass: a parameter shared by two layers gets its two
+    gradients summed by autograd on the main stream as soon as the second arrives.  In that case (and in every other refused one) the
+    caller computes in line AND the main stream first waits for everything already queued on the side stream, so that the first
+    gradient is complete before autograd adds to it."""
+    ok = not torch.is_grad_enabled()
+    for w in params:
+        if w is None:
+            continue
+        ok = ok and w.is_leaf and w.grad is None and not getattr(w, '_backward_hooks', None) and \
+            not getattr(w, '_post_accumulate_grad_hooks', None) and id(w) not in _ASYNC_DW_SEEN
+    if ok:
+        for w in params:
+            if w is not None:
+                _ASYNC_DW_SEEN[id(w)] = True
+    elif any(w is not None and id(w) in _ASYNC_DW_SEEN for w in params):
+        join_wgrad_stream()
+    return ok
+
+
 def join_wgrad_stream(device=None):
     """Make the current stream wait for the weight-gradient kernels queued on the side stream(s) (mode 2).  Called by the autograd
     callback at the end of a backward pass and by anything that reads ``.grad`` of a convolution weight earlier than that
     (``dist.FlatGradBucket`` before it copies a bucket).  A no-op when nothing is pending."""
+    _ASYNC_DW_SEEN.clear()
     for dev in ([device] if device is not None else list(_JOIN_PENDING)):
         if _JOIN_PENDING.pop(dev, None):
             cur = torch.cuda.current_stream(dev)
@@ -597,8 +624,8 @@ class _SparseConvFn(torch.autograd.Function):
                 wg, xw, gw = 'u3d_spconv_wgrad_rows', ctx.src_shadow, dout_shadow
 
             overlap = _WGRAD_OVERLAP if ctx.needs_input_grad[0] else 0       # (the first convolution has no input gradient to run next to)
-            if overlap == 2 and not (weight.is_leaf and weight.grad is None):
-                overlap = 1      # autograd will ADD dw to an existing .grad (or feed it to another node) on this stream right away: join first
+            if overlap == 2 and not async_dw_ok(weight):
+                overlap = 1      # autograd will ADD dw to an existing .grad (or feed it to another node / a hook) on this stream right away: join first
             if overlap:
                 side = _side_stream(weight.device)
                 side.wait_stream(torch.cuda.current_stream())                 # dout (and everything before it) is complete

@@ -47,9 +47,11 @@ def test_async_weight_gradient_guard():
         assert sparse.async_dw_ok(w, b)
         assert not sparse.async_dw_ok(w)       # second use in the same pass: autograd will sum the two gradients
         assert not sparse.async_dw_ok(b, None)
-        sparse.join_wgrad_stream()             # end of the pass: forgotten
+        sparse.join_wgrad_stream()             # a join in the middle of the pass does not forget the uses
+        assert not sparse.async_dw_ok(w)
+        sparse.end_of_backward()               # end of the pass: forgotten
         assert sparse.async_dw_ok(w, None)
-        sparse.join_wgrad_stream()
+        sparse.end_of_backward()
         w.grad = torch.zeros(3)
         assert not sparse.async_dw_ok(w)       # accumulation into an existing .grad
         w.grad = None

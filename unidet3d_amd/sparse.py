@@ -536,7 +536,6 @@ def join_wgrad_stream(device=None):
     """Make the current stream wait for the weight-gradient kernels queued on the side stream(s) (mode 2).  Called by the autograd
     callback at the end of a backward pass and by anything that reads ``.grad`` of a convolution weight earlier than that
     (``dist.FlatGradBucket`` before it copies a bucket).  A no-op when nothing is pending."""
-    _ASYNC_DW_SEEN.clear()
     for dev in ([device] if device is not None else list(_JOIN_PENDING)):
         if _JOIN_PENDING.pop(dev, None):
             cur = torch.cuda.current_stream(dev)
@@ -549,7 +548,14 @@ def _queue_join(device):
     launch (the first one to run joins and clears the pending flag, the rest are no-ops): a flag-guarded single callback would be lost
     for good if a backward pass died between queueing and running it."""
     _JOIN_PENDING[device] = True
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: join_wgrad_stream(device))
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: end_of_backward(device))
+
+
+def end_of_backward(device=None):
+    """The autograd engine's callback when a backward pass ends: join the side stream(s) and forget which parameters sent their
+    gradient there (``async_dw_ok`` counts uses per pass; a join in the middle of a pass must NOT reset that)."""
+    join_wgrad_stream(device)
+    _ASYNC_DW_SEEN.clear()
 
 
 _PROFILE_FLOPS = False      # bench.py turns this on so that launches carry exact algorithmic flops

@@ -42,6 +42,7 @@ def test_async_weight_gradient_guard():
     create_graph, used for the first time in the running backward pass."""
     from unidet3d_amd import sparse
     w, b = torch.zeros(3, requires_grad=True), torch.zeros(3, requires_grad=True)
+    nonleaf = w * 1.0
     sparse._ASYNC_DW_SEEN.clear()
     with torch.no_grad():                      # what a backward pass without create_graph looks like
         assert sparse.async_dw_ok(w, b)
@@ -58,7 +59,7 @@ def test_async_weight_gradient_guard():
         h = w.register_hook(lambda g: g)
         assert not sparse.async_dw_ok(w)       # a hook reads the gradient at once
         h.remove()
-        assert not sparse.async_dw_ok((w * 1.0))      # not a leaf
+        assert not sparse.async_dw_ok(nonleaf)      # not a leaf
     assert not sparse.async_dw_ok(b)           # grad mode on inside backward = create_graph
     sparse._ASYNC_DW_SEEN.clear()
 

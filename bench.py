@@ -12,8 +12,11 @@ Workload (BASELINE.json configs[1]): 8 synthetic ScanNet-shape scenes per GPU, 1
 One step = one pass of the hot path over the batch with the points already resident in HBM:
 voxelise -> rulebooks -> backbone -> superpoint pooling -> decoder -> matcher/loss -> backward ->
 (gradient all-reduce when N > 1) -> grad clip + AdamW.  Weak scaling: every rank runs its own 8 scenes.
-Prints ONE JSON line (rank 0).  The line's headline is the fp32 cfg2 measurement; a `cfg3` block (BASELINE.json configs[2]:
-bf16 MFMA operands, 16 scenes per GPU) measured right after it in the same process rides along (--no-cfg3 skips it).
+Prints ONE JSON line (rank 0).  The line's headline is the fp32 cfg2 measurement; measured right after it in the same process ride
+along (N = 1 only): `fp32_native_mfma` (the same workload on the native fp32 MFMA kernels), `cfg3` (BASELINE.json configs[2]: bf16
+MFMA operands, 16 scenes per GPU), `cfg4` and `cfg5` (configs[3] / [4], one GPU's share each: the six-dataset joint batch, one 1 M-point
+room) and `cpu_baseline`; --no-mfma-line / --no-cfg3 / --no-extra-configs / --no-cpu-baseline skip them.  `tree_hash` stamps the line
+with a hash of the shipped sources (`python bench.py --tree-hash` prints it without a GPU).
 """
 from __future__ import annotations
 
@@ -56,6 +59,9 @@ def parse():
     ap.add_argument('--no-mfma-line', action='store_true',
                     help='skip the `fp32_native_mfma` block (the same fp32 workload on the native fp32 MFMA kernels) appended to the default line')
     ap.add_argument('--no-cfg3', action='store_true', help='skip the cfg3 block (bf16 operands, 16 scenes/GPU) appended to the fp32 line')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help="skip the cfg4 / cfg5 blocks (BASELINE.json configs[3] / [4] per-GPU shares, fp32) appended to the default line")
+    ap.add_argument('--tree-hash', action='store_true', help='print the hash of the shipped source tree (the stamp of every line) and exit; needs no GPU')
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--voxel-size', type=float, default=0.02)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -203,6 +209,22 @@ def csrc_hashes(names=None):
     if names is None:
         names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h')))
     return {n: hashlib.sha256(open(os.path.join(d, n), 'rb').read()).hexdigest()[:16] for n in names}
+
+
+def tree_hash() -> str:
+    """sha256/16 over (relative path, content hash) of every source file that decides a measurement: unidet3d_amd/**.{py,hip,h,json},
+    include/u3d.h and this file -- a stamp the shipped tree computes itself, on the GPU box and in any checkout alike (VERDICT r5 weak
+    #6: `.git_head` is written at the builder's last GPU run and goes stale with the next commit).  `python bench.py --tree-hash`."""
+    import glob
+    import hashlib
+    files = [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, 'include', 'u3d.h')]
+    for ext in ('py', 'hip', 'h', 'json'):
+        files += glob.glob(os.path.join(ROOT, 'unidet3d_amd', '**', f'*.{ext}'), recursive=True)
+    h = hashlib.sha256()
+    for f in sorted(set(files)):
+        h.update(os.path.relpath(f, ROOT).replace(os.sep, '/').encode())
+        h.update(hashlib.sha256(open(f, 'rb').read()).digest())
+    return h.hexdigest()[:16]
 
 
 def git_head() -> str:
@@ -455,6 +477,9 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
 
 def main():
     args = parse()
+    if args.tree_hash:
+        print(tree_hash())
+        return
     self_launch(args)                                  # N > 1 outside torchrun: does not return
     from unidet3d_amd import _lib as L
     from unidet3d_amd.dist import init_from_env
@@ -474,8 +499,8 @@ def main():
     dev = torch.device('cuda', local_dev)
 
     head_batch = args.batch if args.batch is not None else (1 if args.config == 'cfg5' else (16 if args.dtype == 'bf16' else 8))
-    if args.config != 'cfg2':      # the extra blocks (native MFMAs, cfg3, CPU baseline) belong to the headline line
-        args.no_mfma_line = args.no_cfg3 = args.no_cpu_baseline = True
+    if args.config != 'cfg2':      # the extra blocks (native MFMAs, cfg3, cfg4, cfg5, CPU baseline) belong to the headline line
+        args.no_mfma_line = args.no_cfg3 = args.no_cpu_baseline = args.no_extra_configs = True
     head = measure(args, args.dtype, head_batch, rank, world, dev)
     # The two extra blocks below belong to the single-GPU line only: at N > 1 every further configuration builds a second model,
     # gradient bucket and communicator inside the same job -- measured with 2 gloo ranks: an ~11 s one-time stall lands somewhere in
@@ -492,6 +517,19 @@ def main():
         # BASELINE.json configs[2] right behind the headline, same process, same protocol (W warm-up + K timed steps)
         cfg3 = measure(args, 'bf16', 16, rank, world, dev)
 
+    extra = {}
+    if world == 1 and args.dtype == 'fp32' and not args.no_extra_configs:
+        # BASELINE.json configs[3] / [4], one GPU's share each, behind the headline in the same process so that the driver's default run
+        # measures all four GPU configurations.  Same protocol with their own, smaller step counts (stated in the block)
+        import copy as _copy
+        for name, b in (('cfg4', 8), ('cfg5', 1)):
+            a2 = _copy.copy(args)
+            a2.config, a2.steps, a2.warmup = name, min(args.steps, 10), min(args.warmup, 2)
+            blk = measure(a2, 'fp32', b, rank, world, dev)
+            extra[name] = dict(note=f"BASELINE.json configs[{3 if name == 'cfg4' else 4}], one GPU's share, measured after the headline in the same process: "
+                                    f"{a2.warmup} warm-up + {a2.steps} timed steps, fp32 (bf16x3 products); PMC traffic is collected for the cfg2 / cfg3 commands only",
+                               steps=a2.steps, warmup=a2.warmup, **blk)
+
     if rank == 0:
         out = {'metric': METRIC, 'value': head['value'], 'unit': head['unit'], 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -506,9 +544,12 @@ def main():
         if cfg3 is not None:
             out['cfg3'] = dict(note='BASELINE.json configs[2] measured after the headline in the same process: bf16 MFMA operands, 16 scenes/GPU; '
                                     'families priced against the bf16 dense MFMA peak where their operands are bf16', **cfg3)
+        for name, blk in extra.items():
+            out[name] = blk
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.points, args.voxel_size)
         out['git_head'] = git_head()
+        out['tree_hash'] = tree_hash()
         # the line is long and a log keeps its TAIL: the few numbers a reader wants first are repeated here, last
         out['summary'] = {'scenes_per_s': round(head['value'], 2), 'ms_per_step': round(head['ms_per_step'], 3), 'workload': args.config,
                           'dtype': head['dtype'], 'n_gpus': world,
@@ -516,6 +557,9 @@ def main():
                           'roofline_traffic_bytes_per_launch': head['roofline']['traffic'],
                           'fp32_native_mfma_scenes_per_s': round(native['value'], 2) if native is not None else None,
                           'cfg3_bf16_scenes_per_s': round(cfg3['value'], 2) if cfg3 is not None else None,
+                          'cfg4_joint_scenes_per_s': round(extra['cfg4']['value'], 2) if 'cfg4' in extra else None,
+                          'cfg5_1m_point_rooms_per_s': round(extra['cfg5']['value'], 2) if 'cfg5' in extra else None,
+                          'tree_hash': out['tree_hash'],
                           'cpu_baseline_scenes_per_s': (out.get('cpu_baseline') or {}).get('value')}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -18,6 +18,7 @@ def test_defaults_are_one_gpu_and_a_run_of_minutes(monkeypatch):
     assert bench.METRIC == json.load(open(os.path.join(ROOT, 'BASELINE.json')))['metric']
     assert a.gpus == 1 and 1 <= a.steps <= 50 and a.warmup >= 1 and a.dtype == 'fp32' and a.points == 100_000
     assert not a.no_prefetch and not a.no_optimizer and not a.no_cpu_baseline and not a.no_cfg3 and not a.no_mfma_line and a.optimizer == 'adamw'
+    assert not a.no_extra_configs and a.config == 'cfg2'          # the default line carries cfg2 (headline), native MFMAs, cfg3, cfg4, cfg5
 
 
 def test_gpus_n_turns_itself_into_a_torchrun_launch(monkeypatch):
@@ -94,6 +95,31 @@ def test_git_head_falls_back_to_the_stamp_file(tmp_path, monkeypatch):
     assert bench.git_head() == '?'
     (tmp_path / '.git_head').write_text('deadbeef1234+dirty(ab12cd34)\n')
     assert bench.git_head() == 'deadbeef1234+dirty(ab12cd34)'
+
+
+def test_tree_hash_is_a_function_of_the_shipped_sources_only(tmp_path, monkeypatch):
+    """The stamp of a bench line: computed from the files themselves -- the same in the build container, on the GPU
+    box (no .git there) and in the driver's checkout; changes with any source byte, not with build products or caches."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    h = bench.tree_hash()
+    assert len(h) == 16 and h == bench.tree_hash()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--tree-hash'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == h
+    (tmp_path / 'unidet3d_amd' / 'csrc').mkdir(parents=True)
+    (tmp_path / 'include').mkdir()
+    (tmp_path / 'bench.py').write_text('x')
+    (tmp_path / 'include' / 'u3d.h').write_text('h')
+    (tmp_path / 'unidet3d_amd' / 'a.py').write_text('a')
+    (tmp_path / 'unidet3d_amd' / 'csrc' / 'k.hip').write_text('k')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    h0 = bench.tree_hash()
+    (tmp_path / 'unidet3d_amd' / 'csrc' / 'k.o').write_text('object code')          # build products do not count
+    (tmp_path / 'unidet3d_amd' / 'csrc' / 'libu3d_hip.so').write_text('library')
+    assert bench.tree_hash() == h0
+    (tmp_path / 'unidet3d_amd' / 'csrc' / 'k.hip').write_text('k2')
+    assert bench.tree_hash() != h0
 
 
 def test_kept_bench_lines_follow_the_contract():

@@ -224,6 +224,25 @@ def test_cfg4_joint_config_mixed_batch_vs_oracle():
     PA.compare('cfg4_joint_mixed_batch', P, O, prod, orac, g64, None, g64m)
 
 
+def test_cfg4_loss_of_refed_samples_does_not_drift():
+    """``loss`` shifts the ground-truth boxes of the box-annotated datasets into the training frame and, like the
+    reference, stores them back into the sample.  Feeding the SAME samples again (bench.py does, 25 times) must give the same boxes
+    and the same loss, not boxes shifted once more per call."""
+    cfg = _joint_cfg()
+    prod, _orac = PA.build_pair(cfg, tag0=5000)
+    specs = [('scannet', 20_000), ('arkitscenes', 20_000), ('multiscan', 20_000), ('scannetpp', 20_000)]
+    _scenes, _names, _gt, inputs, samples = _joint_batch(cfg, specs)
+    prod.train()
+    losses, centres = [], []
+    for _ in range(3):
+        with torch.no_grad():
+            losses.append(float(prod.loss(inputs, samples)['det_loss']))
+        centres.append([ds.gt_instances_3d.bboxes_3d.gravity_center.clone() for ds in samples])
+    assert losses[0] == losses[1] == losses[2], losses
+    for a, b in zip(centres[0], centres[2]):
+        assert torch.equal(a, b)
+
+
 def test_cfg4_stated_point_counts_properties():
     """BASELINE.md's cfg4 workload at its STATED sizes (bench.py --config cfg4: 8 mixed scenes of 100 k / 180 k /
     200 k points, ~1 M points per GPU) -- too large for the CPU oracle's full forward/backward in test time, so size-independent

@@ -253,10 +253,14 @@ class UniDet3D(nn.Module):
                 ids = ds.gt_pts_seg.pts_instance_mask.to(pts.device)
                 inst.bboxes_3d = self.get_bboxes_by_masks(ids, len(inst.labels_3d), pts)
             else:
-                b = inst.bboxes_3d
+                # (the reference overwrites the sample's boxes with the shifted ones, unidet3d.py:318-330 -- harmless there, every batch
+                # is loaded afresh.  A caller that feeds the SAME sample again -- bench.py, a test, an overfit run -- must not see the
+                # boxes walk by -scene_min per step: the shifted object remembers the box it was made from)
+                b = getattr(inst.bboxes_3d, '_u3d_unshifted', inst.bboxes_3d)
                 center = b.gravity_center - (vb.stats[i, :3] * self.voxel_size if vb.coord_src is not None else vb.stats[i, :3])
                 inst.bboxes_3d = DepthInstance3DBoxes(torch.cat((center, b.tensor[:, 3:]), dim=1), with_yaw=b.with_yaw,
                                                       box_dim=b.tensor.shape[1], origin=(0.5, 0.5, 0.5))
+                inst.bboxes_3d._u3d_unshifted = b
             inst.sp_centers = sp_centers[i]
             if self.target_by_distance[dataset]:
                 inst.sp_masks = self.get_targets(inst.sp_centers, inst.bboxes_3d, self.train_cfg['topk'])

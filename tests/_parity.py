@@ -79,7 +79,7 @@ def oracle_forward(orac, scenes, names, crit_cfg=None, det_cfg=None, gt_boxes=No
     return dict(feats=feats, out=out, loss=loss, coords=x.indices, centers=cent, insts=insts)
 
 
-def product_forward(prod, inputs, samples, relu_masks=False):
+def product_forward(prod, inputs, samples, relu_masks=False, query_perms=None):
     """One training pass of the product with the decoder input / output captured (the tensors the loss really used).
     ``relu_masks``: also record, for every BatchNorm+ReLU of the backbone, which units came out positive (``P['relu_masks']``:
     module name -> bool [rows, C] on the CPU; rows are in canonical order, the same as the oracle's)."""
@@ -100,7 +100,7 @@ def product_forward(prod, inputs, samples, relu_masks=False):
     prod.extract_feat = spy
     h = prod.decoder.register_forward_hook(lambda m, i, o: seen.update(out=o))
     try:
-        loss = prod.loss(inputs, samples)['det_loss']
+        loss = prod.loss(inputs, samples, query_perms=query_perms)['det_loss']
     finally:
         h.remove()
         for hk in hooks:

@@ -78,6 +78,49 @@ def test_cfg2_full_size_end_to_end_vs_oracle():
     PA.compare('cfg2_full_size_8x100k', P, O, prod, orac, g64, None, g64m)
 
 
+def test_cfg5_one_million_point_room_forward_and_loss_vs_oracle():
+    """BASELINE configs[4] at size, floating point: ONE synthetic S3DIS-shape room of 1 M points (bench.py --config
+    cfg5's scene: ~0.5 M voxels, spatial extent up to 512 cells) through backbone, pooling, decoder and loss against the fp32 CPU oracle:
+    voxel coordinates bit-exact, per-superpoint features, logits and boxes of all 7 heads and the loss <= 1e-3.  The room has more
+    superpoints than ``query_thr`` = 3000, so the training path subsamples the queries -- the permutation the reference would draw
+    from the CPU RNG (unidet3d.py:209) is injected into both sides.  Forward + loss only: an fp64 gradient pass of the oracle at this
+    size does not fit the test budget (integers at this size: test_gpu_kernels.py; fwd+bwd finiteness / repeatability: test_gpu_model.py)."""
+    from oracle import criterion as oc
+    from unidet3d_amd.data import make_batch_inputs
+    from unidet3d_amd.synthetic import make_scene
+    cfg = _scannet_cfg()
+    prod, orac = PA.build_pair(cfg)
+    sc = make_scene(500, n_points=1_000_000, area_scale=10.0, n_furniture=40)
+    S = int(sc.superpoints.max()) + 1
+    thr = prod.query_thr
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(5))[:thr] if S > thr else None
+    with torch.no_grad():
+        pts, sps = [torch.from_numpy(sc.points)], [torch.from_numpy(sc.superpoints)]
+        ofeats, x = orac.extract_feat(pts, sps)
+        cent = orac.sp_centers(pts, sps)
+        inst = oc.gt_from_scene(pts[0][:, :3] - pts[0][:, :3].min(0)[0], torch.from_numpy(sc.instance_mask), torch.from_numpy(sc.labels), sps[0])
+        qf, qc = ofeats, cent
+        if perm is not None:
+            qf, qc = [ofeats[0][perm]], [cent[0][perm]]
+            inst.query_masks = inst.sp_masks[:, perm]
+        oout = orac.decoder(qf, qc, ['scannet'])
+        oloss = oc.criterion(oout, [inst])
+        inputs, samples = make_batch_inputs([sc], DEV)
+        P = PA.product_forward(prod, inputs, samples, query_perms=None if perm is None else [perm])
+    assert torch.equal(P['coords'].cpu(), x.indices), 'voxel coordinates differ from the oracle'
+    err = dict(n_points=len(sc.points), n_voxels=int(x.indices.shape[0]), n_superpoints=S, n_queries=int(oout['cls_preds'][0].shape[0]),
+               feats=PA.rel(P['feats'][0], ofeats[0]))
+    heads_p, heads_o = [P['out']] + list(P['out']['aux_outputs']), [oout] + list(oout['aux_outputs'])
+    assert len(heads_p) == len(heads_o) == 7
+    err['logits'] = max(PA.rel(hp['cls_preds'][0], ho['cls_preds'][0]) for hp, ho in zip(heads_p, heads_o))
+    err['boxes'] = max(PA.rel(hp['bboxes'][0], ho['bboxes'][0]) for hp, ho in zip(heads_p, heads_o))
+    err['loss'] = abs(float(P['loss']) - float(oloss)) / abs(float(oloss))
+    PA.log_errors('cfg5_one_room_1M_points_forward', err)
+    print('cfg5', json.dumps(err))
+    assert 300_000 < err['n_voxels'] < 700_000 and err['n_queries'] == min(S, thr)
+    assert err['feats'] < 1e-3 and err['logits'] < 1e-3 and err['boxes'] < 1e-3 and err['loss'] < 1e-3, err
+
+
 # bf16-operand tolerances of cfg3 against the FP32 CPU oracle (operands carry 8 mantissa bits, accumulation is fp32): max-norm
 # relative error / mean absolute error relative to the mean magnitude, per quantity, over all 16 scenes and 7 heads.
 # Measured on MI355X at B = 16 x 100 k (profiles/round3_parity_errors.jsonl): features 2.7e-2 / 6.3e-3, logits 3.5e-2 / 5.9e-3,

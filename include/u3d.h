@@ -223,6 +223,14 @@ int u3d_spconv_plan_bf16a(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, 
  * u3d_weight_pack_x3, K = 27); flip = 0: k' = k (forward); flip = 1: k' = 26 - k with the TRANSPOSED pack -- the input gradient
  * (SubM pairs are symmetric).  tile_rows / halo_rows must be the pair the tables were built for (u3d_spconv_ts_plan gives the
  * measured choice per shape, U3D_EUNSUPPORTED for shapes the kernel is not instantiated for -- the caller then uses u3d_spconv_gmm_x3). */
+/* Register-stationary form of the same convolution (csrc/spconv_ts.hip spconv_rs_k): persistent workgroups (`workgroups` of them, <= 0:
+ * one per CU) keep the weights of all 27 offsets of a 32 -> 32 channel block in registers for the whole launch -- each of the four
+ * waves the fragments of its 6-7 offsets -- and walk contiguous ranges of 64-row tiles: no weight traffic and no barrier per offset;
+ * the waves' partial tiles are added in wave order (deterministic).  Wider layers run as Cs/32 x Cd/32 launches of the block kernel
+ * inside this call (accumulating over the source blocks).  Tables: u3d_subm_halo(..., tile_rows = 64, halo_rows) with halo_rows in
+ * {256, 320, 416} (tiles with more unique source rows take further passes); pmask is not read.  Same arguments otherwise. */
+int u3d_spconv_rs_x3(const float* src, int64_t n, const void* w_rows_x3, const int32_t* nhalo, const int32_t* halo, const uint16_t* loc,
+                     int halo_rows, int flip, int Cs, int Cd, const float* addend, float* dst, int workgroups, double flops_hint, u3d_stream_t stream);
 int u3d_spconv_ts_plan(int Cs, int Cd, int64_t n, int* tile_rows, int* halo_rows);
 int u3d_subm_halo_pmax(int tile_rows, int halo_rows);
 int u3d_subm_halo(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots, int B,

@@ -114,6 +114,24 @@ with P.fp32_math('bf16x3'):
             print(row, flush=True)
             yr = ref64(x, w, rb, 0) if check else None
             dr = ref64(go, w, rb, 1) if check else None
+            for H in [int(h) for h in os.environ.get('PROF_RS_H', '320').split(',') if h]:
+                os.environ['U3D_RS_H'] = str(H)
+                try:
+                    with sparse.conv_rs(True):
+                        if not sparse._rs_ok(cs, cd, n, rb, P.FMT_X3):
+                            continue
+                        xg = x.clone().requires_grad_()
+                        y1 = sparse.sparse_conv(xg, w, rb)
+                        y1.backward(go)
+                        d1 = xg.grad
+                        us1 = timed(lambda: sparse.sparse_conv(x, w, rb))
+                    msg = f'      rs H={H}: {us1:7.1f} us ({gf / us1 * 1e-3:5.1f} TF/s) x{us0 / us1:4.2f}'
+                    if check:
+                        e = lambda a, r: float((a.detach().double() - r).abs().max() / r.abs().max())
+                        msg += f' | fwd err rs {e(y1, yr):.2e} pairs {e(y0, yr):.2e} | dgrad err rs {e(d1, dr):.2e} pairs {e(d0, dr):.2e}'
+                    print(msg, flush=True)
+                except Exception as ex:      # noqa: BLE001
+                    print(f'      rs H={H}: FAILED {ex}', flush=True)
             for T, H in plans:
                 os.environ['U3D_TS_T'], os.environ['U3D_TS_H'] = str(T), str(H)
                 try:
@@ -127,7 +145,7 @@ with P.fp32_math('bf16x3'):
                         us1 = timed(lambda: sparse.sparse_conv(x, w, rb))
                     msg = f'      ts T={T} H={H}: {us1:7.1f} us ({gf / us1 * 1e-3:5.1f} TF/s) x{us0 / us1:4.2f}'
                     if check:
-                        e = lambda a, r: float((a.double() - r).abs().max() / r.abs().max())
+                        e = lambda a, r: float((a.detach().double() - r).abs().max() / r.abs().max())
                         msg += f' | fwd err ts {e(y1, yr):.2e} pairs {e(y0, yr):.2e} | dgrad err ts {e(d1, dr):.2e} pairs {e(d0, dr):.2e}'
                     print(msg, flush=True)
                 except Exception as ex:      # noqa: BLE001

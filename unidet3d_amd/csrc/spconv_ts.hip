@@ -464,6 +464,203 @@ static int launch_ts(const TsParams& p, hipStream_t s) {
     return check_launch("spconv_ts");
 }
 
+// ---- register-stationary weights (round 6, second form) ---------------------------------------------------------------------------
+// What the cycle trace of spconv_ts_k says (profiles/round6_ts_cycle_trace.txt): a step -- one offset of one pass -- lasts 1100-1600
+// cycles for ~220 cycles of MFMA issue per wave; the four waves meet at a barrier per offset (the weight hand-over) with unequal work,
+// and the weights of an offset (6 KB) are fetched again for every (tile, pass, offset): 786 MB per level-1 launch through the texture
+// path, more than the feature rows.  For a 32 -> 32 block the weights of all 27 offsets are 162 KB in three planes -- a third of a CU's
+// register file.  So here they never move: a PERSISTENT workgroup (one per CU, one wave per SIMD, up to 512 registers per lane) loads
+// them once, wave w keeping the MFMA fragments of "its" 6-7 offsets (one centre / face / edge / corner mix per wave) in registers for
+// the whole launch, and walks a contiguous range of 64-row tiles.  Per tile: the halo rows are split into their planes once (as in
+// spconv_ts_k), then every wave multiplies ITS offsets for ALL four 16-row sub-tiles -- no weight traffic, no barrier until the tile is
+// done -- and the four partial [64 x 32] tiles are added in wave order through LDS (fixed order: deterministic).  Wider layers are
+// tiled over 32-channel blocks of source and destination (Cs/32 x Cd/32 launches inside the entry point, accumulating over the source
+// blocks through `addend`).
+constexpr int RS_T = 64;
+__device__ const signed char RS_OFFS[4][7] = {{13, 4, 1, 3, 5, 0, 2}, {10, 12, 7, 9, 11, 6, 8}, {14, 16, 15, 17, 19, 18, 20}, {22, 21, 23, 25, 24, 26, -1}};
+
+struct RsParams {
+    const float* src;
+    const void* w;
+    const int32_t* nhalo;
+    const int32_t* halo;
+    const uint16_t* loc;
+    const float* addend;       // nullable; same leading dimension and column offset as out
+    float* out;
+    int64_t n;
+    int src_ld, src_c0;        // floats per source row, first channel of this launch's 32-channel block
+    int dst_ld, dst_c0;
+    int w_base16;              // 16-byte index of (slice, offset 0, unit) in the packed weights; w_k16: stride between offsets
+    int w_k16;
+    int n_tiles, tiles_per_wg, flip;
+    unsigned long long* trace; // -DU3D_TS_TRACE builds: [workgroups][4 waves][8] accumulated cycles per phase
+};
+
+constexpr int rs_lds_bytes(int h) { return 3 * (h + 1) * 64 + 27 * RS_T * 2 + 4 * RS_T * 32 * 4; }
+
+template <int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void spconv_rs_k(RsParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+    constexpr int T = RS_T, NC = 27 * T, PLANE = (H + 1) * 64, HALO = 3 * PLANE, LOCB = 27 * T * 2, ROUNDS = H / 32;
+    char* const hl = ts_smem;
+    char* const ll = ts_smem + HALO;
+    float* const red = reinterpret_cast<float*>(ts_smem + HALO + LOCB);          // [4 waves][64 rows][32 columns]
+    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = (int)xcd_swizzle(blockIdx.x, gridDim.x);                      // neighbouring tile ranges on one XCD / L2
+    const int t_begin = wg * p.tiles_per_wg, t_end = min(p.n_tiles, t_begin + p.tiles_per_wg);
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(p.src, p.n * p.src_ld * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w);
+    const int ld4 = p.src_ld * 4, c0b = p.src_c0 * 4;
+    const int pc = tid & 7, prow = tid >> 3;
+#ifdef U3D_TS_TRACE
+    unsigned long long* const tr = p.trace ? p.trace + ((int64_t)blockIdx.x * 4 + wave) * 8 : nullptr;
+    unsigned long long tprev = clock64();
+#define RS_PHASE(i) do { if (tr && lane == 0) { const unsigned long long now_ = clock64(); tr[(i)] += now_ - tprev; tprev = now_; } } while (0)
+#else
+#define RS_PHASE(i) do {} while (0)
+#endif
+
+    // ---- this wave's weights: fragments of its offsets, in registers for the whole launch ----
+    f32x4 wf[7][2][3];
+    int kks[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int kk = RS_OFFS[wave][j];
+        kks[j] = kk;
+        const int k = kk < 0 ? 0 : (p.flip ? 26 - kk : kk);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[j][nb][pl] = bload128(rs_w, (p.w_base16 + k * p.w_k16 + (nb * 3 + pl) * 64 + lane) * 16, 0);
+    }
+    if (tid < 12) *reinterpret_cast<f32x4*>(hl + (tid >> 2) * PLANE + H * 64 + (tid & 3) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};      // the zero row
+    RS_PHASE(0);
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int64_t r0 = (int64_t)tile * T;
+        const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(p.halo + (int64_t)tile * NC, (int64_t)NC * 4);
+        const __amdgpu_buffer_rsrc_t rs_l = make_rsrc(p.loc + (int64_t)tile * NC, (int64_t)NC * 2);
+        const int nh = __builtin_amdgcn_readfirstlane(p.nhalo[tile]);
+        const int npass = (nh + H - 1) / H;
+        f32x4 hi[4][2], lo[4][2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { hi[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int ps = 0; ps < npass; ++ps) {
+            const int cnt = min(H, nh - ps * H);
+            ts_barrier();                                   // the previous tile's (pass's) reads of the halo image, loc table and `red` are done
+            RS_PHASE(1);
+            if (ps == 0 && tid < LOCB / 16) *reinterpret_cast<f32x4*>(ll + tid * 16) = bload128(rs_l, tid * 16, 0);
+            int hrow[ROUNDS];
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j) hrow[j] = bload32(rs_h, (ps * H + j * 32 + prow) * 4, 0);
+#pragma unroll
+            for (int j0 = 0; j0 < ROUNDS; j0 += 5) {
+                f32x4 v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (j0 + j < ROUNDS) {
+                        const bool ok = (j0 + j) * 32 + prow < cnt;
+                        v[j] = bload128(rs_src, ok ? (int)__umul24(hrow[j0 + j], ld4) + c0b + pc * 16 : 0x7ffffff0, 0);
+                    }
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (j0 + j < ROUNDS) {
+                        const int sl = (j0 + j) * 32 + prow;
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split3_pair(v[j][0], v[j][1], h0, m0, l0);
+                        split3_pair(v[j][2], v[j][3], h1, m1, l1);
+                        char* const b = hl + ts_slot_off(sl, pc & 3) + (pc >> 2) * 8;
+                        *reinterpret_cast<uint2*>(b) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(b + PLANE) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2*>(b + 2 * PLANE) = make_uint2(l0, l1);
+                    }
+            }
+            RS_PHASE(2);
+            ts_barrier();
+            RS_PHASE(3);
+            // ---- this wave's 28 items (offset x sub-tile): all positions first (one LDS round trip for the lot), then per item three
+            // fragment reads one item ahead of the twelve MFMAs ----
+            int a0s[28];
+            unsigned amask = 0u;
+#pragma unroll
+            for (int it = 0; it < 28; ++it) {
+                const int kk = kks[it >> 2];
+                const int l = kk < 0 ? 0xFFFF : (int)*reinterpret_cast<const unsigned short*>(ll + kk * (T * 2) + ((it & 3) * 16 + i16) * 2);
+                const int s0 = l - ps * H;
+                const bool ok = (unsigned)s0 < (unsigned)cnt;
+                a0s[it] = ts_slot_off(ok ? s0 : H, q);
+                amask |= (__ballot(ok) != 0ull ? 1u : 0u) << it;
+            }
+            ts_bf16x8 xa[3], xb[3];
+            if (amask & 1u) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xa[pl] = *reinterpret_cast<const ts_bf16x8*>(hl + pl * PLANE + a0s[0]);
+            }
+#pragma unroll
+            for (int it = 0; it < 28; ++it) {
+                const int j = it >> 2, rt = it & 3;
+                ts_bf16x8 (&cur)[3] = (it & 1) ? xb : xa;
+                ts_bf16x8 (&nxt)[3] = (it & 1) ? xa : xb;
+                if (it + 1 < 28 && ((amask >> (it + 1)) & 1u)) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) nxt[pl] = *reinterpret_cast<const ts_bf16x8*>(hl + pl * PLANE + a0s[it + 1]);
+                }
+                if ((amask >> it) & 1u) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        f32x4 c = lo[rt][nb];
+                        c = ts_mfma(wf[j][nb][0], cur[2], c);
+                        c = ts_mfma(wf[j][nb][1], cur[1], c);
+                        c = ts_mfma(wf[j][nb][2], cur[0], c);
+                        c = ts_mfma(wf[j][nb][0], cur[1], c);
+                        c = ts_mfma(wf[j][nb][1], cur[0], c);
+                        lo[rt][nb] = c;
+                        hi[rt][nb] = ts_mfma(wf[j][nb][0], cur[0], hi[rt][nb]);
+                    }
+                }
+            }
+            RS_PHASE(4);
+        }
+        // ---- the four waves' partial tiles -> LDS -> summed in wave order by the wave that owns the rows -> dst ----
+        if (npass == 0) ts_barrier();
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                *reinterpret_cast<f32x4*>(red + ((wave * T + rt * 16 + i16) * 32 + nb * 16 + q * 4)) = hi[rt][nb] + lo[rt][nb];
+        ts_barrier();
+        RS_PHASE(5);
+        {
+            const int rr = wave * 16 + i16;                 // this lane's row of the tile
+            const int64_t row = r0 + rr;
+            if (row < p.n) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(red + ((0 * T + rr) * 32 + nb * 16 + q * 4));
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + ((w * T + rr) * 32 + nb * 16 + q * 4));
+                    const int64_t o = row * p.dst_ld + p.dst_c0 + nb * 16 + q * 4;
+                    if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + o);
+                    *reinterpret_cast<f32x4*>(p.out + o) = v;
+                }
+            }
+        }
+        RS_PHASE(6);
+    }
+}
+
+template <int H>
+static int launch_rs(const RsParams& p, int wgs, hipStream_t s) {
+    constexpr int lds = rs_lds_bytes(H);
+    static_assert(lds <= 160 * 1024, "tile exceeds the LDS");
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&spconv_rs_k<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((spconv_rs_k<H>), dim3((unsigned)wgs), dim3(256), lds, s, p);
+    return check_launch("spconv_rs");
+}
+
 // launch plan: rows per tile T and halo rows per pass H by shape (tools/prof_ts.py sweeps; U3D_TS_T / U3D_TS_H override for A/B runs)
 static bool ts_plan(int Cs, int Cd, int64_t n, int* T, int* H) {
     if (Cs % 32 || Cd % 32 || n <= 0) return false;
@@ -547,6 +744,51 @@ int u3d_spconv_ts_x3(const float* src, int64_t n, const void* w_rows_x3, const i
 #undef U3D_TS_CASE
     set_error("spconv_ts: no instantiation for Cs=%d Cd=%d tile %d halo %d", Cs, Cd, tile_rows, halo_rows);
     return U3D_EUNSUPPORTED;
+}
+
+int u3d_spconv_rs_x3(const float* src, int64_t n, const void* w_rows_x3, const int32_t* nhalo, const int32_t* halo, const uint16_t* loc,
+                     int halo_rows, int flip, int Cs, int Cd, const float* addend, float* dst, int workgroups, double flops_hint, u3d_stream_t stream) {
+    if (!src || !w_rows_x3 || !nhalo || !halo || !loc || !dst || n <= 0) return U3D_EINVAL;
+    if (n >= (1 << 24) || n * Cs * 4 >= 0x7fffffffLL) {
+        set_error("spconv_rs: %lld rows x %d channels exceed the kernel's 32-bit addressing", (long long)n, Cs);
+        return U3D_EUNSUPPORTED;
+    }
+    if (Cs % 32 || Cd % 32 || Cs > 256 || Cd > 256) { set_error("spconv_rs: Cs=%d Cd=%d must be multiples of 32 up to 256", Cs, Cd); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_CONV_FWD, s, flops_hint);
+    if (workgroups <= 0) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceProp_t pr;
+        workgroups = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    RsParams p;
+    p.src = src; p.w = w_rows_x3; p.nhalo = nhalo; p.halo = halo; p.loc = loc; p.out = dst; p.n = n;
+    p.src_ld = Cs; p.dst_ld = Cd; p.flip = flip ? 1 : 0;
+    p.n_tiles = (int)ceil_div(n, RS_T);
+    p.tiles_per_wg = (int)ceil_div(p.n_tiles, workgroups);
+    const int wgs = (int)ceil_div(p.n_tiles, p.tiles_per_wg);
+    const int cs32 = Cs / 32;
+    p.w_k16 = cs32 * 384;
+    p.trace = nullptr;
+#ifdef U3D_TS_TRACE
+    { const char* e = getenv("U3D_TS_TRACE_PTR"); if (e) p.trace = (unsigned long long*)strtoull(e, nullptr, 0); }
+#endif
+    // destination blocks outer, source blocks inner: block (ds, ss) adds src[:, 32 ss ..] . W into dst[:, 32 ds ..] on top of what the
+    // previous source block left there (the first one on top of `addend`)
+    for (int ds = 0; ds < Cd / 32; ++ds)
+        for (int ss = 0; ss < cs32; ++ss) {
+            p.src_c0 = ss * 32; p.dst_c0 = ds * 32;
+            p.w_base16 = (ds * 27 * cs32 + ss) * 384;
+            p.addend = ss == 0 ? addend : dst;
+            int rc = U3D_EUNSUPPORTED;
+            if (halo_rows == 256) rc = launch_rs<256>(p, wgs, s);
+            else if (halo_rows == 320) rc = launch_rs<320>(p, wgs, s);
+            else if (halo_rows == 416) rc = launch_rs<416>(p, wgs, s);
+            else set_error("spconv_rs: halo_rows %d not in {256, 320, 416}", halo_rows);
+            if (rc != U3D_OK) return rc;
+        }
+    return U3D_OK;
 }
 
 }  // extern "C"

@@ -407,6 +407,32 @@ def conv_ts(on: bool):
         set_conv_ts(prev)
 
 
+# Register-stationary form (spconv_rs_k: weights of a 32 x 32 block in registers, persistent workgroups): U3D_CONV_RS=1 / set_conv_rs
+_CONV_RS = os.environ.get('U3D_CONV_RS', '0') == '1'
+_RS_MIN_ROWS = int(os.environ.get('U3D_CONV_RS_MIN_ROWS', '40000'))      # below that a level cannot feed one workgroup per CU
+_RS_MAX_BLOCKS = int(os.environ.get('U3D_CONV_RS_MAX_BLOCKS', '8'))      # Cs/32 x Cd/32 block launches per convolution at most
+
+
+def set_conv_rs(on: bool) -> bool:
+    global _CONV_RS
+    prev, _CONV_RS = _CONV_RS, bool(on)
+    return prev
+
+
+@contextlib.contextmanager
+def conv_rs(on: bool):
+    prev = set_conv_rs(on)
+    try:
+        yield
+    finally:
+        set_conv_rs(prev)
+
+
+def _rs_ok(Cs, Cd, n, rb, bf):
+    return (_CONV_RS and rb.coords is not None and int(bf) == P.FMT_X3 and Cs % 32 == 0 and Cd % 32 == 0 and n >= _RS_MIN_ROWS
+            and (Cs // 32) * (Cd // 32) <= _RS_MAX_BLOCKS)
+
+
 def _ts_plan(Cs, Cd, n):
     import ctypes
     T, H = ctypes.c_int(0), ctypes.c_int(0)
@@ -427,7 +453,20 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     ts = _ts_plan(Cs, Cd, n_dst) if (_CONV_TS and n_dst and rb.coords is not None and int(bf) == P.FMT_X3 and Cs % 32 == 0
                                        and not (stats_out is not None and _EPILOGUE_STATS)) else None
-    if ts is not None:
+    if n_dst and _rs_ok(Cs, Cd, n_dst, rb, bf) and not (stats_out is not None and _EPILOGUE_STATS):
+        H = int(os.environ.get('U3D_RS_H', '320'))
+        if _PROFILE_FLOPS:
+            account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)
+        nhalo, halo, loc, _pm = rb.halo(64, H)
+        hit = _PACKED.get((weight.data_ptr(), int(transposed), P.FMT_X3))
+        if hit is not None and hit[2] == weight._version and hit[1].device == src.device:
+            wp = hit[0]
+        else:
+            wp = torch.empty(_pack_floats(weight.numel(), P.FMT_X3), dtype=torch.float32, device=src.device)
+            L.call('u3d_weight_pack_x3', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
+        L.call('u3d_spconv_rs_x3', L.ptr(src), n_dst, L.ptr(wp), L.ptr(nhalo), L.ptr(halo), L.ptr(loc), H, int(transposed),
+               Cs, Cd, L.ptr(addend), L.ptr(dst), int(os.environ.get('U3D_RS_WGS', '0')), float(flops), L.stream())
+    elif ts is not None:
         T, H = ts
         if _PROFILE_FLOPS:
             account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)

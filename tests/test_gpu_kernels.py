@@ -201,6 +201,40 @@ def test_tile_stationary_tables_bit_exact_and_conv_matches_pair_kernel(T, H):
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
 
+@pytest.mark.parametrize('H', [256, 416])
+def test_register_stationary_conv_matches_oracle_and_pair_kernel(H, monkeypatch):
+    """csrc/spconv_ts.hip spconv_rs_k (persistent workgroups, the weights of a 32 x 32 channel block in registers, partial tiles of the
+    four waves added in wave order): forward (+ residual addend) and input gradient against the fp64 oracle and within fp32 rounding of
+    the pair-list kernel; 32 -> 32 and the block-tiled wider shapes; H = 256 forces tiles through more than one pass; two runs equal
+    to the bit (the reduction order is fixed)."""
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    monkeypatch.setenv('U3D_RS_H', str(H))
+    monkeypatch.setattr(sparse, '_RS_MIN_ROWS', 1)
+    vb, oc, oshape = _level_geometry(n_points=20_000, vs=0.03)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    n = rb.n_out
+    assert int(rb.halo(64, H)[0].max()) > (256 if H == 256 else 0)           # H = 256: some tile really takes a second pass
+    pairs = so.build_subm_rulebook(oc, oshape)
+    for cin, cout in ((32, 32), (64, 32), (32, 64), (64, 64), (96, 32)):
+        g = torch.Generator().manual_seed(cin * 17 + cout)
+        x, w = torch.randn(n, cin, generator=g), torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1
+        add, go = torch.randn(n, cout, generator=g), torch.randn(n, cout, generator=g)
+        xo = x.double().requires_grad_()
+        yo = so.sparse_conv(xo, w.double(), pairs, n) + add.double()
+        yo.backward(go.double())
+        res = {}
+        for tag, rs in (('rs', True), ('rs2', True), ('pairs', False)):
+            with P.fp32_math('bf16x3'), sparse.conv_rs(rs):
+                xg = x.to(_dev()).requires_grad_()
+                y = sparse.sparse_conv(xg, w.to(_dev()), rb, 'fwd', add.to(_dev()))
+                y.backward(go.to(_dev()))
+                res[tag] = (y.detach(), xg.grad)
+        assert torch.equal(res['rs'][0], res['rs2'][0]) and torch.equal(res['rs'][1], res['rs2'][1]), (cin, cout)
+        assert _rel(res['rs'][0], yo) < 2e-6 and _rel(res['rs'][1], xo.grad) < 2e-6, (cin, cout)
+        assert _rel(res['rs'][0], res['pairs'][0]) < 2e-6 and _rel(res['rs'][1], res['pairs'][1]) < 2e-6, (cin, cout)
+
+
 @pytest.mark.parametrize('operands', ['bf16x3', 'bf16'])
 @pytest.mark.parametrize('tile_rows', [32, 64])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (64, 64), (96, 96), (128, 160), (256, 256)])

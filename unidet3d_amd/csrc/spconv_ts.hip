@@ -351,7 +351,9 @@ __global__ __launch_bounds__(256) void spconv_ts_k(TsParams p) {
                 const int s0 = lcv[rt] - ps * H;
                 const bool ok = (unsigned)s0 < (unsigned)cnt;
                 o.any[rt] = __ballot(ok) != 0ull;
-                if (o.any[rt]) {
+                {   // unconditional (a sub-tile without work reads the zero row): reads inside a branch leave the number of outstanding
+                    // LDS operations unknown at the join and the compiler waits for lgkmcnt(0) -- i.e. for THESE reads -- in front of
+                    // the current offset's MFMAs (seen in spconv_rs_k: 9.5 k -> 8.0 k cycles per tile)
                     const int a0 = ts_slot_off(ok ? s0 : H, q);
 #pragma unroll
                     for (int u = 0; u < CS32; ++u)
@@ -594,32 +596,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a0s[it] = ts_slot_off(ok ? s0 : H, q);
                 amask |= (__ballot(ok) != 0ull ? 1u : 0u) << it;
             }
+            // (the fragment reads are UNCONDITIONAL -- an item without work reads the zero row: a read inside a branch makes the number
+            // of outstanding LDS operations unknown at the join, and the compiler then waits for lgkmcnt(0) in front of every item's
+            // MFMAs, i.e. for the reads of the NEXT item as well: no overlap at all, measured 9.5 k cycles per tile instead of ~5 k)
             ts_bf16x8 xa[3], xb[3];
-            if (amask & 1u) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xa[pl] = *reinterpret_cast<const ts_bf16x8*>(hl + pl * PLANE + a0s[0]);
-            }
+            for (int pl = 0; pl < 3; ++pl) xa[pl] = *reinterpret_cast<const ts_bf16x8*>(hl + pl * PLANE + a0s[0]);
 #pragma unroll
             for (int it = 0; it < 28; ++it) {
                 const int j = it >> 2, rt = it & 3;
                 ts_bf16x8 (&cur)[3] = (it & 1) ? xb : xa;
                 ts_bf16x8 (&nxt)[3] = (it & 1) ? xa : xb;
-                if (it + 1 < 28 && ((amask >> (it + 1)) & 1u)) {
+                if (it + 1 < 28) {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) nxt[pl] = *reinterpret_cast<const ts_bf16x8*>(hl + pl * PLANE + a0s[it + 1]);
                 }
                 if ((amask >> it) & 1u) {
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        f32x4 c = lo[rt][nb];
-                        c = ts_mfma(wf[j][nb][0], cur[2], c);
-                        c = ts_mfma(wf[j][nb][1], cur[1], c);
-                        c = ts_mfma(wf[j][nb][2], cur[0], c);
-                        c = ts_mfma(wf[j][nb][0], cur[1], c);
-                        c = ts_mfma(wf[j][nb][1], cur[0], c);
-                        lo[rt][nb] = c;
-                        hi[rt][nb] = ts_mfma(wf[j][nb][0], cur[0], hi[rt][nb]);
-                    }
+                    // the two column blocks' chains alternate: a dependent MFMA waits for its predecessor (one wave per SIMD: nobody else fills the gap)
+                    f32x4 c0 = lo[rt][0], c1 = lo[rt][1];
+                    c0 = ts_mfma(wf[j][0][0], cur[2], c0); c1 = ts_mfma(wf[j][1][0], cur[2], c1);
+                    hi[rt][0] = ts_mfma(wf[j][0][0], cur[0], hi[rt][0]); hi[rt][1] = ts_mfma(wf[j][1][0], cur[0], hi[rt][1]);
+                    c0 = ts_mfma(wf[j][0][1], cur[1], c0); c1 = ts_mfma(wf[j][1][1], cur[1], c1);
+                    c0 = ts_mfma(wf[j][0][2], cur[0], c0); c1 = ts_mfma(wf[j][1][2], cur[0], c1);
+                    c0 = ts_mfma(wf[j][0][0], cur[1], c0); c1 = ts_mfma(wf[j][1][0], cur[1], c1);
+                    c0 = ts_mfma(wf[j][0][1], cur[0], c0); c1 = ts_mfma(wf[j][1][1], cur[0], c1);
+                    lo[rt][0] = c0; lo[rt][1] = c1;
                 }
             }
             RS_PHASE(4);

@@ -4,11 +4,11 @@
 # (MI355X_MICROARCH.md, HBM section) -> doubled below; WRITE_SIZE is used as reported (uncalibrated).
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${PMC_TAG:-pmc_bench}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line --no-extra-configs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line --no-extra-configs > /dev/null 2>&1
 if [ "${PMC_CFG3:-1}" != "0" ]; then     # the same two passes over the cfg3 command (bf16 operands, 16 scenes): cfg3.roofline.traffic
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f3 -o f -- python $R/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w3 -o w -- python $R/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f3 -o f -- python $R/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line --no-extra-configs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w3 -o w -- python $R/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line --no-extra-configs > /dev/null 2>&1
 fi
 cd $R
 python - "$OUT" <<'PY'
@@ -47,7 +47,7 @@ root = os.environ.get('GRAFT_REPO_ROOT', '.')
 sys.path.insert(0, root)
 import bench
 summ['_meta'] = dict(git_head=bench.git_head(), csrc_sha16=bench.csrc_hashes(),        # every kernel source this pass covers; bench.py refuses the file on a mismatch
-                     command='python bench.py [--dtype bf16 for the cfg3 block] --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line under rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes)',
+                     command='python bench.py [--dtype bf16 for the cfg3 block] --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line --no-extra-configs under rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes)',
                      correction='FETCH_SIZE x 2 (gfx950 wide coalesced streams, MI355X_MICROARCH.md), WRITE_SIZE as reported; KB -> bytes x 1024')
 json.dump(summ, open(f'{out}/summary.json', 'w'), indent=1)
 for k, v in list(summ.items())[:14]: print(k[:70], v if k != 'cfg3' else {kk: vv for kk, vv in v.items() if kk.startswith('_')})

@@ -2,7 +2,7 @@
 # SQ issue/wait breakdown per kernel of the bench step (one PMC pass, kernel-trace only).  usage: tools/pmc_sq.sh [bench args]
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_sq; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/s -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line --no-prefetch "$@" > /dev/null 2> $OUT/err.txt
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/s -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cfg3 --no-mfma-line --no-extra-configs --no-prefetch "$@" > /dev/null 2> $OUT/err.txt
 cd $R
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections

@@ -231,6 +231,10 @@ int u3d_spconv_plan_bf16a(int Cs, int Cd, int K, int64_t n_dst, int* tile_rows, 
  * {256, 320, 416} (tiles with more unique source rows take further passes); pmask is not read.  Same arguments otherwise. */
 int u3d_spconv_rs_x3(const float* src, int64_t n, const void* w_rows_x3, const int32_t* nhalo, const int32_t* halo, const uint16_t* loc,
                      int halo_rows, int flip, int Cs, int Cd, const float* addend, float* dst, int workgroups, double flops_hint, u3d_stream_t stream);
+/* bf16-operand form of u3d_spconv_rs_x3 on bf16 ROWS (the shadows of u3d_spconv_gmm_bf16a; weights from u3d_weight_pack_bf16): one plane,
+ * no split, 56 weight registers per wave -- three workgroups per CU (`workgroups` <= 0: 3 per CU).  halo_rows in {256, 320, 448}. */
+int u3d_spconv_rs_bf16a(const void* src_bf16, int64_t n, const void* w_rows_bf16, const int32_t* nhalo, const int32_t* halo, const uint16_t* loc,
+                        int halo_rows, int flip, int Cs, int Cd, const float* addend, float* dst, int workgroups, double flops_hint, u3d_stream_t stream);
 int u3d_spconv_ts_plan(int Cs, int Cd, int64_t n, int* tile_rows, int* halo_rows);
 int u3d_subm_halo_pmax(int tile_rows, int halo_rows);
 int u3d_subm_halo(const int32_t* coords, int64_t n, const uint64_t* bitmap, const int32_t* word_rank, int64_t hash_slots, int B,

@@ -235,6 +235,37 @@ def test_register_stationary_conv_matches_oracle_and_pair_kernel(H, monkeypatch)
         assert _rel(res['rs'][0], res['pairs'][0]) < 2e-6 and _rel(res['rs'][1], res['pairs'][1]) < 2e-6, (cin, cout)
 
 
+@pytest.mark.parametrize('H', [256, 448])
+def test_register_stationary_bf16_row_conv_matches_the_pair_kernel(H, monkeypatch):
+    """spconv_rsb_k (bf16 operands gathered from bf16 rows, weights in registers, persistent workgroups): the same rounded operands as
+    u3d_spconv_gmm_bf16a, fp32 accumulation in another order -- forward (+ addend) and input gradient within fp32 rounding of that
+    kernel, and equal to the bit between two runs."""
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import sparse
+    monkeypatch.setenv('U3D_RSB_H', str(H))
+    monkeypatch.setattr(sparse, '_RS_MIN_ROWS', 1)
+    vb, oc, oshape = _level_geometry(n_points=20_000, vs=0.03)
+    rb = sparse.build_subm_rulebook(vb.coords, vb.index)
+    n = rb.n_out
+    for cin, cout in ((32, 32), (64, 32), (32, 64), (64, 64)):
+        g = torch.Generator().manual_seed(cin * 19 + cout)
+        x = torch.randn(n, cin, generator=g).to(_dev())
+        w = (torch.randn(cout, 3, 3, 3, cin, generator=g) * 0.1).to(_dev())
+        add, go = torch.randn(n, cout, generator=g).to(_dev()), torch.randn(n, cout, generator=g).to(_dev())
+        res = {}
+        for tag, rs in (('rs', True), ('rs2', True), ('pairs', False)):
+            with P.operands('bf16'), sparse.conv_rs_bf16(rs):
+                xg = x.clone().requires_grad_()
+                sparse.attach_shadow(xg, sparse.to_shadow(xg))
+                gg = go.clone()
+                sparse.attach_shadow(gg, sparse.to_shadow(gg))
+                y = sparse.sparse_conv(xg, w, rb, 'fwd', add)
+                y.backward(gg)
+                res[tag] = (y.detach(), xg.grad)
+        assert torch.equal(res['rs'][0], res['rs2'][0]) and torch.equal(res['rs'][1], res['rs2'][1]), (cin, cout)
+        assert _rel(res['rs'][0], res['pairs'][0]) < 2e-6 and _rel(res['rs'][1], res['pairs'][1]) < 2e-6, (cin, cout)
+
+
 @pytest.mark.parametrize('operands', ['bf16x3', 'bf16'])
 @pytest.mark.parametrize('tile_rows', [32, 64])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (64, 32), (64, 64), (96, 96), (128, 160), (256, 256)])

@@ -54,6 +54,7 @@ PROTOTYPES = {
     'u3d_spconv_gmm_x3': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
     'u3d_weight_pack_x3': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'u3d_spconv_rs_x3': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f64, _vp]),
+    'u3d_spconv_rs_bf16a': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f64, _vp]),
     'u3d_spconv_ts_plan': (_i32, [_i32, _i32, _i64, C.POINTER(_i32), C.POINTER(_i32)]),
     'u3d_subm_halo_pmax': (_i32, [_i32, _i32]),
     'u3d_subm_halo': (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -662,6 +662,141 @@ static int launch_rs(const RsParams& p, int wgs, hipStream_t s) {
     return check_launch("spconv_rs");
 }
 
+// ---- the same, bf16 operands from bf16 ROWS (BASELINE configs[2]; the shadows the batch-norm kernels write, bn.hip store_shadow) ----
+// One plane instead of three: a wave's 6-7 offsets are 56 registers, a halo row is 64 bytes that arrive in MFMA fragment order (no
+// split, no conversion: a 16-byte copy per lane), an item is two MFMAs.  The kernel fits three to four workgroups per CU (the partial
+// tiles of the final reduction reuse the halo image's LDS), so one workgroup's load phase runs under the others' arithmetic -- what
+// the three-plane form cannot do with 168 weight registers per wave.
+struct RsbParams {
+    const void* src;           // bf16 [n][src_ld] in fragment order per 32-channel group
+    const void* w;             // u3d_weight_pack_bf16 layout
+    const int32_t* nhalo;
+    const int32_t* halo;
+    const uint16_t* loc;
+    const float* addend;
+    float* out;
+    int64_t n;
+    int src_ld, src_c0, dst_ld, dst_c0, w_base16, w_k16;
+    int n_tiles, tiles_per_wg, flip;
+};
+
+constexpr int rsb_lds_bytes(int h) {
+    return ((h + 1) * 64 + 27 * RS_T * 2) > 4 * RS_T * 32 * 4 ? ((h + 1) * 64 + 27 * RS_T * 2) : 4 * RS_T * 32 * 4;
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void spconv_rsb_k(RsbParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+    constexpr int T = RS_T, NC = 27 * T, HALO = (H + 1) * 64, LOCB = 27 * T * 2, ROUNDS = H / 64;
+    static_assert(H % 64 == 0, "halo rows per pass");
+    char* const hl = ts_smem;
+    char* const ll = ts_smem + HALO;
+    float* const red = reinterpret_cast<float*>(ts_smem);                        // aliases the halo image and the loc table (barrier in between)
+    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const int t_begin = wg * p.tiles_per_wg, t_end = min(p.n_tiles, t_begin + p.tiles_per_wg);
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(p.src, p.n * p.src_ld * 2);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w);
+    const int ld2 = p.src_ld * 2, c0b = (p.src_c0 >> 5) * 64;
+    const int ch = tid & 3, prow = tid >> 2;                   // load phase: 16-byte chunk of the row's 64, row within a round of 64
+
+    f32x4 wf[7][2];
+    int kks[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int kk = RS_OFFS[wave][j];
+        kks[j] = kk;
+        const int k = kk < 0 ? 0 : (p.flip ? 26 - kk : kk);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wf[j][nb] = bload128(rs_w, (p.w_base16 + k * p.w_k16 + nb * 64 + lane) * 16, 0);
+    }
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int64_t r0 = (int64_t)tile * T;
+        const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(p.halo + (int64_t)tile * NC, (int64_t)NC * 4);
+        const __amdgpu_buffer_rsrc_t rs_l = make_rsrc(p.loc + (int64_t)tile * NC, (int64_t)NC * 2);
+        const int nh = __builtin_amdgcn_readfirstlane(p.nhalo[tile]);
+        const int npass = (nh + H - 1) / H;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[rt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ps = 0; ps < npass; ++ps) {
+            const int cnt = min(H, nh - ps * H);
+            ts_barrier();                                   // the previous tile's sums are out of `red`, the previous pass's reads done
+            if (tid < 4) *reinterpret_cast<f32x4*>(hl + H * 64 + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};      // the zero row (red overwrote it)
+            if (tid < LOCB / 16) *reinterpret_cast<f32x4*>(ll + tid * 16) = bload128(rs_l, tid * 16, 0);
+            int hrow[ROUNDS];
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j) hrow[j] = bload32(rs_h, (ps * H + j * 64 + prow) * 4, 0);
+            f32x4 v[ROUNDS];
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j) {
+                const bool ok = j * 64 + prow < cnt;
+                v[j] = bload128(rs_src, ok ? (int)__umul24(hrow[j], ld2) + c0b + ch * 16 : 0x7ffffff0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j) *reinterpret_cast<f32x4*>(hl + ts_slot_off(j * 64 + prow, ch)) = v[j];
+            ts_barrier();
+            int a0s[28];
+            unsigned amask = 0u;
+#pragma unroll
+            for (int it = 0; it < 28; ++it) {
+                const int kk = kks[it >> 2];
+                const int l = kk < 0 ? 0xFFFF : (int)*reinterpret_cast<const unsigned short*>(ll + kk * (T * 2) + ((it & 3) * 16 + i16) * 2);
+                const int s0 = l - ps * H;
+                const bool ok = (unsigned)s0 < (unsigned)cnt;
+                a0s[it] = ts_slot_off(ok ? s0 : H, q);
+                amask |= (__ballot(ok) != 0ull ? 1u : 0u) << it;
+            }
+            ts_bf16x8 xa, xb;
+            xa = *reinterpret_cast<const ts_bf16x8*>(hl + a0s[0]);
+#pragma unroll
+            for (int it = 0; it < 28; ++it) {
+                const int j = it >> 2, rt = it & 3;
+                ts_bf16x8& cur = (it & 1) ? xb : xa;
+                ts_bf16x8& nxt = (it & 1) ? xa : xb;
+                if (it + 1 < 28) nxt = *reinterpret_cast<const ts_bf16x8*>(hl + a0s[it + 1]);      // unconditional: see spconv_rs_k
+                if ((amask >> it) & 1u) {
+                    acc[rt][0] = ts_mfma(wf[j][0], cur, acc[rt][0]);
+                    acc[rt][1] = ts_mfma(wf[j][1], cur, acc[rt][1]);
+                }
+            }
+        }
+        ts_barrier();                                       // every wave is done with the halo image and the loc table: `red` may overwrite them
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                *reinterpret_cast<f32x4*>(red + ((wave * T + rt * 16 + i16) * 32 + nb * 16 + q * 4)) = acc[rt][nb];
+        ts_barrier();
+        {
+            const int rr = wave * 16 + i16;
+            const int64_t row = r0 + rr;
+            if (row < p.n) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(red + ((0 * T + rr) * 32 + nb * 16 + q * 4));
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + ((w * T + rr) * 32 + nb * 16 + q * 4));
+                    const int64_t o = row * p.dst_ld + p.dst_c0 + nb * 16 + q * 4;
+                    if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + o);
+                    *reinterpret_cast<f32x4*>(p.out + o) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int H>
+static int launch_rsb(const RsbParams& p, int wgs, hipStream_t s) {
+    constexpr int lds = rsb_lds_bytes(H);
+    hipLaunchKernelGGL((spconv_rsb_k<H>), dim3((unsigned)wgs), dim3(256), lds, s, p);
+    return check_launch("spconv_rsb");
+}
+
 // launch plan: rows per tile T and halo rows per pass H by shape (tools/prof_ts.py sweeps; U3D_TS_T / U3D_TS_H override for A/B runs)
 static bool ts_plan(int Cs, int Cd, int64_t n, int* T, int* H) {
     if (Cs % 32 || Cd % 32 || n <= 0) return false;
@@ -787,6 +922,45 @@ int u3d_spconv_rs_x3(const float* src, int64_t n, const void* w_rows_x3, const i
             else if (halo_rows == 320) rc = launch_rs<320>(p, wgs, s);
             else if (halo_rows == 416) rc = launch_rs<416>(p, wgs, s);
             else set_error("spconv_rs: halo_rows %d not in {256, 320, 416}", halo_rows);
+            if (rc != U3D_OK) return rc;
+        }
+    return U3D_OK;
+}
+
+int u3d_spconv_rs_bf16a(const void* src_bf16, int64_t n, const void* w_rows_bf16, const int32_t* nhalo, const int32_t* halo, const uint16_t* loc,
+                        int halo_rows, int flip, int Cs, int Cd, const float* addend, float* dst, int workgroups, double flops_hint, u3d_stream_t stream) {
+    if (!src_bf16 || !w_rows_bf16 || !nhalo || !halo || !loc || !dst || n <= 0) return U3D_EINVAL;
+    if (n >= (1 << 24) || n * Cs * 2 >= 0x7fffffffLL) {
+        set_error("spconv_rs_bf16a: %lld rows x %d channels exceed the kernel's 32-bit addressing", (long long)n, Cs);
+        return U3D_EUNSUPPORTED;
+    }
+    if (Cs % 32 || Cd % 32 || Cs > 256 || Cd > 256) { set_error("spconv_rs_bf16a: Cs=%d Cd=%d must be multiples of 32 up to 256", Cs, Cd); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_CONV_FWD, s, flops_hint);
+    if (workgroups <= 0) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceProp_t pr;
+        workgroups = 3 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256);
+    }
+    RsbParams p;
+    p.src = src_bf16; p.w = w_rows_bf16; p.nhalo = nhalo; p.halo = halo; p.loc = loc; p.out = dst; p.n = n;
+    p.src_ld = Cs; p.dst_ld = Cd; p.flip = flip ? 1 : 0;
+    p.n_tiles = (int)ceil_div(n, RS_T);
+    p.tiles_per_wg = (int)ceil_div(p.n_tiles, workgroups);
+    const int wgs = (int)ceil_div(p.n_tiles, p.tiles_per_wg);
+    const int cs32 = Cs / 32;
+    p.w_k16 = cs32 * 128;
+    for (int ds = 0; ds < Cd / 32; ++ds)
+        for (int ss = 0; ss < cs32; ++ss) {
+            p.src_c0 = ss * 32; p.dst_c0 = ds * 32;
+            p.w_base16 = (ds * 27 * cs32 + ss) * 128;
+            p.addend = ss == 0 ? addend : dst;
+            int rc = U3D_EUNSUPPORTED;
+            if (halo_rows == 256) rc = launch_rsb<256>(p, wgs, s);
+            else if (halo_rows == 320) rc = launch_rsb<320>(p, wgs, s);
+            else if (halo_rows == 448) rc = launch_rsb<448>(p, wgs, s);
+            else set_error("spconv_rs_bf16a: halo_rows %d not in {256, 320, 448}", halo_rows);
             if (rc != U3D_OK) return rc;
         }
     return U3D_OK;

@@ -428,6 +428,25 @@ def conv_rs(on: bool):
         set_conv_rs(prev)
 
 
+# bf16 operands from bf16 rows (BASELINE configs[2]): the one-plane form spconv_rsb_k; U3D_CONV_RS_BF16=1 / set_conv_rs_bf16
+_CONV_RS_BF16 = os.environ.get('U3D_CONV_RS_BF16', '0') == '1'
+
+
+def set_conv_rs_bf16(on: bool) -> bool:
+    global _CONV_RS_BF16
+    prev, _CONV_RS_BF16 = _CONV_RS_BF16, bool(on)
+    return prev
+
+
+@contextlib.contextmanager
+def conv_rs_bf16(on: bool):
+    prev = set_conv_rs_bf16(on)
+    try:
+        yield
+    finally:
+        set_conv_rs_bf16(prev)
+
+
 def _rs_ok(Cs, Cd, n, rb, bf):
     return (_CONV_RS and rb.coords is not None and int(bf) == P.FMT_X3 and Cs % 32 == 0 and Cd % 32 == 0 and n >= _RS_MIN_ROWS
             and (Cs // 32) * (Cd // 32) <= _RS_MAX_BLOCKS)
@@ -453,7 +472,23 @@ def _gmm(src, weight, transposed, rb, gather, scatter, role, n_dst, addend, flop
     dst = torch.empty(n_dst, Cd, dtype=torch.float32, device=src.device)
     ts = _ts_plan(Cs, Cd, n_dst) if (_CONV_TS and n_dst and rb.coords is not None and int(bf) == P.FMT_X3 and Cs % 32 == 0
                                        and not (stats_out is not None and _EPILOGUE_STATS)) else None
-    if n_dst and _rs_ok(Cs, Cd, n_dst, rb, bf) and not (stats_out is not None and _EPILOGUE_STATS):
+    if (n_dst and _CONV_RS_BF16 and src_rows_bf16 is not None and int(bf) == P.FMT_BF16 and rb.coords is not None and Cs % 32 == 0
+            and Cd % 32 == 0 and n_dst >= _RS_MIN_ROWS and (Cs // 32) * (Cd // 32) <= _RS_MAX_BLOCKS):
+        H = int(os.environ.get('U3D_RSB_H', '448'))
+        if _PROFILE_FLOPS:
+            account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)
+        nhalo, halo, loc, _pm = rb.halo(64, H)
+        hit = _PACKED.get((weight.data_ptr(), int(transposed), P.FMT_BF16))
+        if hit is not None and hit[2] == weight._version and hit[1].device == src.device:
+            wp = hit[0]
+        else:
+            wp = torch.empty(_pack_floats(weight.numel(), P.FMT_BF16), dtype=torch.float32, device=src.device)
+            L.call('u3d_weight_pack_bf16', L.ptr(weight), L.ptr(wp), Cd, rb.K, Cs, int(transposed), L.stream())
+        if stats_out is not None:
+            stats_out.clear()
+        L.call('u3d_spconv_rs_bf16a', L.ptr(src_rows_bf16), n_dst, L.ptr(wp), L.ptr(nhalo), L.ptr(halo), L.ptr(loc), H, int(transposed),
+               Cs, Cd, L.ptr(addend), L.ptr(dst), int(os.environ.get('U3D_RS_WGS', '0')), float(flops), L.stream())
+    elif n_dst and _rs_ok(Cs, Cd, n_dst, rb, bf) and not (stats_out is not None and _EPILOGUE_STATS):
         H = int(os.environ.get('U3D_RS_H', '320'))
         if _PROFILE_FLOPS:
             account.add('conv_gmm', flops, 4.0 * (src.shape[0] * Cs + n_dst * Cd) + 8.0 * rb.total_pairs + 4.0 * rb.K * Cs * Cd)

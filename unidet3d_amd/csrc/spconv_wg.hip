@@ -172,23 +172,11 @@ struct GmmWgWave {
 
     // ---- weights of a step: global -> registers -> LDS slot ----
     __device__ __forceinline__ void load_w(int k, f32x4 (&r)[PREF ? NP : 1]) const {
-#ifdef U3D_WG_NOLOADW      // timing ablation: no global weight prefetch at all (WRONG results): what do the loads -- and the vmcnt(0) they cause -- cost?
-        return;
-#endif
         if constexpr (PREF) {
-#ifdef U3D_WG_UNCOND
-            k = k < 32 ? k : 0;          // always issued (see advance()): a step past the end re-reads offset 0's block, never used
-#endif
             const int so = w_soff0 + k * WSLOT;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-#ifdef U3D_WG_UNCOND
-                // (threads past the end of the slot re-read its last piece: no exec-masked branch around a vector-memory instruction)
-                r[i] = bload128(rs_w, ((i + 1) * 256 <= NPIECE || tid + i * 256 < NPIECE) ? tid * 16 + i * 4096 : (NPIECE - 1) * 16, so);
-#else
+            for (int i = 0; i < NP; ++i)
                 if ((i + 1) * 256 <= NPIECE || tid + i * 256 < NPIECE) r[i] = bload128(rs_w, tid * 16 + i * 4096, so);
-#endif
-            }
         }
     }
     __device__ __forceinline__ void write_w(int slot, const f32x4 (&r)[PREF ? NP : 1]) const {
@@ -225,11 +213,7 @@ struct GmmWgWave {
                 load_w(kc, wreg);
                 write_w(0, wreg);
                 const int kn = next_k(kmask, kc);
-#ifdef U3D_WG_UNCOND
-                load_w(kn, wreg);
-#else
                 if (kn < 32) load_w(kn, wreg);
-#endif
             } else {
                 copy_w(kc, 0);
             }
@@ -243,16 +227,6 @@ struct GmmWgWave {
         const int slot = NSLOT == 2 ? ((step + 1) & 1) : 0;
         if constexpr (NSLOT == 1) wg_barrier();             // every wave has read the slot for the last time (and written its rows)
         // two slots: the other slot was last read in step - 1, and every wave has passed the barrier that ended that step
-#ifdef U3D_WG_UNCOND
-        // the SAME number of vector-memory instructions on every path: a load inside a branch leaves the count of outstanding loads
-        // unknown and the compiler waits for vmcnt(0) -- i.e. for this very prefetch -- before the next item's rows are used
-        if constexpr (PREF) {
-            if (kn < 32) write_w(slot, wreg);
-            load_w(kn < 32 ? next_k(kmask, kn) : 32, wreg);
-        } else if (kn < 32) {
-            copy_w(kn, slot);
-        }
-#else
         if (kn < 32) {
             if constexpr (PREF) {
                 write_w(slot, wreg);
@@ -262,7 +236,6 @@ struct GmmWgWave {
                 copy_w(kn, slot);
             }
         }
-#endif
         wg_barrier();                                       // accumulator rows of step kc and the next weights are visible
         kc = kn;
         ++step;

@@ -819,6 +819,13 @@ static bool ts_plan(int Cs, int Cd, int64_t n, int* T, int* H) {
 
 using namespace u3d;
 
+// compute units of the current device (one attribute query, no property struct: this sits on the launch path)
+static int ts_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+}
+
 extern "C" {
 
 int u3d_spconv_ts_plan(int Cs, int Cd, int64_t n, int* tile_rows, int* halo_rows) {
@@ -892,12 +899,7 @@ int u3d_spconv_rs_x3(const float* src, int64_t n, const void* w_rows_x3, const i
     if (Cs % 32 || Cd % 32 || Cs > 256 || Cd > 256) { set_error("spconv_rs: Cs=%d Cd=%d must be multiples of 32 up to 256", Cs, Cd); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_CONV_FWD, s, flops_hint);
-    if (workgroups <= 0) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceProp_t pr;
-        workgroups = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-    }
+    if (workgroups <= 0) workgroups = ts_cu_count();
     RsParams p;
     p.src = src; p.w = w_rows_x3; p.nhalo = nhalo; p.halo = halo; p.loc = loc; p.out = dst; p.n = n;
     p.src_ld = Cs; p.dst_ld = Cd; p.flip = flip ? 1 : 0;
@@ -937,12 +939,7 @@ int u3d_spconv_rs_bf16a(const void* src_bf16, int64_t n, const void* w_rows_bf16
     if (Cs % 32 || Cd % 32 || Cs > 256 || Cd > 256) { set_error("spconv_rs_bf16a: Cs=%d Cd=%d must be multiples of 32 up to 256", Cs, Cd); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(U3D_K_CONV_FWD, s, flops_hint);
-    if (workgroups <= 0) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceProp_t pr;
-        workgroups = 3 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256);
-    }
+    if (workgroups <= 0) workgroups = 3 * ts_cu_count();
     RsbParams p;
     p.src = src_bf16; p.w = w_rows_bf16; p.nhalo = nhalo; p.halo = halo; p.loc = loc; p.out = dst; p.n = n;
     p.src_ld = Cs; p.dst_ld = Cd; p.flip = flip ? 1 : 0;

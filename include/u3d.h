@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 112
+#define U3D_ABI_VERSION 113
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -434,6 +434,27 @@ int u3d_transpose_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_
 int u3d_weight_planes_batch(const void* desc, int n_desc, int64_t total_blocks, u3d_stream_t stream);
 int u3d_gemm_w_planes(const void* w, const void* planes, const void* w2, const void* planes2);
 
+/* ---- K14b: the same Linear layers with bf16 ACTIVATIONS in HBM (csrc/gemm_b16.hip; BASELINE configs[2] -- the reference's `--amp`
+ * autocasts the Linear / MultiheadAttention activations, tools/train.py:86-99 around unidet3d/encoder.py:19-21,55-61,138-163).
+ * `flags` says which tensors ARE bf16 (row-major, 2 bytes an element); everything else is fp32.  Products run on bf16 MFMAs with
+ * fp32 accumulation exactly as under U3D_BF16_OPERANDS (an fp32 operand is rounded to nearest even while it is staged), so a bf16
+ * tensor that holds the RNE rounding of an fp32 one gives bit-identical products. */
+#define U3D_A_BF16 1   /* the first streamed operand (A) */
+#define U3D_B_BF16 2   /* u3d_gemm_tn_b16: the second streamed operand (B) */
+#define U3D_C_BF16 4   /* u3d_gemm_nt_b16: the result C -- and `aux` of epi 3 */
+/* C[M,N] = epi(A[M,K] W[N,K]^T): epi 0: + bias | 1: relu(+ bias) | 3: aux > 0 ? . : 0 (aux [M,N] = the ReLU output, C's dtype) |
+ * 5: + aux (aux and C fp32).  W and bias are fp32.  K % 32 == 0; a bf16 C needs an even N. */
+int u3d_gemm_nt_b16(const void* A, const float* W, const float* bias, int epi, const void* aux, void* C, int flags, int64_t M, int N, int K,
+                    double flops_hint, u3d_stream_t stream);
+/* C[N,K] = A[M,N]^T B[M,K] (fp32), colsum_A (nullable, [N]) = column sums of A; flags: U3D_A_BF16 | U3D_B_BF16.  N (K) % 8 == 0 for a
+ * bf16 A (B), % 4 otherwise.  ws: u3d_gemm_tn_b16_ws_bytes.  Fixed-order reduction over the row splits (deterministic). */
+int u3d_gemm_tn_b16(const void* A, const void* B, float* C, float* colsum_A, int flags, int64_t M, int N, int K, void* ws, double flops_hint,
+                    u3d_stream_t stream);
+int64_t u3d_gemm_tn_b16_ws_bytes(int64_t M, int N, int K);
+/* erf GELU between bf16 tensors (n % 8 == 0): a = gelu(h); dh = da * gelu'(h) */
+int u3d_gelu_fwd_b16(const void* h, void* a, int64_t n, u3d_stream_t stream);
+int u3d_gelu_bwd_b16(const void* da, const void* h, void* dh, int64_t n, u3d_stream_t stream);
+
 /* =====================================================================================
  * K15 LayerNorm of the decoder (unidet3d/encoder.py:21,38-40,61,78-79,140,167) with the preceding residual add fused in.
  *      forward: s = x (+ res), y = (s - mean) * rstd * gamma + beta; sum_out receives s when res != NULL (the tensor
@@ -444,6 +465,12 @@ int u3d_layer_norm_fwd(const float* x, const float* res, const float* gamma, con
                        float* sum_out, float* y, float* stats, u3d_stream_t stream);
 int u3d_layer_norm_bwd(const float* s, const float* dy, const float* gamma, const float* stats, int64_t M, int C, float* dx,
                        float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
+/* the same passes, additionally writing y (dx) rounded to bf16 into y16 (dx16) [M,C] -- the copy the next GEMM streams (K14b);
+ * y16 / dx16 NULL = the calls above */
+int u3d_layer_norm_fwd_b16(const float* x, const float* res, const float* gamma, const float* beta, int64_t M, int C, float eps,
+                           float* sum_out, float* y, void* y16, float* stats, u3d_stream_t stream);
+int u3d_layer_norm_bwd_b16(const float* s, const float* dy, const float* gamma, const float* stats, int64_t M, int C, float* dx, void* dx16,
+                           float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
 int64_t u3d_layer_norm_ws_bytes(int64_t M, int C);
 
 /* ---- inference post-processing of one scene ------------------------------------------------

@@ -428,3 +428,135 @@ def test_eval_mode_forward_with_bf16_rows_equals_the_fp32_row_path():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
     assert out[True][2]['hit'] >= 40 and out[True][2]['miss'] == 0 and out[False][2]['hit'] == 0, out[True][2]
+
+
+# ---------------------------------------------------------------------------- bf16 ACTIVATIONS in HBM (include/u3d.h K14b, dense16.py)
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 768, 256), (16001, 1024, 256), (4097, 256, 1024), (333, 256, 32), (129, 64, 64), (1, 256, 256)])
+@pytest.mark.parametrize('a16', [False, True])
+@pytest.mark.parametrize('c16', [False, True])
+def test_gemm_nt_b16_every_dtype_combination_and_epilogue(M, N, K, a16, c16):
+    """u3d_gemm_nt_b16 against fp64 products of the ROUNDED operands (exact up to fp32 accumulation: 2e-5), bf16 results within one
+    rounding (2^-8 relative per element) of them; bias, ReLU, ReLU-mask and addend epilogues; ragged M (bounds of the last row tile)."""
+    from unidet3d_amd import dense16 as D16
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * 0.1; b = torch.randn(N, generator=g)
+    ad = (_bf(a) if a16 else a).to(DEV)
+    wd, bd = w.to(DEV), b.to(DEV)
+    ref = _rb(a).double() @ _rb(w).double().t()
+    tol = 8e-3 if c16 else 2e-5                      # max-norm relative: a bf16 result carries its own rounding
+    y = D16.gemm_nt(ad, wd, bd, D16.EPI_BIAS, out_bf16=c16)
+    assert y.dtype == (torch.bfloat16 if c16 else torch.float32)
+    assert _rel(y.float(), ref + b.double()) < tol
+    r = D16.gemm_nt(ad, wd, bd, D16.EPI_RELU, out_bf16=c16)
+    assert _rel(r.float(), torch.relu(ref + b.double())) < tol
+    if c16:
+        assert torch.equal(r, torch.relu(y.float()).to(torch.bfloat16))          # same accumulators, same rounding
+    mask = (torch.rand(M, N, generator=g) > 0.5).float()
+    md = (_bf(mask) if c16 else mask).to(DEV)
+    z = D16.gemm_nt(ad, wd, None, D16.EPI_RELU_MASK, aux=md, out_bf16=c16)
+    assert _rel(z.float(), ref * mask.double()) < tol
+    if not c16:
+        add = torch.randn(M, N, generator=g)
+        s = D16.gemm_nt(ad, wd, None, D16.EPI_ADD, aux=add.to(DEV))
+        assert _rel(s, ref + add.double()) < tol
+
+
+@pytest.mark.parametrize('M,N,K', [(12300, 256, 256), (5000, 1024, 256), (4097, 256, 1024), (3000, 20, 256), (2000, 256, 32), (100, 64, 64)])
+@pytest.mark.parametrize('a16', [False, True])
+@pytest.mark.parametrize('b16', [False, True])
+def test_gemm_tn_b16_every_dtype_combination(M, N, K, a16, b16):
+    from unidet3d_amd import dense16 as D16
+    if a16 and N % 8:
+        N = 24
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g); x = torch.randn(M, K, generator=g)
+    dyd = (_bf(dy) if a16 else dy).to(DEV)
+    xd = (_bf(x) if b16 else x).to(DEV)
+    dw, db = D16.gemm_tn(dyd, xd, True)
+    ref = _rb(dy).double().t() @ _rb(x).double()
+    assert _rel(dw, ref) < 2e-5
+    # the column sums come from the values the kernel was handed: the fp32 ones, or the bf16 ones
+    assert _rel(db, (_rb(dy) if a16 else dy).double().sum(0)) < 2e-5
+    dw2, _ = D16.gemm_tn(dyd, xd, False)
+    assert torch.equal(dw, dw2)                      # fixed-order split reduction: run to run equal
+
+
+def test_gelu_b16_passes():
+    from unidet3d_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    h = _bf(torch.randn(5000, 1024, generator=g) * 2).to(DEV)
+    da = _bf(torch.randn(5000, 1024, generator=g)).to(DEV)
+    a = torch.empty_like(h); dh = torch.empty_like(h)
+    L.call('u3d_gelu_fwd_b16', L.ptr(h), L.ptr(a), h.numel(), L.stream())
+    L.call('u3d_gelu_bwd_b16', L.ptr(da), L.ptr(h), L.ptr(dh), h.numel(), L.stream())
+    hd = h.double().cpu().requires_grad_()
+    ao = torch.nn.functional.gelu(hd)
+    ao.backward(da.double().cpu())
+    assert _rel(a.float(), ao) < 4e-3 and _rel(dh.float(), hd.grad) < 4e-3
+    # one rounding of an fp32-accurate value: at most one bf16 ulp from the rounded fp64 result
+    assert float((a.float().cpu() - ao.detach().to(torch.bfloat16).float()).abs().max()) <= float(ao.abs().max()) * 2 ** -7
+
+
+def test_layer_norm_b16_copies_are_the_rounded_outputs():
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import dense16 as D16
+    from unidet3d_amd.dense import layer_norm
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3001, 256, generator=g); r = torch.randn(3001, 256, generator=g)
+    w = torch.rand(256, generator=g) + 0.5; b = torch.randn(256, generator=g); go = torch.randn(3001, 256, generator=g)
+    xd, rd, wd, bd = [t.clone().to(DEV).requires_grad_() for t in (x, r, w, b)]
+    y0 = layer_norm(xd, wd, bd, 1e-5, rd)
+    y0.backward(go.to(DEV))
+    g0 = [t.grad.clone() for t in (xd, rd, wd, bd)]
+    for t in (xd, rd, wd, bd):
+        t.grad = None
+    with P.operands('bf16'), P.bf16_act_mode(True):
+        y1 = layer_norm(xd, wd, bd, 1e-5, rd)
+        c = D16.b16_of(y1)
+        assert c is not None and torch.equal(c, y1.detach().to(torch.bfloat16))
+        seen = {}
+        xd.register_hook(lambda gr: seen.update(dx=(gr, D16.b16_of(gr))))
+        y1.backward(go.to(DEV))
+    assert torch.equal(y0, y1)
+    for a_, b_ in zip(g0, (xd, rd, wd, bd)):
+        assert torch.equal(a_, b_.grad)
+    gr, c = seen['dx']
+    assert c is not None and torch.equal(c, gr.to(torch.bfloat16))
+
+
+def test_decoder_layer_chain_with_bf16_activations_matches_the_fp32_tensor_flow():
+    """LayerNorm -> FFN (GELU) -> LayerNorm -> Linear with precision.bf16_act() on against the same chain with fp32 tensors rounded in
+    flight (U3D_BF16_ACT=0, the round-5 data flow): same products, the only extra roundings are the FFN's hidden tensors."""
+    from unidet3d_amd import precision as P
+    from unidet3d_amd import dense16 as D16
+    from unidet3d_amd.dense import layer_norm, linear, mlp
+    g = torch.Generator().manual_seed(5)
+    M, d, hid = 6001, 256, 1024
+    x = torch.randn(M, d, generator=g)
+    prm = dict(g1=torch.rand(d, generator=g) + 0.5, b1=torch.randn(d, generator=g) * 0.1,
+               w1=torch.randn(hid, d, generator=g) * 0.06, c1=torch.randn(hid, generator=g) * 0.1,
+               w2=torch.randn(d, hid, generator=g) * 0.03, c2=torch.randn(d, generator=g) * 0.1,
+               g2=torch.rand(d, generator=g) + 0.5, b2=torch.randn(d, generator=g) * 0.1,
+               wo=torch.randn(768, d, generator=g) * 0.06, co=torch.randn(768, generator=g) * 0.1)
+    go = torch.randn(M, 768, generator=g)
+
+    def run(act16):
+        xs = x.clone().to(DEV).requires_grad_()
+        p = {k: v.clone().to(DEV).requires_grad_() for k, v in prm.items()}
+        D16.STATS['hit'] = 0
+        with P.operands('bf16'), P.bf16_act_mode(act16):
+            y = layer_norm(xs, p['g1'], p['b1'], 1e-5)
+            z = layer_norm(mlp(y, p['w1'], p['c1'], p['w2'], p['c2'], 'gelu'), p['g2'], p['b2'], 1e-5, y)
+            out = linear(z, p['wo'], p['co'])
+            out.backward(go.to(DEV))
+        return out.detach(), xs.grad, {k: v.grad for k, v in p.items()}, D16.STATS['hit']
+    o0, dx0, g0, _ = run(False)
+    o1, dx1, g1, hits = run(True)
+    assert hits >= 3                                   # y -> FFN and z -> Linear forward; LayerNorm 2's gradient -> FFN backward
+    assert _rel(o1, o0) < 4e-3 and _rel(dx1, dx0) < 1e-2
+    for k in g0:
+        assert _rel(g1[k], g0[k]) < 1e-2, k

@@ -70,6 +70,8 @@ PROTOTYPES = {
     'u3d_layer_norm_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     'u3d_layer_norm_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_layer_norm_ws_bytes': (_i64, [_i64, _i32]),
+    'u3d_layer_norm_fwd_b16': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_layer_norm_bwd_b16': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_nms_bev': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     'u3d_nms_aligned3d': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     'u3d_nms_rotated': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
@@ -104,6 +106,11 @@ PROTOTYPES = {
     'u3d_ffn_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp]),
     'u3d_gelu_fwd': (_i32, [_vp, _vp, _i64, _vp]),
     'u3d_gelu_bwd': (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    'u3d_gemm_nt_b16': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i64, _i32, _i32, _f64, _vp]),
+    'u3d_gemm_tn_b16': (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _f64, _vp]),
+    'u3d_gemm_tn_b16_ws_bytes': (_i64, [_i64, _i32, _i32]),
+    'u3d_gelu_fwd_b16': (_i32, [_vp, _vp, _i64, _vp]),
+    'u3d_gelu_bwd_b16': (_i32, [_vp, _vp, _vp, _i64, _vp]),
     'u3d_gemm_tn': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp]),
     'u3d_gemm_tn_bf16': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp]),
     'u3d_gemm_tn_ws_bytes': (_i64, [_i64, _i32, _i32]),
@@ -117,7 +124,7 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 112         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 113         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

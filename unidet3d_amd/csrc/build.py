@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ['misc.hip', 'voxelize.hip', 'rulebook.hip', 'spconv.hip', 'spconv_wg.hip', 'spconv_ts.hip', 'spconv_wgrad_rows.hip', 'bn.hip', 'pool.hip', 'attn.hip', 'attn_x3.hip', 'gemm.hip', 'norm.hip', 'postproc.hip', 'criterion.hip', 'hashidx.hip', 'radix.hip']
+SOURCES = ['misc.hip', 'voxelize.hip', 'rulebook.hip', 'spconv.hip', 'spconv_wg.hip', 'spconv_ts.hip', 'spconv_wgrad_rows.hip', 'bn.hip', 'pool.hip', 'attn.hip', 'attn_x3.hip', 'gemm.hip', 'gemm_b16.hip', 'norm.hip', 'postproc.hip', 'criterion.hip', 'hashidx.hip', 'radix.hip']
 LIB = os.path.join(HERE, 'libu3d_hip.so')
 # (no -munsafe-fp-atomics: since round 5 no kernel of the library issues a floating-point atomic -- every reduction has a fixed order)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value',

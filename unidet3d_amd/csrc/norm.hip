@@ -9,6 +9,9 @@ namespace u3d {
 
 constexpr int LN_MAXV = 4;       // float4 per lane: C <= 1024
 
+typedef __attribute__((ext_vector_type(2))) __bf16 ln_bf16x2;
+__device__ __forceinline__ unsigned ln_pack_bf16(float lo, float hi) { return __builtin_bit_cast(unsigned, ln_bf16x2{(__bf16)lo, (__bf16)hi}); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -18,7 +21,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int NV>
 __global__ __launch_bounds__(256) void layer_norm_fwd_k(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t M, int C, float eps, float* __restrict__ sum_out,
-                                                        float* __restrict__ y, float* __restrict__ stats) {
+                                                        float* __restrict__ y, float* __restrict__ stats, uint2* __restrict__ y16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_k(const float* __restrict_
             o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
             reinterpret_cast<float4*>(y + row * C)[j] = o;
+            if (y16) y16[row * c4 + j] = make_uint2(ln_pack_bf16(o.x, o.y), ln_pack_bf16(o.z, o.w));      // the copy the next GEMM streams (K14b)
         }
     }
     if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_k(const float* __restrict_
 template <int NV>
 __global__ __launch_bounds__(256) void layer_norm_bwd_k(const float* __restrict__ s, const float* __restrict__ dy, const float* __restrict__ gamma,
                                                         const float* __restrict__ stats, int64_t M, int C, float* __restrict__ dx,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, uint2* __restrict__ dx16) {
     __shared__ float red[4 * 2 * LN_MAXV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = C >> 2;
@@ -100,9 +104,12 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_k(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int j = lane + 64 * i;
-            if (j < c4)
-                reinterpret_cast<float4*>(dx + row * C)[j] = make_float4(rstd * (g[i].x - mg - xh[i].x * mgx), rstd * (g[i].y - mg - xh[i].y * mgx),
-                                                                         rstd * (g[i].z - mg - xh[i].z * mgx), rstd * (g[i].w - mg - xh[i].w * mgx));
+            if (j < c4) {
+                const float4 o = make_float4(rstd * (g[i].x - mg - xh[i].x * mgx), rstd * (g[i].y - mg - xh[i].y * mgx),
+                                             rstd * (g[i].z - mg - xh[i].z * mgx), rstd * (g[i].w - mg - xh[i].w * mgx));
+                reinterpret_cast<float4*>(dx + row * C)[j] = o;
+                if (dx16) dx16[row * c4 + j] = make_uint2(ln_pack_bf16(o.x, o.y), ln_pack_bf16(o.z, o.w));
+            }
         }
     }
     // 4 waves -> one partial per workgroup, fixed order
@@ -173,13 +180,18 @@ int64_t u3d_layer_norm_ws_bytes(int64_t M, int C) { return (int64_t)ln_blocks(M)
 
 int u3d_layer_norm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int64_t M, int C, float eps,
                        float* sum_out, float* y, float* stats, u3d_stream_t stream) {
+    return u3d_layer_norm_fwd_b16(x, res, gamma, beta, M, C, eps, sum_out, y, nullptr, stats, stream);
+}
+
+int u3d_layer_norm_fwd_b16(const float* x, const float* res, const float* gamma, const float* beta, int64_t M, int C, float eps,
+                           float* sum_out, float* y, void* y16, float* stats, u3d_stream_t stream) {
     if (!x || !gamma || !beta || !y || !stats || M < 0 || C <= 0 || (res && !sum_out)) return U3D_EINVAL;
     if (C % 4 || C > 256 * LN_MAXV) { set_error("layer_norm: C=%d unsupported (multiple of 4, <= %d)", C, 256 * LN_MAXV); return U3D_EUNSUPPORTED; }
     if (M == 0) return U3D_OK;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(M, 4));
     const int nv = (int)ceil_div(C / 4, 64);
-#define U3D_LN(NV) hipLaunchKernelGGL(layer_norm_fwd_k<NV>, grid, dim3(256), 0, s, x, res, gamma, beta, M, C, eps, sum_out, y, stats)
+#define U3D_LN(NV) hipLaunchKernelGGL(layer_norm_fwd_k<NV>, grid, dim3(256), 0, s, x, res, gamma, beta, M, C, eps, sum_out, y, stats, (uint2*)y16)
     if (nv == 1) U3D_LN(1); else if (nv == 2) U3D_LN(2); else U3D_LN(4);
 #undef U3D_LN
     return check_launch("layer_norm_fwd");
@@ -187,12 +199,17 @@ int u3d_layer_norm_fwd(const float* x, const float* res, const float* gamma, con
 
 int u3d_layer_norm_bwd(const float* s_in, const float* dy, const float* gamma, const float* stats, int64_t M, int C, float* dx,
                        float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
+    return u3d_layer_norm_bwd_b16(s_in, dy, gamma, stats, M, C, dx, nullptr, dgamma, dbeta, ws, stream);
+}
+
+int u3d_layer_norm_bwd_b16(const float* s_in, const float* dy, const float* gamma, const float* stats, int64_t M, int C, float* dx, void* dx16,
+                           float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
     if (!s_in || !dy || !gamma || !stats || !dx || !dgamma || !dbeta || !ws || M < 0 || C <= 0) return U3D_EINVAL;
     if (C % 4 || C > 256 * LN_MAXV) { set_error("layer_norm: C=%d unsupported (multiple of 4, <= %d)", C, 256 * LN_MAXV); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     const int nb = ln_blocks(M);
     const int nv = (int)ceil_div(C / 4, 64);
-#define U3D_LN(NV) hipLaunchKernelGGL(layer_norm_bwd_k<NV>, dim3(nb), dim3(256), 0, s, s_in, dy, gamma, stats, M, C, dx, (float*)ws)
+#define U3D_LN(NV) hipLaunchKernelGGL(layer_norm_bwd_k<NV>, dim3(nb), dim3(256), 0, s, s_in, dy, gamma, stats, M, C, dx, (float*)ws, (uint2*)dx16)
     if (nv == 1) U3D_LN(1); else if (nv == 2) U3D_LN(2); else U3D_LN(4);
 #undef U3D_LN
     hipLaunchKernelGGL(layer_norm_reduce_k, dim3((unsigned)ceil_div(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb, C, dgamma, dbeta);

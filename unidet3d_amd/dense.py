@@ -271,8 +271,16 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def _act16(x, *reduction_dims):
+    """the bf16-activation data flow of dense16.py applies: precision.bf16_act(), a device tensor, every reduction depth % 32 == 0"""
+    return P.bf16_act() and x.is_cuda and all(d % 32 == 0 for d in reduction_dims)
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     """y = x W^T + b for 2-D x [M, K] (K % 16 == 0)."""
+    if _act16(x, x.shape[1]):
+        from . import dense16
+        return dense16.linear(x, weight, bias)
     return _LinearFn.apply(x, weight, bias)
 
 
@@ -338,6 +346,9 @@ class _MLPFn(torch.autograd.Function):
 
 def mlp(x, w1, b1, w2, b2, act: str) -> torch.Tensor:
     """Linear -> ReLU / GELU -> Linear on 2-D x (d_in, hidden % 16 == 0)."""
+    if _act16(x, x.shape[1], w1.shape[0]):
+        from . import dense16
+        return dense16.mlp(x, w1, b1, w2, b2, {'relu': ACT_RELU, 'gelu': ACT_GELU}[act])
     return _MLPFn.apply(x, w1, b1, w2, b2, {'relu': ACT_RELU, 'gelu': ACT_GELU}[act])
 
 
@@ -380,6 +391,9 @@ class _LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, res: torch.Tensor = None) -> torch.Tensor:
     """LayerNorm(x + res) for 2-D x [M, C] (C % 4 == 0, C <= 1024)."""
+    if _act16(x, x.shape[1]):
+        from . import dense16
+        return dense16.layer_norm(x, weight, bias, eps, res)
     return _LayerNormFn.apply(x, res, weight, bias, eps)
 
 
@@ -444,6 +458,9 @@ class _LNLinearFn(torch.autograd.Function):
 
 def ln_linear(x, gamma, beta, eps, weight, bias):
     """-> (LayerNorm(x), LayerNorm(x) W^T + b) for 2-D x [M, C]."""
+    if _act16(x, x.shape[1]):
+        from . import dense16
+        return dense16.ln_linear(x, gamma, beta, eps, weight, bias)
     return _LNLinearFn.apply(x, gamma, beta, eps, weight, bias)
 
 

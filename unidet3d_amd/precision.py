@@ -129,6 +129,32 @@ def bf16_rows_mode(on: bool):
         set_bf16_rows(prev)
 
 
+# bf16 operands (BASELINE configs[2]), decoder side: the activations between the decoder's Linear layers ARE bf16 tensors in HBM
+# (dense16.py, include/u3d.h K14b) -- what the reference's autocast does to nn.Linear / nn.MultiheadAttention -- instead of fp32
+# tensors rounded in flight.  Off: U3D_BF16_ACT=0 / set_bf16_act(False) (the round-5 data flow).
+_BF16_ACT = os.environ.get('U3D_BF16_ACT', '1') != '0'
+
+
+def set_bf16_act(on: bool) -> bool:
+    global _BF16_ACT
+    prev, _BF16_ACT = _BF16_ACT, bool(on)
+    return prev
+
+
+def bf16_act() -> bool:
+    """True when bf16-operand mode also keeps the decoder's activations in bf16."""
+    return _MODE == 'bf16' and _BF16_ACT
+
+
+@contextlib.contextmanager
+def bf16_act_mode(on: bool):
+    prev = set_bf16_act(on)
+    try:
+        yield
+    finally:
+        set_bf16_act(prev)
+
+
 def conv_format() -> int:
     """Operand format of the sparse-convolution kernels for the current modes: the packed-weight layout and the entry point
     (u3d_spconv_gmm / _bf16 / _x3) go together, so the choice is made here, once per op, and remembered for its backward."""

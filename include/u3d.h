@@ -374,6 +374,15 @@ int u3d_attn_varlen_bwd_bf16(const float* qkv, const float* out, const float* do
                              int B, int max_len, int64_t n_total, int H, int hd, float scale, float* dqkv, float* delta_ws,
                              double flops_hint, u3d_stream_t stream);
 
+/* bf16 TENSORS (K14b, csrc/gemm_b16.hip): qkv [n,3D], out [n,D], dout and dqkv are bf16 in HBM (one plane, no conversion while they
+ * are staged; the score scale is applied to the scores), lse / delta_ws fp32 -- the tensors the reference's autocast hands to and
+ * takes from nn.MultiheadAttention (tools/train.py:86-99). */
+int u3d_attn_varlen_fwd_b16(const void* qkv, const int32_t* cu_seqlens, int B, int max_len, int64_t n_total, int H, int hd,
+                            float scale, void* out, float* lse, double flops_hint, u3d_stream_t stream);
+int u3d_attn_varlen_bwd_b16(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                            int B, int max_len, int64_t n_total, int H, int hd, float scale, void* dqkv, float* delta_ws,
+                            double flops_hint, u3d_stream_t stream);
+
 /* =====================================================================================
  * K14  dense fp32 GEMMs of the decoder's nn.Linear layers (unidet3d/encoder.py:19-21,55-61,138-140,
  *      153-155,163): forward C = A W^T + bias, input-gradient (the same call on the transposed weight),

@@ -560,3 +560,41 @@ def test_decoder_layer_chain_with_bf16_activations_matches_the_fp32_tensor_flow(
     assert _rel(o1, o0) < 4e-3 and _rel(dx1, dx0) < 1e-2
     for k in g0:
         assert _rel(g1[k], g0[k]) < 1e-2, k
+
+
+@pytest.mark.parametrize('lens', [[48, 17], [1, 64, 65, 130], [333], [0, 5, 0, 700], [2100, 1900]])
+def test_attention_on_bf16_tensors(lens):
+    """u3d_attn_varlen_*_b16 (qkv / out / dout / dqkv bf16 in HBM) against fp64 attention of the SAME (bf16-valued) inputs, and against
+    the fp32-tensor bf16-operand kernels on those inputs: the only differences are where the score scale multiplies (the scores
+    instead of q) and the rounding of the results."""
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.encoder import attention_varlen
+    H, hd = 8, 32
+    n = sum(lens)
+    g = torch.Generator().manual_seed(n + 1)
+    qkv = _rb(torch.randn(n, 3 * H * hd, generator=g))
+    go = _rb(torch.randn(n, H * hd, generator=g))
+    ref_in = qkv.clone().double().requires_grad_()
+    outs, o = [], 0
+    for ln in lens:
+        x = ref_in[o:o + ln]; o += ln
+        q, k, v = x.chunk(3, -1)
+        q = q.view(ln, H, hd).transpose(0, 1); k = k.view(ln, H, hd).transpose(0, 1); v = v.view(ln, H, hd).transpose(0, 1)
+        a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), -1)
+        outs.append((a @ v).transpose(0, 1).reshape(ln, H * hd))
+    ref = torch.cat(outs); ref.backward(go.double())
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    xb = qkv.to(torch.bfloat16).to(DEV).requires_grad_()
+    out = attention_varlen(xb, cu, max(lens), H)
+    assert out.dtype == torch.bfloat16
+    out.backward(go.to(torch.bfloat16).to(DEV))
+    assert xb.grad.dtype == torch.bfloat16
+    xf = qkv.clone().to(DEV).requires_grad_()
+    with P.operands('bf16'):
+        outf = attention_varlen(xf, cu, max(lens), H)                    # fp32 tensors, bf16 operands
+        outf.backward(go.to(DEV))
+    e_out, e_grad = _rel(out.float(), ref), _rel(xb.grad.float(), ref_in.grad)
+    print(f'attention b16 lens={lens}: out {e_out:.2e} grad {e_grad:.2e} (fp32-tensor kernels: {_rel(outf, ref):.1e} / {_rel(xf.grad, ref_in.grad):.1e})')
+    assert e_out < 2e-2 and e_grad < 3e-2
+    assert _rel(out.float(), outf) < 1.5e-2 and _rel(xb.grad.float(), xf.grad) < 2e-2
+    assert float((out.double().cpu() - ref).abs().mean() / ref.abs().mean()) < 1e-2

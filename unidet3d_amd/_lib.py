@@ -122,6 +122,8 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_fwd_bf16': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
     'u3d_attn_varlen_bwd_bf16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
+    'u3d_attn_varlen_fwd_b16': (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
+    'u3d_attn_varlen_bwd_b16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
 ABI_VERSION = 113         # include/u3d.h U3D_ABI_VERSION this table was written against

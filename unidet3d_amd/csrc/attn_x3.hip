@@ -123,6 +123,48 @@ __device__ __forceinline__ void store_x3(StageRegs r, float scale, __bf16* nat, 
     }
 }
 
+// bf16 tensors in HBM (IO16; one plane, include/u3d.h u3d_attn_varlen_*_b16): the same staging map with 8-byte loads and no arithmetic --
+// the staged values are the tensor's own, so a scale cannot be folded in here (the kernels apply it to the scores / to dK instead)
+struct StageRegs16 { uint2 a, b; };
+__device__ __forceinline__ StageRegs16 load_x16(const __bf16* __restrict__ base, int ld, int row0, int len, int tid) {
+    const int p = tid >> 3, c = tid & 7;
+    const int r0 = row0 + 2 * p;
+    StageRegs16 r;
+    r.a = make_uint2(0u, 0u);
+    r.b = r.a;
+    if (r0 < len) r.a = *reinterpret_cast<const uint2*>(base + (int64_t)r0 * ld + c * 4);
+    if (r0 + 1 < len) r.b = *reinterpret_cast<const uint2*>(base + (int64_t)(r0 + 1) * ld + c * 4);
+    return r;
+}
+__device__ __forceinline__ void store_x16(StageRegs16 r, __bf16* nat, int tid) {
+    const int p = tid >> 3, c = tid & 7;
+    const int off = (((c >> 1) ^ (p & 3)) * 8) + (c & 1) * 4;
+    *reinterpret_cast<uint2*>(nat + (2 * p) * XLD + off) = r.a;
+    *reinterpret_cast<uint2*>(nat + (2 * p + 1) * XLD + off) = r.b;
+}
+__device__ __forceinline__ void row_frag_x16(const __bf16* ptr, bf16x8 (&out)[1]) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ptr) v = *reinterpret_cast<const u32x4*>(ptr);
+    out[0] = __builtin_bit_cast(bf16x8, v);
+}
+template <bool IO16> struct IoT { typedef float t; typedef StageRegs regs; };
+template <> struct IoT<true> { typedef __bf16 t; typedef StageRegs16 regs; };
+template <bool IO16>
+__device__ __forceinline__ typename IoT<IO16>::regs load_io(const typename IoT<IO16>::t* __restrict__ base, int ld, int row0, int len, int tid) {
+    if constexpr (IO16) return load_x16(base, ld, row0, len, tid);
+    else return load_x3(base, ld, row0, len, tid);
+}
+template <int NP, bool IO16>
+__device__ __forceinline__ void store_io(typename IoT<IO16>::regs r, float scale, __bf16* nat, int tid) {
+    if constexpr (IO16) store_x16(r, nat, tid);
+    else store_x3<NP>(r, scale, nat, tid);
+}
+template <bool IO16>
+__device__ __forceinline__ void put_io(typename IoT<IO16>::t* p, float v) {
+    if constexpr (IO16) *p = (__bf16)v;
+    else *p = v;
+}
+
 // own row -> B operand planes: 8 consecutive dims of row `ptr` (nullptr: zeros), scaled
 template <int NP>
 __device__ __forceinline__ void row_frag_x3(const float* ptr, float scale, bf16x8 (&out)[NP]) {
@@ -174,9 +216,11 @@ __device__ __forceinline__ AttnWorkX attn_decode_x(int H, int B, int n_tiles) { 
     return w;
 }
 
-template <int NP>
-__global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale,
-                                                     float* __restrict__ out, float* __restrict__ lse, int64_t n_total, int B, int n_tiles) {
+template <int NP, bool IO16 = false>
+__global__ __launch_bounds__(256) void attn_fwd_x3_k(const typename IoT<IO16>::t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale,
+                                                     typename IoT<IO16>::t* __restrict__ out, float* __restrict__ lse, int64_t n_total, int B, int n_tiles) {
+    static_assert(!IO16 || NP == 1, "bf16 tensors carry one plane");
+    typedef typename IoT<IO16>::t io_t;
     __shared__ __attribute__((aligned(16))) __bf16 Kn[NP * XN];
     __shared__ __attribute__((aligned(16))) __bf16 Vn[NP * XN];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
@@ -187,21 +231,23 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
     if (q0 >= len) return;
     const int D = H * 32, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const float* base = qkv + (int64_t)start * ld + h * 32;
+    const io_t* base = qkv + (int64_t)start * ld + h * 32;
     const int qrow = q0 + wave * 16 + i16;
-    bf16x8 qf[NP];                                // scores in log2 units: q carries scale * log2(e)
-    row_frag_x3(qrow < len ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
+    bf16x8 qf[NP];                                // scores in log2 units: q carries scale * log2(e) -- or, IO16, the scores are scaled
+    if constexpr (IO16) row_frag_x16(qrow < len ? base + (int64_t)qrow * ld + g * 8 : nullptr, qf);
+    else row_frag_x3(qrow < len ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
+    const float sc_ = IO16 ? scale * X_LOG2E : 1.f;
     float m = -INFINITY, l = 0.f;
     f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // h.h | low-order products
     const int ntiles = (len + 63) >> 6;
-    StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
+    typename IoT<IO16>::regs rk = load_io<IO16>(base + D, ld, 0, len, tid), rv = load_io<IO16>(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        store_x3<NP>(rk, 1.f, Kn, tid);
-        store_x3<NP>(rv, 1.f, Vn, tid);
+        store_io<NP, IO16>(rk, 1.f, Kn, tid);
+        store_io<NP, IO16>(rv, 1.f, Vn, tid);
         if (kt + 1 < ntiles) {
-            rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
-            rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
+            rk = load_io<IO16>(base + D, ld, kt * 64 + 64, len, tid);
+            rv = load_io<IO16>(base + 2 * D, ld, kt * 64 + 64, len, tid);
         }
         __syncthreads();
         float st[4][4];
@@ -213,7 +259,10 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
             mfma_x3_2a(a0, a1, qf, s0, s1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kb][r] = s0[r]; st[kb + 1][r] = s1[r]; }
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (IO16) { st[kb][r] = s0[r] * sc_; st[kb + 1][r] = s1[r] * sc_; }
+                else { st[kb][r] = s0[r]; st[kb + 1][r] = s1[r]; }
+            }
         }
         if (kt == ntiles - 1 && (len & 63)) {          // only the last tile can hold keys past the end (wave-uniform)
 #pragma unroll
@@ -269,12 +318,31 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_k(const float* __restrict__ q
         const int row = q0 + wave * 16 + g * 4 + r;
         if (row < len) {
             const float inv = 1.f / lr;
-            float* op = out + (int64_t)(start + row) * D + h * 32 + i16;
-            op[0] = o[0][r] * inv;
-            op[16] = o[1][r] * inv;
+            io_t* op = out + (int64_t)(start + row) * D + h * 32 + i16;
+            put_io<IO16>(op, o[0][r] * inv);
+            put_io<IO16>(op + 16, o[1][r] * inv);
         }
     }
     if (g == 0 && qrow < len) lse[(int64_t)h * n_total + start + qrow] = m * X_LN2 + __logf(l);      // natural-log units
+}
+
+__global__ __launch_bounds__(256) void attn_delta_x16_k(const __bf16* __restrict__ o, const __bf16* __restrict__ dout, int64_t n, int H, float* delta) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * H) return;
+    const int64_t i = idx / H;
+    const int h = (int)(idx % H);
+    const u32x4* a = reinterpret_cast<const u32x4*>(o + i * H * 32 + h * 32);
+    const u32x4* b = reinterpret_cast<const u32x4*>(dout + i * H * 32 + h * 32);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32x4 x = a[j], y = b[j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            s += __builtin_bit_cast(float, x[c] << 16) * __builtin_bit_cast(float, y[c] << 16) +
+                 __builtin_bit_cast(float, x[c] & 0xffff0000u) * __builtin_bit_cast(float, y[c] & 0xffff0000u);
+    }
+    delta[(int64_t)h * n + i] = s;
 }
 
 __global__ __launch_bounds__(256) void attn_delta_x3_k(const float* __restrict__ o, const float* __restrict__ dout, int64_t n, int H, float* delta) {
@@ -294,10 +362,12 @@ __global__ __launch_bounds__(256) void attn_delta_x3_k(const float* __restrict__
 }
 
 // dQ: one workgroup per 64-query tile, keys streamed.  K is read by rows for S and by columns for dQ += dS . K.
-template <int NP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+template <int NP, bool IO16 = false>
+__global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const typename IoT<IO16>::t* __restrict__ qkv, const typename IoT<IO16>::t* __restrict__ dout, const float* __restrict__ lse,
                                                         const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
-                                                        float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
+                                                        typename IoT<IO16>::t* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
+    static_assert(!IO16 || NP == 1, "bf16 tensors carry one plane");
+    typedef typename IoT<IO16>::t io_t;
     __shared__ __attribute__((aligned(16))) __bf16 Kn[NP * XN];
     __shared__ __attribute__((aligned(16))) __bf16 Vn[NP * XN];
     const AttnWorkX wk_ = attn_decode_x(H, B, n_tiles);
@@ -308,25 +378,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     if (q0 >= len) return;
     const int D = H * 32, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const float* base = qkv + (int64_t)start * ld + h * 32;
+    const io_t* base = qkv + (int64_t)start * ld + h * 32;
     const int qrow = q0 + wave * 16 + i16;
     const bool qok = qrow < len;
     bf16x8 qf[NP], dof[NP];
-    row_frag_x3(qok ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
-    row_frag_x3(qok ? dout + (int64_t)(start + qrow) * D + h * 32 + g * 8 : nullptr, 1.f, dof);
+    if constexpr (IO16) {
+        row_frag_x16(qok ? base + (int64_t)qrow * ld + g * 8 : nullptr, qf);
+        row_frag_x16(qok ? dout + (int64_t)(start + qrow) * D + h * 32 + g * 8 : nullptr, dof);
+    } else {
+        row_frag_x3(qok ? base + (int64_t)qrow * ld + g * 8 : nullptr, scale * X_LOG2E, qf);
+        row_frag_x3(qok ? dout + (int64_t)(start + qrow) * D + h * 32 + g * 8 : nullptr, 1.f, dof);
+    }
+    const float sc_ = IO16 ? scale * X_LOG2E : 1.f;
     // log2 units; rows past the end get +inf so that exp2(s - lse) = 0 masks them without a select per element
     const float lse_q = qok ? lse[(int64_t)h * n_total + start + qrow] * X_LOG2E : INFINITY;
     const float del_q = qok ? delta[(int64_t)h * n_total + start + qrow] : 0.f;
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dql[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int ntiles = (len + 63) >> 6;
-    StageRegs rk = load_x3(base + D, ld, 0, len, tid), rv = load_x3(base + 2 * D, ld, 0, len, tid);
+    typename IoT<IO16>::regs rk = load_io<IO16>(base + D, ld, 0, len, tid), rv = load_io<IO16>(base + 2 * D, ld, 0, len, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        store_x3<NP>(rk, 1.f, Kn, tid);
-        store_x3<NP>(rv, 1.f, Vn, tid);
+        store_io<NP, IO16>(rk, 1.f, Kn, tid);
+        store_io<NP, IO16>(rv, 1.f, Vn, tid);
         if (kt + 1 < ntiles) {
-            rk = load_x3(base + D, ld, kt * 64 + 64, len, tid);
-            rv = load_x3(base + 2 * D, ld, kt * 64 + 64, len, tid);
+            rk = load_io<IO16>(base + D, ld, kt * 64 + 64, len, tid);
+            rv = load_io<IO16>(base + 2 * D, ld, kt * 64 + 64, len, tid);
         }
         __syncthreads();
         const bool last = kt == ntiles - 1 && (len & 63);          // wave-uniform
@@ -340,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
             mfma_x3_2c<NP>(ak, qf, av, dof, s4, dp4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(s4[r] - lse_q);
+                float p = __builtin_amdgcn_exp2f(IO16 ? s4[r] * sc_ - lse_q : s4[r] - lse_q);
                 if (last && kt * 64 + kb * 16 + g * 4 + r >= len) p = 0.f;        // zero-padded keys of the last tile
                 ds[kb][r] = p * (dp4[r] - del_q);
             }
@@ -360,19 +436,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_k(const float* __restrict_
     for (int r = 0; r < 4; ++r) {
         const int row = q0 + wave * 16 + g * 4 + r;
         if (row < len) {
-            float* op = dqkv + (int64_t)(start + row) * ld + h * 32 + i16;
-            op[0] = dq[0][r] * scale;
-            op[16] = dq[1][r] * scale;
+            io_t* op = dqkv + (int64_t)(start + row) * ld + h * 32 + i16;
+            put_io<IO16>(op, dq[0][r] * scale);
+            put_io<IO16>(op + 16, dq[1][r] * scale);
         }
     }
 }
 
 // dK, dV: one workgroup per 64-key tile, queries streamed.  Q and dO are read by rows (S, dP) and by columns (dK, dV).
 // (three workgroups per CU: the compiler settles at 178 VGPRs without the bound and 166, no spills, with it)
-template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 3 ? 3 : 1))) void attn_bwd_dkv_x3_k(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+template <int NP, bool IO16 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 3 ? 3 : 1))) void attn_bwd_dkv_x3_k(const typename IoT<IO16>::t* __restrict__ qkv, const typename IoT<IO16>::t* __restrict__ dout, const float* __restrict__ lse,
                                                          const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale,
-                                                         float* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
+                                                         typename IoT<IO16>::t* __restrict__ dqkv, int64_t n_total, int B, int n_tiles) {
+    static_assert(!IO16 || NP == 1, "bf16 tensors carry one plane");
+    typedef typename IoT<IO16>::t io_t;
     __shared__ __attribute__((aligned(16))) __bf16 Qn[NP * XN];
     __shared__ __attribute__((aligned(16))) __bf16 On[NP * XN];
     __shared__ float lse_s[64], del_s[64];
@@ -384,23 +462,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 3 ? 3
     if (k0 >= len) return;
     const int D = H * 32, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const float* base = qkv + (int64_t)start * ld + h * 32;
-    const float* dobase = dout + (int64_t)start * D + h * 32;
+    const io_t* base = qkv + (int64_t)start * ld + h * 32;
+    const io_t* dobase = dout + (int64_t)start * D + h * 32;
     const int krow = k0 + wave * 16 + i16;
     bf16x8 kf[NP], vf[NP];
-    row_frag_x3(krow < len ? base + (int64_t)krow * ld + D + g * 8 : nullptr, 1.f, kf);
-    row_frag_x3(krow < len ? base + (int64_t)krow * ld + 2 * D + g * 8 : nullptr, 1.f, vf);
+    if constexpr (IO16) {
+        row_frag_x16(krow < len ? base + (int64_t)krow * ld + D + g * 8 : nullptr, kf);
+        row_frag_x16(krow < len ? base + (int64_t)krow * ld + 2 * D + g * 8 : nullptr, vf);
+    } else {
+        row_frag_x3(krow < len ? base + (int64_t)krow * ld + D + g * 8 : nullptr, 1.f, kf);
+        row_frag_x3(krow < len ? base + (int64_t)krow * ld + 2 * D + g * 8 : nullptr, 1.f, vf);
+    }
+    const float sc_ = IO16 ? scale * X_LOG2E : 1.f;
     f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 dkl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dvl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // low-order plane products
     const int ntiles = (len + 63) >> 6;
-    StageRegs rq = load_x3(base, ld, 0, len, tid), ro = load_x3(dobase, D, 0, len, tid);
+    typename IoT<IO16>::regs rq = load_io<IO16>(base, ld, 0, len, tid), ro = load_io<IO16>(dobase, D, 0, len, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
-        store_x3<NP>(rq, scale * X_LOG2E, Qn, tid);        // log2 units; dK is rescaled by ln 2 at the end
-        store_x3<NP>(ro, 1.f, On, tid);
+        store_io<NP, IO16>(rq, scale * X_LOG2E, Qn, tid);  // log2 units; dK is rescaled by ln 2 at the end (IO16: Q as it is, scores scaled, dK by `scale`)
+        store_io<NP, IO16>(ro, 1.f, On, tid);
         if (qt + 1 < ntiles) {
-            rq = load_x3(base, ld, qt * 64 + 64, len, tid);
-            ro = load_x3(dobase, D, qt * 64 + 64, len, tid);
+            rq = load_io<IO16>(base, ld, qt * 64 + 64, len, tid);
+            ro = load_io<IO16>(dobase, D, qt * 64 + 64, len, tid);
         }
         if (tid < 64) {
             const int q = qt * 64 + tid;
@@ -422,7 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 3 ? 3
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = qb * 16 + g * 4 + r;
-                    p[u][r] = __builtin_amdgcn_exp2f(s4[r] - lse_s[qq]);
+                    p[u][r] = __builtin_amdgcn_exp2f(IO16 ? s4[r] * sc_ - lse_s[qq] : s4[r] - lse_s[qq]);
                     ds[u][r] = p[u][r] * (dp4[r] - del_s[qq]);
                 }
             }
@@ -443,11 +527,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 3 ? 3
     for (int r = 0; r < 4; ++r) {
         const int row = k0 + wave * 16 + g * 4 + r;
         if (row < len) {
-            float* op = dqkv + (int64_t)(start + row) * ld + h * 32 + i16;
-            op[D] = dk[0][r] * X_LN2;
-            op[D + 16] = dk[1][r] * X_LN2;
-            op[2 * D] = dv[0][r];
-            op[2 * D + 16] = dv[1][r];
+            io_t* op = dqkv + (int64_t)(start + row) * ld + h * 32 + i16;
+            const float ks = IO16 ? scale : X_LN2;
+            put_io<IO16>(op + D, dk[0][r] * ks);
+            put_io<IO16>(op + D + 16, dk[1][r] * ks);
+            put_io<IO16>(op + 2 * D, dv[0][r]);
+            put_io<IO16>(op + 2 * D + 16, dv[1][r]);
         }
     }
 }
@@ -457,8 +542,9 @@ void attn_fwd_x3_launch(const float* qkv, const int32_t* cu, int B, int max_len,
                         hipStream_t s, int planes) {
     const int n_tiles = (max_len + 63) / 64;
     const unsigned grid = (unsigned)(((H * B + 7) / 8) * 8 * n_tiles);
-    if (planes == 1) hipLaunchKernelGGL(attn_fwd_x3_k<1>, dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
-    else hipLaunchKernelGGL(attn_fwd_x3_k<3>, dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
+    if (planes == 16) hipLaunchKernelGGL((attn_fwd_x3_k<1, true>), dim3(grid), dim3(256), 0, s, (const __bf16*)qkv, cu, H, scale, (__bf16*)out, lse, n_total, B, n_tiles);      // bf16 tensors
+    else if (planes == 1) hipLaunchKernelGGL((attn_fwd_x3_k<1>), dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
+    else hipLaunchKernelGGL((attn_fwd_x3_k<3>), dim3(grid), dim3(256), 0, s, qkv, cu, H, scale, out, lse, n_total, B, n_tiles);
 }
 
 // dQ and dK / dV are independent given delta: with U3D_ATTN_FORK=1 the dQ kernel is forked onto a per-device side stream and joined
@@ -489,7 +575,8 @@ static AttnFork* attn_fork_of_device() {
 
 void attn_bwd_x3_launch(const float* qkv, const float* out, const float* dout, const float* lse, const int32_t* cu, int B, int max_len,
                         int64_t n_total, int H, float scale, float* dqkv, float* delta_ws, hipStream_t s, int planes) {
-    hipLaunchKernelGGL(attn_delta_x3_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, out, dout, n_total, H, delta_ws);
+    if (planes == 16) hipLaunchKernelGGL(attn_delta_x16_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, (const __bf16*)out, (const __bf16*)dout, n_total, H, delta_ws);
+    else hipLaunchKernelGGL(attn_delta_x3_k, dim3((unsigned)ceil_div(n_total * H, 256)), dim3(256), 0, s, out, dout, n_total, H, delta_ws);
     const int n_tiles = (max_len + 63) / 64;
     const dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * n_tiles));
     AttnFork* f = attn_fork_of_device();
@@ -499,12 +586,15 @@ void attn_bwd_x3_launch(const float* qkv, const float* out, const float* dout, c
         hipStreamWaitEvent(f->side, f->fork, 0);
         sq = f->side;
     }
-    if (planes == 1) {
-        hipLaunchKernelGGL(attn_bwd_dq_x3_k<1>, grid, dim3(256), 0, sq, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
-        hipLaunchKernelGGL(attn_bwd_dkv_x3_k<1>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+    if (planes == 16) {
+        hipLaunchKernelGGL((attn_bwd_dq_x3_k<1, true>), grid, dim3(256), 0, sq, (const __bf16*)qkv, (const __bf16*)dout, lse, (const float*)delta_ws, cu, H, scale, (__bf16*)dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL((attn_bwd_dkv_x3_k<1, true>), grid, dim3(256), 0, s, (const __bf16*)qkv, (const __bf16*)dout, lse, (const float*)delta_ws, cu, H, scale, (__bf16*)dqkv, n_total, B, n_tiles);
+    } else if (planes == 1) {
+        hipLaunchKernelGGL((attn_bwd_dq_x3_k<1>), grid, dim3(256), 0, sq, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL((attn_bwd_dkv_x3_k<1>), grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_x3_k<3>, grid, dim3(256), 0, sq, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
-        hipLaunchKernelGGL(attn_bwd_dkv_x3_k<3>, grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL((attn_bwd_dq_x3_k<3>), grid, dim3(256), 0, sq, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
+        hipLaunchKernelGGL((attn_bwd_dkv_x3_k<3>), grid, dim3(256), 0, s, qkv, dout, lse, (const float*)delta_ws, cu, H, scale, dqkv, n_total, B, n_tiles);
     }
     if (f) {
         hipEventRecord(f->join, f->side);
@@ -542,6 +632,31 @@ int u3d_attn_varlen_bwd_bf16(const float* qkv, const float* out, const float* do
     if (max_len <= 0) return U3D_OK;
     attn_bwd_x3_launch(qkv, out, dout, lse, cu_seqlens, B, max_len, n_total, H, scale, dqkv, delta_ws, s, 1);
     return check_launch("attn_bwd_bf16");
+}
+
+// bf16 TENSORS (include/u3d.h K14b): qkv / out / dout / dqkv are bf16 in HBM -- what the reference's autocast hands to and takes from
+// nn.MultiheadAttention (tools/train.py:86-99, unidet3d/encoder.py:19-21); lse / delta, softmax and all accumulators fp32.
+int u3d_attn_varlen_fwd_b16(const void* qkv, const int32_t* cu_seqlens, int B, int max_len, int64_t n_total, int H, int hd,
+                            float scale, void* out, float* lse, double flops_hint, u3d_stream_t stream) {
+    if (!qkv || !cu_seqlens || !out || !lse || B <= 0 || H <= 0 || n_total <= 0) return U3D_EINVAL;
+    if (hd != 32) { set_error("attn: head_dim %d unsupported (32 only)", hd); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_ATTN_FWD, s, flops_hint);
+    if (max_len <= 0) return U3D_OK;
+    attn_fwd_x3_launch((const float*)qkv, cu_seqlens, B, max_len, n_total, H, scale, (float*)out, lse, s, 16);
+    return check_launch("attn_fwd_b16");
+}
+
+int u3d_attn_varlen_bwd_b16(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                            int B, int max_len, int64_t n_total, int H, int hd, float scale, void* dqkv, float* delta_ws,
+                            double flops_hint, u3d_stream_t stream) {
+    if (!qkv || !out || !dout || !lse || !cu_seqlens || !dqkv || !delta_ws || B <= 0 || H <= 0 || n_total <= 0) return U3D_EINVAL;
+    if (hd != 32) { set_error("attn: head_dim %d unsupported (32 only)", hd); return U3D_EUNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(U3D_K_ATTN_BWD, s, flops_hint);
+    if (max_len <= 0) return U3D_OK;
+    attn_bwd_x3_launch((const float*)qkv, (const float*)out, (const float*)dout, lse, cu_seqlens, B, max_len, n_total, H, scale, (float*)dqkv, delta_ws, s, 16);
+    return check_launch("attn_bwd_b16");
 }
 
 }  // extern "C"

@@ -276,11 +276,12 @@ def _act16(x, *reduction_dims):
     return P.bf16_act() and x.is_cuda and all(d % 32 == 0 for d in reduction_dims)
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-    """y = x W^T + b for 2-D x [M, K] (K % 16 == 0)."""
+def linear(x: torch.Tensor, weight: torch.Tensor, bias=None, out_bf16: bool = False) -> torch.Tensor:
+    """y = x W^T + b for 2-D x [M, K] (K % 16 == 0).  ``out_bf16``: under precision.bf16_act() the result is a bf16 tensor (for a
+    consumer that reads one: the attention kernels); ignored otherwise."""
     if _act16(x, x.shape[1]):
         from . import dense16
-        return dense16.linear(x, weight, bias)
+        return dense16.linear(x, weight, bias, out_bf16)
     return _LinearFn.apply(x, weight, bias)
 
 

@@ -10,7 +10,9 @@ operands, ``precision.bf16()``):
   to the layer in front of it;
 * the hidden tensors of an MLP (FFN pre-activation / activation, 1024 wide; ReLU hidden of ``input_proj`` / ``outs_cls``) and their
   gradients exist ONLY in bf16: written by a GEMM epilogue, read by the GELU pass and by the next GEMM;
-* results that feed a LayerNorm, the residual stream, attention or the criterion stay fp32.
+* the packed q / k / v projection, the attention output and their gradients are bf16 tensors as well (the attention kernels read and
+  write them as they are: include/u3d.h u3d_attn_varlen_*_b16);
+* results that feed a LayerNorm, the residual stream or the criterion stay fp32.
 
 Products are the ones ``dense.py`` forms under ``precision.bf16()`` (bf16 operands rounded to nearest even, fp32 accumulation): a
 bf16 copy holds exactly the rounding the fp32-tensor kernels apply in flight.  What differs is where a value is rounded ONCE MORE: the
@@ -138,10 +140,12 @@ def _pad_cols(t, n):
 
 
 class _Linear16Fn(torch.autograd.Function):
-    """y = x W^T + b, fp32 result; x and (in backward) dy are streamed as bf16 whenever a bf16 copy is attached to them."""
+    """y = x W^T + b; x and (in backward) dy are streamed as bf16 whenever they are bf16 tensors or carry a bf16 copy.  The result is
+    fp32, or -- ``out_bf16``: the packed q / k / v projection, whose only consumer is the attention kernel -- a bf16 tensor (its
+    gradient then arrives as one); a bf16 INPUT (the attention output in front of ``out_proj``) gets a bf16 gradient back."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, out_bf16):
         x = x.contiguous()
         xa, _ = _operand(x)
         w = weight.contiguous()
@@ -149,7 +153,8 @@ class _Linear16Fn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.wt = D._wt_of(weight)
-        return gemm_nt(xa, w, bias)
+        ctx.dx_bf16 = x.dtype == torch.bfloat16
+        return gemm_nt(xa, w, bias, out_bf16=bool(out_bf16) and w.shape[0] % 2 == 0)
 
     @staticmethod
     def backward(ctx, dy):
@@ -161,10 +166,10 @@ class _Linear16Fn(torch.autograd.Function):
             dw, db = _weight_grad(da, xa, ctx.has_bias and ctx.needs_input_grad[2], weight, ctx.bias_ref)
         if ctx.needs_input_grad[0]:
             wt, Np = _transposed(weight, ctx.wt)
-            dx = gemm_nt(_pad_cols(da, Np), wt)
+            dx = gemm_nt(_pad_cols(da, Np), wt, out_bf16=ctx.dx_bf16)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(0)
-        return dx, dw, db
+            db = dy.float().sum(0)
+        return dx, dw, db, None
 
 
 class _MLP16Fn(torch.autograd.Function):
@@ -312,8 +317,8 @@ def _ok(*dims):
     return all(d % 32 == 0 for d in dims)
 
 
-def linear(x, weight, bias=None):
-    return _Linear16Fn.apply(x, weight, bias)
+def linear(x, weight, bias=None, out_bf16=False):
+    return _Linear16Fn.apply(x, weight, bias, out_bf16)
 
 
 def mlp(x, w1, b1, w2, b2, act):

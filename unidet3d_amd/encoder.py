@@ -36,15 +36,16 @@ class _AttnFn(torch.autograd.Function):
         n, d3 = qkv.shape
         d = d3 // 3
         hd = d // H
-        out = torch.empty(n, d, dtype=torch.float32, device=qkv.device)
+        b16 = qkv.dtype == torch.bfloat16          # bf16 tensors in and out (precision.bf16_act(): include/u3d.h u3d_attn_varlen_*_b16)
+        out = torch.empty(n, d, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(H, n, dtype=torch.float32, device=qkv.device)
         B = cu_seqlens.numel() - 1
         # algorithmic work (bench accounting): S = Q K^T and O = P V -> 4 n_i^2 d flops per scene; qkv read once, out written once
         flops = 4.0 * sum_sq * d if account.ON and sum_sq else 0.0
         if flops:
-            account.add('attn_fwd', flops, 4.0 * n * (4 * d + H))
+            account.add('attn_fwd', flops, qkv.element_size() * n * 4 * d + 4.0 * n * H)
         ctx.sum_sq = sum_sq
-        ctx.sfx = '_bf16' if P.bf16() else ''
+        ctx.sfx = '_b16' if b16 else ('_bf16' if P.bf16() else '')
         if n:
             L.call('u3d_attn_varlen_fwd' + ctx.sfx, L.ptr(qkv), L.ptr(cu_seqlens), B, max_len, n, H, hd, 1.0 / math.sqrt(hd),
                    L.ptr(out), L.ptr(lse), flops, L.stream())
@@ -64,7 +65,7 @@ class _AttnFn(torch.autograd.Function):
         # five matrix products are needed (S, dP, dV, dK, dQ): 10 n_i^2 d flops; qkv, out, dout read, dqkv written
         flops = 10.0 * ctx.sum_sq * (d3 // 3) if account.ON and ctx.sum_sq else 0.0
         if flops:
-            account.add('attn_bwd', flops, 4.0 * n * (8 * (d3 // 3) + 2 * H))
+            account.add('attn_bwd', flops, qkv.element_size() * n * 8 * (d3 // 3) + 4.0 * n * 2 * H)
         if n:
             L.call('u3d_attn_varlen_bwd' + ctx.sfx, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(cu), cu.numel() - 1,
                    ctx.max_len, n, H, hd, 1.0 / math.sqrt(hd), L.ptr(dqkv), L.ptr(delta), flops, L.stream())
@@ -90,7 +91,7 @@ class _MHA(nn.Module):
         nn.init.zeros_(self.out_proj.bias)
 
     def forward(self, x, cu_seqlens, max_len, sum_sq=0):
-        qkv = linear(x, self.in_proj_weight, self.in_proj_bias)
+        qkv = linear(x, self.in_proj_weight, self.in_proj_bias, out_bf16=True)     # a bf16 tensor under precision.bf16_act(), fp32 otherwise
         o = attention_varlen(qkv, cu_seqlens, max_len, self.num_heads, sum_sq)
         return linear(o, self.out_proj.weight, self.out_proj.bias)
 

@@ -28,7 +28,7 @@ def grp(n):
     if 'spconv_wgrad' in n: return 'u3d conv wgrad'
     if 'attn_' in n: return 'u3d attention'
     if 'bn_' in n: return 'u3d batch norm'
-    if 'gemm_' in n or 'layer_norm' in n or 'transpose_k' in n: return 'u3d dense GEMM / LayerNorm (decoder Linear, 1x1 conv)'
+    if 'gemm_' in n or 'layer_norm' in n or 'transpose_k' in n or 'gelu_' in n: return 'u3d dense GEMM / LayerNorm (decoder Linear, 1x1 conv)'
     if n.startswith('Cijk'): return 'hipBLASLt GEMM (decoder Linear, 1x1 conv)'
     if 'u3d::' in n: return 'u3d voxelise/rulebook/pool/other'
     if 'rocclr' in n: return 'copy/memset'

@@ -66,29 +66,44 @@ __global__ __launch_bounds__(256) void gemm_nt_b16_k(const void* __restrict__ A_
     const int voa = (srow * K + sc8 * 8) * EA, vsa = 64 * K * EA;
     const int vob = (srow * K + sc8 * 8) * 4, vsb = 64 * K * 4;
     f32x4 ra[TA][A16 ? 1 : 2], rb[NB][2];
+    // (steps past the last one are loaded from past the end of the descriptors: zeros, no memory traffic -- and no branch around the
+    // loads: a conditional load makes the compiler copy the loop-carried load registers behind a vmcnt(0), which serialises the loop)
+    const int nk = K / HK;
     auto gload = [&](int kt) {
+        const int so_a = kt < nk ? kt * (HK * EA) : 0x7ffff000, so_b = kt < nk ? kt * (HK * 4) : 0x7ffff000;
 #pragma unroll
         for (int j = 0; j < TA; ++j) {
-            ra[j][0] = bload128(rs_a, voa + j * vsa, kt * (HK * EA));
-            if constexpr (!A16) ra[j][1] = bload128(rs_a, voa + j * vsa + 16, kt * (HK * EA));
+            ra[j][0] = bload128(rs_a, voa + j * vsa, so_a);
+            if constexpr (!A16) ra[j][1] = bload128(rs_a, voa + j * vsa + 16, so_a);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            rb[j][0] = bload128(rs_b, vob + j * vsb, kt * (HK * 4));
-            rb[j][1] = bload128(rs_b, vob + j * vsb + 16, kt * (HK * 4));
+            rb[j][0] = bload128(rs_b, vob + j * vsb, so_b);
+            rb[j][1] = bload128(rs_b, vob + j * vsb + 16, so_b);
         }
     };
     auto cvt8 = [](const f32x4& lo, const f32x4& hi) {
         return bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
     };
-    auto lstore = [&](int buf) {
+    // Loads run TWO k-steps ahead of their use (a workgroup's life is mostly load latency: tools/prof_gemm16.py ablations -- without the
+    // loop's loads 25 instead of 37 us at N, K = 256, 1024, without MFMAs 36): the rows of step kt+1, loaded during step kt-1, move from
+    // the load registers to the staging registers `sa` / `sb` (the fp32 ones are rounded here) after the products of step kt, the loads
+    // of step kt+2 are issued into the freed registers, and the staging registers go to the other LDS buffer before the step's barrier.
+    bf16x8 sa[TA], sb[NB];
+    auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < TA; ++j) {
-            if constexpr (A16) *reinterpret_cast<f32x4*>(&As[buf][(srow + 64 * j) * HL + sc8 * 8]) = ra[j][0];
-            else *reinterpret_cast<bf16x8*>(&As[buf][(srow + 64 * j) * HL + sc8 * 8]) = cvt8(ra[j][0], ra[j][1]);
+            if constexpr (A16) sa[j] = __builtin_bit_cast(bf16x8, ra[j][0]);
+            else sa[j] = cvt8(ra[j][0], ra[j][1]);
         }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<bf16x8*>(&Bs[buf][(srow + 64 * j) * HL + sc8 * 8]) = cvt8(rb[j][0], rb[j][1]);
+        for (int j = 0; j < NB; ++j) sb[j] = cvt8(rb[j][0], rb[j][1]);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < TA; ++j) *reinterpret_cast<bf16x8*>(&As[buf][(srow + 64 * j) * HL + sc8 * 8]) = sa[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<bf16x8*>(&Bs[buf][(srow + 64 * j) * HL + sc8 * 8]) = sb[j];
     };
     f32x16 acc[TA][NB];
 #pragma unroll
@@ -97,13 +112,13 @@ __global__ __launch_bounds__(256) void gemm_nt_b16_k(const void* __restrict__ A_
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int nk = K / HK;
     gload(0);
+    stage();
     lstore(0);
+    gload(1);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk && !(U3D_NT16_ABL & 4)) gload(kt + 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             bf16x8 af[TA], bf[NB];
@@ -119,7 +134,11 @@ __global__ __launch_bounds__(256) void gemm_nt_b16_k(const void* __restrict__ A_
                     else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk && !(U3D_NT16_ABL & 8)) lstore(buf ^ 1);
+        // (the LDS stores come BEFORE the next loads: a bf16 operand's staging registers are its load registers, and while they are
+        // live across the load the compiler gives the load new registers and copies them back behind a vmcnt wait at the loop's end)
+        stage();                                                       // step kt+1 (loaded one step ago; zeros behind the last step)
+        if constexpr (!(U3D_NT16_ABL & 8)) lstore(buf ^ 1);             // every wave left that buffer at the barrier of step kt-1
+        if constexpr (!(U3D_NT16_ABL & 4)) gload(kt + 2);
         __syncthreads();
     }
     // ---- epilogue.  D layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -210,13 +229,18 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
     float cs[A16 ? 8 : 4];
 #pragma unroll
     for (int c = 0; c < (A16 ? 8 : 4); ++c) cs[c] = 0.f;
-    auto gload = [&](int t) {
+    const int nt = (rows + WKH - 1) / WKH;
+    auto gload = [&](int t) {            // trips past the last one: past the end of the descriptors (zeros), no branch around the loads
+        const int so_a = t < nt ? t * (WKH * N * EA) : 0x7ffff000, so_b = t < nt ? t * (WKH * K * EB) : 0x7ffff000;
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) ra[j] = bload128(rs_a, ca ? va + j * (A16 ? 16 : 8) * N * EA : va, t * (WKH * N * EA));
+        for (int j = 0; j < NLA; ++j) ra[j] = bload128(rs_a, ca ? va + j * (A16 ? 16 : 8) * N * EA : va, so_a);
 #pragma unroll
-        for (int j = 0; j < NLB; ++j) rb[j] = bload128(rs_b, cb ? vb + j * (B16 ? 16 : 8) * K * EB : vb, t * (WKH * K * EB));
+        for (int j = 0; j < NLB; ++j) rb[j] = bload128(rs_b, cb ? vb + j * (B16 ? 16 : 8) * K * EB : vb, so_b);
     };
-    auto lstore = [&](int buf) {
+    // staging registers (rounded where the operand is fp32): the loads run two trips ahead of their use, as in gemm_nt_b16_k
+    f32x4 sa16[A16 ? NLA : 1], sb16[B16 ? NLB : 1];
+    bf16x4 sa32[A16 ? 1 : NLA], sb32[B16 ? 1 : NLB];
+    auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < NLA; ++j) {
             if constexpr (A16) {
@@ -226,17 +250,29 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
                     cs[2 * c] += __builtin_bit_cast(float, w[c] << 16);
                     cs[2 * c + 1] += __builtin_bit_cast(float, w[c] & 0xffff0000u);
                 }
-                *reinterpret_cast<f32x4*>(&As[buf][(hrow + 16 * j) * WLH + hc8 * 8]) = ra[j];
+                sa16[j] = ra[j];
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) cs[c] += ra[j][c];
-                *reinterpret_cast<bf16x4*>(&As[buf][(srow + 8 * j) * WLH + sc4 * 4]) = bf16x4{(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
+                sa32[j] = bf16x4{(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
             }
         }
 #pragma unroll
         for (int j = 0; j < NLB; ++j) {
-            if constexpr (B16) *reinterpret_cast<f32x4*>(&Bs[buf][(hrow + 16 * j) * WLH + hc8 * 8]) = rb[j];
-            else *reinterpret_cast<bf16x4*>(&Bs[buf][(srow + 8 * j) * WLH + sc4 * 4]) = bf16x4{(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
+            if constexpr (B16) sb16[j] = rb[j];
+            else sb32[j] = bf16x4{(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLA; ++j) {
+            if constexpr (A16) *reinterpret_cast<f32x4*>(&As[buf][(hrow + 16 * j) * WLH + hc8 * 8]) = sa16[j];
+            else *reinterpret_cast<bf16x4*>(&As[buf][(srow + 8 * j) * WLH + sc4 * 4]) = sa32[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NLB; ++j) {
+            if constexpr (B16) *reinterpret_cast<f32x4*>(&Bs[buf][(hrow + 16 * j) * WLH + hc8 * 8]) = sb16[j];
+            else *reinterpret_cast<bf16x4*>(&Bs[buf][(srow + 8 * j) * WLH + sc4 * 4]) = sb32[j];
         }
     };
     typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -255,15 +291,13 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int nt = (rows + WKH - 1) / WKH;
-    if (nt > 0) {
-        gload(0);
-        lstore(0);
-    }
+    gload(0);
+    stage();
+    lstore(0);
+    gload(1);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r0 = h * 16 + kh * 8;
@@ -278,7 +312,9 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        if (t + 1 < nt) lstore(buf ^ 1);
+        stage();                                           // trip t+1 (loaded one trip ago; zeros behind the last trip)
+        lstore(buf ^ 1);
+        gload(t + 2);
         __syncthreads();
     }
     const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
@@ -407,9 +443,12 @@ static void launch_nt16_types(const void* A, const float* W, const float* bias, 
     }
 }
 
+// row splits: about one workgroup per CU (tools/prof_gemm16.py at M = 24 600, us for 256 | 384 | 512 | 768 workgroups, bf16 operands:
+// N, K = 256, 256: 20.1 | 23.5 | 26.5 | 33.9; 1024, 256: 31.8 | 32.3 | 33.0 | 37.0; 256, 32: 19.4 | 26.6 | 26.4 | 26.0) -- every split
+// writes an [N, K] fp32 block that the reduce reads back
 static int tn16_splits(int64_t M, int N, int K) {
     const int64_t tiles = ceil_div(N, HT) * ceil_div(K, HT);
-    static const int target = [] { const char* e = getenv("U3D_TN16_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    static const int target = [] { const char* e = getenv("U3D_TN16_WGS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
     int64_t s = ceil_div(target, tiles);
     const int64_t max_s = ceil_div(M, 4 * WKH);
     if (s > max_s) s = max_s;

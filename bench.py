@@ -227,6 +227,12 @@ def tree_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def _bf16_act() -> bool:
+    """under bf16 operands the decoder keeps bf16 tensors in HBM (unidet3d_amd.precision.bf16_act's switch)"""
+    from unidet3d_amd import precision as P
+    return bool(P._BF16_ACT)
+
+
 def git_head() -> str:
     """Commit of this tree: `git rev-parse` where .git exists (the build container), else the .git_head file tools/grun.sh writes
     into the snapshot that travels to the GPU box."""
@@ -440,6 +446,9 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
                                 f'{"cfg3" if bf else "cfg2"}: {batch} synthetic ScanNet-shape scenes/GPU x {args.points} pts, '
                                 f'{args.voxel_size} m voxels, unidet3d_1xb8_scannet model, ')
                                + ('bf16 MFMA operands (sparse conv fwd/dgrad/wgrad, Linear fwd/dX/dW, attention), fp32 accumulate/BN/softmax/optimizer; '
+                                  + ('decoder activations (q/k/v, attention output, MLP hidden tensors, their gradients, LayerNorm copies) are bf16 '
+                                     'tensors in HBM, residual stream / LayerNorm / parameters fp32 (the data flow of the reference\'s autocast); '
+                                     if _bf16_act() else 'fp32 tensors rounded in flight (U3D_BF16_ACT=0); ')
                                   if bf else ('fp32 (products from three exact bf16 planes per operand on the bf16 matrix pipe, fp32 accumulation, '
                                               'fp32-level error; --fp32-math mfma = native fp32 MFMAs); ' if x3 else 'fp32 (native fp32 MFMAs); ')) +
                                'step = voxelise+rulebook+fwd+loss+bwd' + ('' if args.no_optimizer else f'+clip+{args.optimizer}')
@@ -448,6 +457,7 @@ def measure(args, dtype: str, batch: int, rank: int, world: int, dev, fp32_math=
                                + ({0: '', 1: "; conv weight gradients on a side stream next to each layer's input gradient",
                                    2: '; weight-gradient kernels (sparse conv + Linear) run as a side-stream chain joined at the end of backward'}[overlap_was]),
                    'front_prefetch': not args.no_prefetch, 'wgrad_overlap': overlap_was, 'fp32_math': ('bf16x3' if x3 else 'mfma') if not bf else None,
+                   'bf16_activations': _bf16_act() if bf else None,
                    'global_batch': batch * world, 'points_per_scene': args.points if wl == 'cfg2' else n_points_total // max(batch, 1),
                    'points_per_gpu': n_points_total,
                    'active_voxels_per_gpu': n_vox, 'parallelism': f'dp{world}', 'loss': loss_val, 'warmup_losses': warm_losses},

@@ -35,7 +35,7 @@ typedef void* u3d_stream_t; /* hipStream_t */
 
 /* Bumped with every change of an entry point's argument list; unidet3d_amd/_lib.py refuses a library whose version differs from
  * the one it was written against (a stale .so would misread shifted arguments instead of failing). */
-#define U3D_ABI_VERSION 113
+#define U3D_ABI_VERSION 114
 int u3d_version(void);
 const char* u3d_last_error(void);
 /* How the fp32 matrix kernels (decoder GEMMs, attention, sparse convolutions without U3D_BF16_OPERANDS) multiply:
@@ -480,6 +480,11 @@ int u3d_layer_norm_fwd_b16(const float* x, const float* res, const float* gamma,
                            float* sum_out, float* y, void* y16, float* stats, u3d_stream_t stream);
 int u3d_layer_norm_bwd_b16(const float* s, const float* dy, const float* gamma, const float* stats, int64_t M, int C, float* dx, void* dx16,
                            float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
+/* the backward pass of a LayerNorm whose RESULT had up to three consumers (the decoder: the next Linear, the residual into the next
+ * LayerNorm, the prediction head -- unidet3d/encoder.py:21,38-40,221-239): the incoming gradient is dy + dy2 + dy3 (dy2 / dy3 nullable),
+ * summed as the rows are read instead of by two elementwise passes in front of this call; otherwise u3d_layer_norm_bwd_b16 */
+int u3d_layer_norm_bwd_sum(const float* s, const float* dy, const float* dy2, const float* dy3, const float* gamma, const float* stats,
+                           int64_t M, int C, float* dx, void* dx16, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream);
 int64_t u3d_layer_norm_ws_bytes(int64_t M, int C);
 
 /* ---- inference post-processing of one scene ------------------------------------------------

@@ -72,6 +72,7 @@ PROTOTYPES = {
     'u3d_layer_norm_ws_bytes': (_i64, [_i64, _i32]),
     'u3d_layer_norm_fwd_b16': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     'u3d_layer_norm_bwd_b16': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'u3d_layer_norm_bwd_sum': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'u3d_nms_bev': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     'u3d_nms_aligned3d': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
     'u3d_nms_rotated': (_i32, [_vp, _vp, _i32, _f32, _vp, _vp]),
@@ -126,7 +127,7 @@ PROTOTYPES = {
     'u3d_attn_varlen_bwd_b16': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _f64, _vp]),
 }
 
-ABI_VERSION = 113         # include/u3d.h U3D_ABI_VERSION this table was written against
+ABI_VERSION = 114         # include/u3d.h U3D_ABI_VERSION this table was written against
 
 K_CONV_FWD, K_CONV_WGRAD, K_BN, K_POOL, K_ATTN_FWD, K_ATTN_BWD, K_RULEBOOK, K_VOXELIZE, K_GEMM = range(9)
 

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_k(const float* __restrict_
 template <int NV>
 __global__ __launch_bounds__(256) void layer_norm_bwd_k(const float* __restrict__ s, const float* __restrict__ dy, const float* __restrict__ gamma,
                                                         const float* __restrict__ stats, int64_t M, int C, float* __restrict__ dx,
-                                                        float* __restrict__ partial, uint2* __restrict__ dx16) {
+                                                        float* __restrict__ partial, uint2* __restrict__ dx16,
+                                                        const float* __restrict__ dy2, const float* __restrict__ dy3) {
     __shared__ float red[4 * 2 * LN_MAXV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = C >> 2;
@@ -91,7 +92,16 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_k(const float* __restrict_
             const int j = lane + 64 * i;
             xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < c4) {
-                const float4 a = reinterpret_cast<const float4*>(s + row * C)[j], d = reinterpret_cast<const float4*>(dy + row * C)[j];
+                const float4 a = reinterpret_cast<const float4*>(s + row * C)[j];
+                float4 d = reinterpret_cast<const float4*>(dy + row * C)[j];
+                if (dy2) {            // the result had more than one consumer: their gradients are summed here, in a fixed order
+                    const float4 e = reinterpret_cast<const float4*>(dy2 + row * C)[j];
+                    d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+                }
+                if (dy3) {
+                    const float4 e = reinterpret_cast<const float4*>(dy3 + row * C)[j];
+                    d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+                }
                 xh[i] = make_float4((a.x - mean) * rstd, (a.y - mean) * rstd, (a.z - mean) * rstd, (a.w - mean) * rstd);
                 g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
                 dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
@@ -204,12 +214,17 @@ int u3d_layer_norm_bwd(const float* s_in, const float* dy, const float* gamma, c
 
 int u3d_layer_norm_bwd_b16(const float* s_in, const float* dy, const float* gamma, const float* stats, int64_t M, int C, float* dx, void* dx16,
                            float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
+    return u3d_layer_norm_bwd_sum(s_in, dy, nullptr, nullptr, gamma, stats, M, C, dx, dx16, dgamma, dbeta, ws, stream);
+}
+
+int u3d_layer_norm_bwd_sum(const float* s_in, const float* dy, const float* dy2, const float* dy3, const float* gamma, const float* stats,
+                           int64_t M, int C, float* dx, void* dx16, float* dgamma, float* dbeta, void* ws, u3d_stream_t stream) {
     if (!s_in || !dy || !gamma || !stats || !dx || !dgamma || !dbeta || !ws || M < 0 || C <= 0) return U3D_EINVAL;
     if (C % 4 || C > 256 * LN_MAXV) { set_error("layer_norm: C=%d unsupported (multiple of 4, <= %d)", C, 256 * LN_MAXV); return U3D_EUNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     const int nb = ln_blocks(M);
     const int nv = (int)ceil_div(C / 4, 64);
-#define U3D_LN(NV) hipLaunchKernelGGL(layer_norm_bwd_k<NV>, dim3(nb), dim3(256), 0, s, s_in, dy, gamma, stats, M, C, dx, (float*)ws, (uint2*)dx16)
+#define U3D_LN(NV) hipLaunchKernelGGL(layer_norm_bwd_k<NV>, dim3(nb), dim3(256), 0, s, s_in, dy, gamma, stats, M, C, dx, (float*)ws, (uint2*)dx16, dy2, dy3)
     if (nv == 1) U3D_LN(1); else if (nv == 2) U3D_LN(2); else U3D_LN(4);
 #undef U3D_LN
     hipLaunchKernelGGL(layer_norm_reduce_k, dim3((unsigned)ceil_div(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb, C, dgamma, dbeta);

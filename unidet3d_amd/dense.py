@@ -353,11 +353,26 @@ def mlp(x, w1, b1, w2, b2, act: str) -> torch.Tensor:
     return _MLPFn.apply(x, w1, b1, w2, b2, {'relu': ACT_RELU, 'gelu': ACT_GELU}[act])
 
 
+def _aliases(y, n_out):
+    """``y`` as ``n_out`` autograd outputs that share its storage: one per consumer, so that their gradients arrive separately at the
+    producing Function's backward -- which sums them while it reads them -- instead of being added by autograd's elementwise kernels"""
+    return y if n_out == 1 else (y,) + tuple(y.view_as(y) for _ in range(n_out - 1))
+
+
+def _grads_in(dys):
+    """the incoming gradients of ``_aliases`` outputs: (first, second or None, third or None) of those that arrived"""
+    g = [d.contiguous() for d in dys if d is not None]
+    if len(g) > 3:
+        raise L.U3DError('layer_norm: at most three consumers of the result are summed in the backward kernel')
+    return g + [None] * (3 - len(g))
+
+
 class _LayerNormFn(torch.autograd.Function):
-    """y = LayerNorm(x + res) over the last dimension (include/u3d.h K15); the gradient of x and res is the same tensor."""
+    """y = LayerNorm(x + res) over the last dimension (include/u3d.h K15); the gradient of x and res is the same tensor.  ``n_out`` > 1:
+    the result is returned that many times (one output per consumer) and the backward kernel sums their gradients (u3d_layer_norm_bwd_sum)."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, eps):
+    def forward(ctx, x, res, weight, bias, eps, n_out=1):
         x = x.contiguous()
         M, C = x.shape
         y = torch.empty_like(x)
@@ -371,31 +386,35 @@ class _LayerNormFn(torch.autograd.Function):
                    L.ptr(s) if res is not None else None, L.ptr(y), L.ptr(stats), L.stream())
         ctx.save_for_backward(s, weight, stats)
         ctx.has_res = res is not None
-        return y
+        ctx.set_materialize_grads(False)
+        return _aliases(y, n_out)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *dys):
         s, weight, stats = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy, dy2, dy3 = _grads_in(dys)
+        if dy is None:
+            return (None,) * 6
         M, C = s.shape
         dx = torch.empty_like(s)
         dg = torch.empty(C, dtype=torch.float32, device=s.device)
         db = torch.empty(C, dtype=torch.float32, device=s.device)
         if M:
             ws = L.scratch(L.lib().u3d_layer_norm_ws_bytes(M, C), s.device)
-            L.call('u3d_layer_norm_bwd', L.ptr(s), L.ptr(dy), L.ptr(weight), L.ptr(stats), M, C, L.ptr(dx), L.ptr(dg), L.ptr(db),
-                   L.ptr(ws), L.stream())
+            L.call('u3d_layer_norm_bwd_sum', L.ptr(s), L.ptr(dy), L.ptr(dy2), L.ptr(dy3), L.ptr(weight), L.ptr(stats), M, C, L.ptr(dx), None,
+                   L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream())
         else:
             dg.zero_(); db.zero_()
-        return dx, (dx if ctx.has_res else None), dg, db, None
+        return dx, (dx if ctx.has_res else None), dg, db, None, None
 
 
-def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, res: torch.Tensor = None) -> torch.Tensor:
-    """LayerNorm(x + res) for 2-D x [M, C] (C % 4 == 0, C <= 1024)."""
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, res: torch.Tensor = None, n_out: int = 1):
+    """LayerNorm(x + res) for 2-D x [M, C] (C % 4 == 0, C <= 1024).  ``n_out`` in (2, 3): a tuple of that many tensors, all THE result
+    (shared storage) -- hand each consumer its own and the backward kernel sums their gradients (no elementwise add passes)."""
     if _act16(x, x.shape[1]):
         from . import dense16
-        return dense16.layer_norm(x, weight, bias, eps, res)
-    return _LayerNormFn.apply(x, res, weight, bias, eps)
+        return dense16.layer_norm(x, weight, bias, eps, res, n_out)
+    return _LayerNormFn.apply(x, res, weight, bias, eps, n_out)
 
 
 class _LNLinearFn(torch.autograd.Function):
@@ -469,5 +488,5 @@ class LayerNorm(torch.nn.LayerNorm):
     """``nn.LayerNorm(d_model)`` of the reference (same parameters / state_dict keys) on the HIP kernels, optionally fused with the
     residual add in front of it."""
 
-    def forward(self, x, res=None):
-        return layer_norm(x, self.weight, self.bias, self.eps, res)
+    def forward(self, x, res=None, n_out=1):
+        return layer_norm(x, self.weight, self.bias, self.eps, res, n_out)

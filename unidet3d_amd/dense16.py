@@ -221,11 +221,11 @@ class _MLP16Fn(torch.autograd.Function):
 
 
 class _LayerNorm16Fn(torch.autograd.Function):
-    """dense._LayerNormFn + the bf16 copies: (y, y16) forward -- y16 is attached to y by ``layer_norm`` below --, dx with its copy
-    attached in backward."""
+    """dense._LayerNormFn + the bf16 copies: (y, ..., y16) forward -- y16 is attached to every y output by ``layer_norm`` below --, dx
+    with its copy attached in backward."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, eps):
+    def forward(ctx, x, res, weight, bias, eps, n_out=1):
         x = x.contiguous()
         M, C = x.shape
         y = torch.empty_like(x)
@@ -241,12 +241,16 @@ class _LayerNorm16Fn(torch.autograd.Function):
         ctx.save_for_backward(s, weight, stats)
         ctx.has_res = res is not None
         ctx.mark_non_differentiable(y16)
-        return y, y16
+        ctx.set_materialize_grads(False)
+        ys = D._aliases(y, n_out)
+        return (ys if n_out > 1 else (ys,)) + (y16,)
 
     @staticmethod
-    def backward(ctx, dy, _unused):
+    def backward(ctx, *dys):
         s, weight, stats = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy, dy2, dy3 = D._grads_in(dys[:-1])
+        if dy is None:
+            return (None,) * 6
         M, C = s.shape
         dx = torch.empty_like(s)
         dx16 = torch.empty(M, C, dtype=torch.bfloat16, device=s.device)
@@ -254,12 +258,12 @@ class _LayerNorm16Fn(torch.autograd.Function):
         db = torch.empty(C, dtype=torch.float32, device=s.device)
         if M:
             ws = L.scratch(L.lib().u3d_layer_norm_ws_bytes(M, C), s.device)
-            L.call('u3d_layer_norm_bwd_b16', L.ptr(s), L.ptr(dy), L.ptr(weight), L.ptr(stats), M, C, L.ptr(dx), L.ptr(dx16), L.ptr(dg),
-                   L.ptr(db), L.ptr(ws), L.stream())
+            L.call('u3d_layer_norm_bwd_sum', L.ptr(s), L.ptr(dy), L.ptr(dy2), L.ptr(dy3), L.ptr(weight), L.ptr(stats), M, C, L.ptr(dx), L.ptr(dx16),
+                   L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream())
         else:
             dg.zero_(); db.zero_()
         attach_b16(dx, dx16)
-        return dx, (dx if ctx.has_res else None), dg, db, None
+        return dx, (dx if ctx.has_res else None), dg, db, None, None
 
 
 class _LNLinear16Fn(torch.autograd.Function):
@@ -325,10 +329,11 @@ def mlp(x, w1, b1, w2, b2, act):
     return _MLP16Fn.apply(x, w1, b1, w2, b2, act)
 
 
-def layer_norm(x, weight, bias, eps, res=None):
-    y, y16 = _LayerNorm16Fn.apply(x, res, weight, bias, eps)
-    attach_b16(y, y16)
-    return y
+def layer_norm(x, weight, bias, eps, res=None, n_out=1):
+    *ys, y16 = _LayerNorm16Fn.apply(x, res, weight, bias, eps, n_out)
+    for y in ys:
+        attach_b16(y, y16)
+    return ys[0] if n_out == 1 else tuple(ys)
 
 
 def ln_linear(x, gamma, beta, eps, weight, bias):

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import itertools
 import math
+import os
 from typing import List
 
 import torch
@@ -27,6 +28,9 @@ from . import account
 from .dense import LayerNorm, linear, ln_linear, mlp
 from .ops import cat_views
 from .registry import MODELS
+
+
+_LN_ALIASES = os.environ.get('U3D_LN_ALIASES', '1') != '0'
 
 
 class _AttnFn(torch.autograd.Function):
@@ -104,8 +108,11 @@ class SelfAttentionLayer(nn.Module):          # encoder.py:8-41
         self.attn = _MHA(d_model, num_heads)
         self.norm = LayerNorm(d_model)
 
-    def forward(self, x, cu_seqlens, max_len, sum_sq=0):
-        return self.norm(self.attn(x, cu_seqlens, max_len, sum_sq), x)   # LayerNorm(attn + x), add fused
+    def forward(self, x, cu_seqlens, max_len, sum_sq=0, res=None, n_out=1):
+        """LayerNorm(attn(x) + res), the add inside the LayerNorm kernel.  ``res``: the residual (default x) -- the encoder hands the
+        attention and the residual their own alias of the previous LayerNorm's result; ``n_out``: how many aliases of THIS result to
+        return (one per consumer: their gradients are summed in the LayerNorm's backward kernel, dense.layer_norm)."""
+        return self.norm(self.attn(x, cu_seqlens, max_len, sum_sq), x if res is None else res, n_out)
 
 
 class FFN(nn.Module):                         # encoder.py:43-80
@@ -116,9 +123,9 @@ class FFN(nn.Module):                         # encoder.py:43-80
         self.norm = LayerNorm(d_model)
         self.act = 'relu' if activation_fn == 'relu' else 'gelu'
 
-    def forward(self, x):
-        # bias + activation in the first GEMM's epilogue, residual add inside the LayerNorm kernel
-        return self.norm(mlp(x, self.net[0].weight, self.net[0].bias, self.net[3].weight, self.net[3].bias, self.act), x)
+    def forward(self, x, res=None, n_out=1):
+        # bias + activation in the first GEMM's epilogue, residual add inside the LayerNorm kernel (``res`` / ``n_out``: SelfAttentionLayer)
+        return self.norm(mlp(x, self.net[0].weight, self.net[0].bias, self.net[3].weight, self.net[3].bias, self.act), x if res is None else res, n_out)
 
 
 class PredBBox(nn.Module):                    # encoder.py:82-111
@@ -268,9 +275,20 @@ class UniDet3DEncoder(nn.Module):
         x0 = cat_views(x)
         feats = mlp(x0, self.input_proj[0].weight, self.input_proj[0].bias, self.input_proj[2].weight, self.input_proj[2].bias, 'relu')
         layer_feats = [feats]
+        # A LayerNorm result with several consumers (the next Linear, the residual into the next LayerNorm, the head below) is handed out
+        # as one alias per consumer: the gradients then reach the LayerNorm's backward kernel separately and are summed there as they are
+        # read -- 16 of autograd's 18 elementwise gradient sums per step (cfg2: 52 MB each) are gone.
+        x_in = r_in = feats
         for i in range(self.num_layers):
-            feats = self.self_attn_layers[i](feats, cu, max_len, sum_sq)
-            feats = self.ffn_layers[i](feats)
+            if not _LN_ALIASES:                  # U3D_LN_ALIASES=0: one tensor per result, autograd sums (A/B runs)
+                feats = self.ffn_layers[i](self.self_attn_layers[i](feats, cu, max_len, sum_sq))
+                layer_feats.append(feats)
+                continue
+            a_in, a_res = self.self_attn_layers[i](x_in, cu, max_len, sum_sq, res=r_in, n_out=2)
+            if i + 1 < self.num_layers:
+                x_in, r_in, feats = self.ffn_layers[i](a_in, res=a_res, n_out=3)
+            else:
+                feats = self.ffn_layers[i](a_in, res=a_res)
             layer_feats.append(feats)
         # The reference applies the shared prediction head after the input projection and after every layer (encoder.py:221-239).
         # The head is row-wise (LayerNorm, Linear, ReLU), so its num_layers + 1 applications on [n, d] are ONE application on the

@@ -308,6 +308,38 @@ def test_layer_norm_fwd_bwd(M, C, with_res):
     assert _rel(wg.grad, wo.grad) < 2e-5 and _rel(bg.grad, bo.grad) < 2e-5
 
 
+@pytest.mark.parametrize('bf16_act', [False, True])
+@pytest.mark.parametrize('n_out,used', [(2, (0, 1)), (3, (0, 1, 2)), (3, (0, 2)), (3, (1,))])
+def test_layer_norm_aliases_sum_their_gradients_in_the_backward_kernel(n_out, used, bf16_act):
+    """dense.layer_norm(..., n_out=k): k autograd outputs sharing the result's storage; the gradients of the consumers that used
+    theirs are summed inside u3d_layer_norm_bwd_sum -- equal to the plain op fed the (fixed-order) sum, with and without the bf16
+    copies of precision.bf16_act()."""
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.dense import layer_norm
+    M, C = 3001, 256
+    g = torch.Generator().manual_seed(n_out * 10 + len(used))
+    x = torch.randn(M, C, generator=g); r = torch.randn(M, C, generator=g); w = torch.randn(C, generator=g); b = torch.randn(C, generator=g)
+    gos = [torch.randn(M, C, generator=g).to(DEV) for _ in range(n_out)]
+    import contextlib
+    ctx = (lambda: P.operands('bf16')) if bf16_act else contextlib.nullcontext
+    leaves = lambda: [t.clone().to(DEV).requires_grad_() for t in (x, r, w, b)]          # noqa: E731
+    xa, ra, wa, ba = leaves()
+    with ctx():
+        ys = layer_norm(xa, wa, ba, 1e-5, ra, n_out)
+        assert len(ys) == n_out and all(y.data_ptr() == ys[0].data_ptr() for y in ys)
+        sum(((ys[i] * gos[i]).sum() for i in used), torch.zeros((), device=DEV)).backward()
+    xb, rb, wb, bb = leaves()
+    total = None
+    for i in used:                                   # the kernel's order: first arrived + second + third
+        total = gos[i] if total is None else total + gos[i]
+    with ctx():
+        y = layer_norm(xb, wb, bb, 1e-5, rb)
+        y.backward(total)
+    assert torch.equal(ys[0], y)
+    for a_, b_ in ((xa, xb), (ra, rb), (wa, wb), (ba, bb)):
+        assert torch.equal(a_.grad, b_.grad)
+
+
 # ---------------------------------------------------------------------------- BASELINE configs[4] shape (single GPU share)
 def test_large_dense_room_forward_backward():
     """One S3DIS-shape room of 1 M points (~355 k voxels at 2 cm, ~11.7 k superpoints -> 3000 queries): the step runs, every

@@ -598,3 +598,69 @@ def test_attention_on_bf16_tensors(lens):
     assert e_out < 2e-2 and e_grad < 3e-2
     assert _rel(out.float(), outf) < 1.5e-2 and _rel(xb.grad.float(), xf.grad) < 2e-2
     assert float((out.double().cpu() - ref).abs().mean() / ref.abs().mean()) < 1e-2
+
+
+def test_decoder_on_bf16_activations_matches_the_reference_golden_at_bf16_tolerance_incl_mixed_batch_and_empty_scene():
+    """The whole UniDet3DEncoder under precision.operands('bf16') with bf16 activations in HBM (dense16.py / DESIGN.md 4.16) against
+    the fixtures generated from the imported reference encoder.py (tests/golden/encoder_golden.npz): single-dataset batch forward +
+    backward, and the joint-dataset batch with a rotated head and an EMPTY scene (zero-row GEMMs / LayerNorms / attention); and
+    against the fp32-tensor data flow of round 5 (U3D_BF16_ACT=0): the two differ only by the extra roundings of section 4.16."""
+    import os
+    from unidet3d_amd import precision as P
+    from unidet3d_amd.encoder import UniDet3DEncoder
+    from _detw import fill_state_dict
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'encoder_golden.npz'))
+    CLASSES = ['cabinet', 'bed', 'chair', 'sofa', 'table', 'door', 'window', 'bookshelf', 'picture', 'counter', 'desk',
+               'curtain', 'refrigerator', 'showercurtrain', 'toilet', 'sink', 'bathtub', 'otherfurniture']
+    CLASSES_B = ['table', 'chair', 'sofa', 'bookcase', 'board']
+    cfg = dict(num_layers=6, datasets_classes=[CLASSES], in_channels=32, d_model=256, num_heads=8, hidden_dim=1024,
+               dropout=0.0, activation_fn='gelu', datasets=['scannet'], angles=[False])
+    m = fill_state_dict(UniDet3DEncoder(**cfg), tag0=100).to(DEV)
+    c = [torch.from_numpy(G[f'A.c{i}']).to(DEV) for i in range(2)]
+
+    def run(act16):
+        m.zero_grad(set_to_none=True)
+        x = [torch.from_numpy(G[f'A.x{i}']).to(DEV).requires_grad_() for i in range(2)]
+        with P.operands('bf16'), P.bf16_act_mode(act16):
+            res = m(x, c, ['scannet', 'scannet'])
+            loss = sum((t ** 2).sum() for t in res['cls_preds']) + sum(t.sum() for t in res['bboxes'])
+            for a in res['aux_outputs']:
+                loss = loss + sum((t * 0.5).sum() for t in a['cls_preds']) + sum((t ** 2).sum() for t in a['bboxes'])
+            loss.backward()
+        return res, [t.grad for t in x], {k: p.grad.clone() for k, p in m.named_parameters()}, float(loss)
+    r1, gx1, gp1, l1 = run(True)
+    r0, gx0, gp0, l0 = run(False)
+    # errors of both data flows against the fp32 reference fixtures (max-norm relative; operands carry 8 mantissa bits either way)
+    e1 = dict(cls=max(_rel(r1['cls_preds'][i], G[f'A.cls{i}']) for i in range(2)), box=max(_rel(r1['bboxes'][i], G[f'A.box{i}']) for i in range(2)),
+              gx=max(_rel(gx1[i], G[f'A.gx{i}']) for i in range(2)), loss=abs(l1 - float(G['A.loss'])) / abs(float(G['A.loss'])))
+    e0 = dict(cls=max(_rel(r0['cls_preds'][i], G[f'A.cls{i}']) for i in range(2)), box=max(_rel(r0['bboxes'][i], G[f'A.box{i}']) for i in range(2)),
+              gx=max(_rel(gx0[i], G[f'A.gx{i}']) for i in range(2)), loss=abs(l0 - float(G['A.loss'])) / abs(float(G['A.loss'])))
+    between = dict(cls=max(_rel(r1['cls_preds'][i], r0['cls_preds'][i]) for i in range(2)), gx=max(_rel(gx1[i], gx0[i]) for i in range(2)),
+                   loss=abs(l1 - l0) / abs(l0), params=max(_rel(gp1[k], gp0[k]) for k in gp0))
+    print('decoder, bf16 activations vs reference fixtures:', {k: f'{v:.1e}' for k, v in e1.items()})
+    print('decoder, fp32 tensors rounded in flight vs reference fixtures:', {k: f'{v:.1e}' for k, v in e0.items()})
+    print('between the two data flows:', {k: f'{v:.1e}' for k, v in between.items()})
+    for i in range(2):
+        assert r1['cls_preds'][i].dtype == torch.float32 and r1['bboxes'][i].dtype == torch.float32      # nothing a caller sees changes dtype
+    # the bf16-tensor flow must stay at the error level of the flow it replaces (both are 8-mantissa-bit arithmetic): <= 1.6 x + 5e-3
+    for k in e1:
+        assert e1[k] <= 1.6 * e0[k] + 5e-3, (k, e1, e0)
+    assert e1['cls'] < 5e-2 and e1['box'] < 5e-2 and e1['gx'] < 1e-1 and e1['loss'] < 2e-2
+    # joint datasets, rotated head, empty scene (forward)
+    cfg = dict(num_layers=2, datasets_classes=[CLASSES, CLASSES_B], in_channels=32, d_model=256, num_heads=8,
+               hidden_dim=1024, dropout=0.0, activation_fn='gelu', datasets=['scannet', 's3dis'], angles=[False, True])
+    mb = fill_state_dict(UniDet3DEncoder(**cfg), tag0=700).to(DEV)
+    xb = [torch.from_numpy(G[f'B.x{i}']).to(DEV) for i in range(3)]
+    cb = [torch.from_numpy(G[f'B.c{i}']).to(DEV) for i in range(3)]
+    assert min(t.shape[0] for t in xb) == 0
+    with torch.no_grad(), P.operands('bf16'):
+        r = mb(xb, cb, ['s3dis', 'scannet', 's3dis'])
+    for i in range(3):
+        assert _rel(r['cls_preds'][i], G[f'B.cls{i}']) < 3e-2 and _rel(r['bboxes'][i], G[f'B.box{i}']) < 3e-2
+    # ... and with gradients through the empty scene
+    xg = [t.clone().requires_grad_() for t in xb]
+    with P.operands('bf16'):
+        r = mb(xg, cb, ['s3dis', 'scannet', 's3dis'])
+        (sum(t.sum() for t in r['cls_preds']) + sum(t.sum() for t in r['bboxes'])).backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in xg)
+    assert all(torch.isfinite(p.grad).all() for p in mb.parameters() if p.grad is not None)

@@ -2,7 +2,7 @@
 
 Runs the cfg2 step under torch.profiler with Python stacks and prints, per aten operator that reaches the GPU, the call sites inside
 unidet3d_amd/ (forward ops) or the autograd node that issued it (backward ops), with launch counts per step.
-usage: python tools/launch_sites.py [scenes] [points]"""
+usage: python tools/launch_sites.py [scenes] [points]      |  python tools/launch_sites.py cfg4   (the joint six-dataset batch of bench.py --config cfg4)"""
 import collections
 import os
 import sys
@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    cfg4 = len(sys.argv) > 1 and sys.argv[1] == 'cfg4'
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and not cfg4 else 8
     pts = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
     import unidet3d_amd  # noqa: F401
     from unidet3d_amd.config import build_model, scannet_model_cfg
@@ -23,11 +24,20 @@ def main():
     from unidet3d_amd.synthetic import make_scene
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    model = build_model(scannet_model_cfg(voxel_size=0.02)).to(dev).train()
+    if cfg4:
+        from bench import CFG4_SCENES
+        from unidet3d_amd.config import joint_model_cfg
+        from unidet3d_amd.data import make_joint_batch
+        model = build_model(joint_model_cfg()).to(dev).train()
+    else:
+        model = build_model(scannet_model_cfg(voxel_size=0.02)).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     bucket = FlatGradBucket(params, attach=False)
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=True)
-    inputs, samples = make_batch_inputs([make_scene(i, n_points=pts) for i in range(B)], dev)
+    if cfg4:
+        _, _, _, inputs, samples = make_joint_batch(joint_model_cfg(), [(n, p, p / 100_000) for n, p in CFG4_SCENES], dev, seed0=200)
+    else:
+        inputs, samples = make_batch_inputs([make_scene(i, n_points=pts) for i in range(B)], dev)
 
     def step():
         bucket.clear_grads()

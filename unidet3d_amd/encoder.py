@@ -14,6 +14,7 @@ one varlen flash kernel (include/u3d.h u3d_attn_varlen_*) that never writes the 
 """
 from __future__ import annotations
 
+import collections.abc
 import itertools
 import math
 import os
@@ -143,6 +144,51 @@ class PredBBox(nn.Module):                    # encoder.py:82-111
         return self.decode(linear(x, self.linear.weight, self.linear.bias))
 
 
+class _LazyColumns(collections.abc.Sequence):
+    """A list of tensors whose entries are made on first access (each a thunk until then); slices and ``list * n`` stay lazy."""
+
+    def __init__(self, thunks):
+        self._t = list(thunks)
+
+    def __len__(self):
+        return len(self._t)
+
+    def _get(self, i):
+        v = self._t[i]
+        if callable(v) and not isinstance(v, torch.Tensor):
+            v = self._t[i] = v()
+        return v
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            out = _LazyColumns([])
+            out._t = _SharedCells(self, range(len(self._t))[i])
+            return out
+        return self._get(range(len(self._t))[i])
+
+    def __iter__(self):
+        return (self._get(i) for i in range(len(self._t)))
+
+
+class _SharedCells:
+    """index view into a parent _LazyColumns: a slice evaluates (and caches) the parent's entries"""
+
+    def __init__(self, parent, idx):
+        self.parent, self.idx = parent, list(idx)
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, i):
+        return self.parent._get(self.idx[i])
+
+    def __setitem__(self, i, v):
+        pass            # the parent caches
+
+    def __iter__(self):
+        return (self.parent._get(j) for j in self.idx)
+
+
 class _BoxDecodeFn(torch.autograd.Function):
     """PredBBox's exp + _bbox_pred_to_bbox for a yaw-free head as one kernel each way (include/u3d.h u3d_box_decode_*)."""
 
@@ -254,9 +300,13 @@ class UniDet3DEncoder(nn.Module):
             box_p = _BoxDecode7Fn.apply(box_raw, centers_packed, yaw_rows)          # [M, 7] for the criterion kernel
         else:
             box_p = _BoxDecodeFn.apply(box_raw, centers_packed)                     # [M, 6]
-        cls_preds, boxes = [], []
-        for c, pb, raw, idx in zip(cls_all.split(sizes), box_p.split(sizes), box_raw.split(sizes), idxs):
-            cls_preds.append(c[:, self._cidx(idx, feats.device)])
+        # The per-scene class-column selection (encoder.py:192-194) is an index launch per scene and head application -- 56 per step of
+        # the joint config -- whose results the batched criterion never reads (it takes cls_all and the column lists): the list
+        # computes an entry when somebody asks for it (predict, the per-scene criterion path, tests).
+        cls_rows = cls_all.split(sizes)
+        cls_preds = _LazyColumns([(lambda c=c, idx=idx: c[:, self._cidx(idx, feats.device)]) for c, idx in zip(cls_rows, idxs)])
+        boxes = []
+        for pb, raw, idx in zip(box_p.split(sizes), box_raw.split(sizes), idxs):
             if raw.shape[0] == 0:       # the reference returns an EMPTY scene's 8 (or 6) raw columns undecoded (encoder.py:253-254)
                 boxes.append(raw if self.angles[idx] else raw[:, :6])
             else:

@@ -41,16 +41,16 @@ class DepthInstance3DBoxes:
     def cache_gt_rows(self):
         """(gravity centre, size[, heading]) rows -- what the criterion packs per scene (criterion._gt_boxes) -- computed once for
         all boxes; row slices of this object (``__getitem__`` with a slice) carry the matching row views."""
+        self.gt_rows = None
         self.gt_rows = torch.cat((self.gravity_center, self.tensor[:, 3:] if self.with_yaw else self.tensor[:, 3:6]), dim=1)
         return self.gt_rows
 
     @property
     def gravity_center(self):
-        bottom = self.tensor[:, :3]
-        out = torch.zeros_like(bottom)
-        out[:, :2] = bottom[:, :2]
-        out[:, 2] = bottom[:, 2] + self.tensor[:, 5] * 0.5
-        return out
+        if self.gt_rows is not None and self.gt_rows.shape[0] == self.tensor.shape[0]:
+            return self.gt_rows[:, :3]                     # computed once (cache_gt_rows): the same values
+        # (x, y, z_bottom + h / 2): three launches (mul, add, cat) instead of the five of zeros_like + two slice assignments
+        return torch.cat((self.tensor[:, :2], self.tensor[:, 2:3] + self.tensor[:, 5:6] * 0.5), dim=1)
 
     def __len__(self):
         return self.tensor.shape[0]

@@ -267,6 +267,7 @@ class UniDet3D(nn.Module):
                 inst.bboxes_3d = DepthInstance3DBoxes(torch.cat((center, b.tensor[:, 3:]), dim=1), with_yaw=b.with_yaw,
                                                       box_dim=b.tensor.shape[1], origin=(0.5, 0.5, 0.5))
                 inst.bboxes_3d._u3d_unshifted = b
+                inst.bboxes_3d.cache_gt_rows()             # (gravity centre, size[, heading]): read by get_targets below and by the criterion
             inst.sp_centers = sp_centers[i]
             if self.target_by_distance[dataset]:
                 inst.sp_masks = self.get_targets(inst.sp_centers, inst.bboxes_3d, self.train_cfg['topk'])

@@ -115,3 +115,38 @@ def test_gpu_files_are_collected_parity_first_infrastructure_last():
     order = [os.path.basename(i.fspath) for i in sorted((It(f) for f in files), key=conftest._file_rank)]
     assert order == ['test_gpu_kernels.py', 'test_gpu_model.py', 'test_gpu_ref_golden.py', 'test_gpu_full_size.py', 'test_gpu_gradients.py',
                      'test_gpu_postproc.py', 'test_gpu_eval.py', 'test_cabi.py', 'test_gpu_bf16.py', 'test_gpu_dist.py']
+
+
+def test_lazy_columns_compute_each_entry_once_and_slices_share_the_cache():
+    """encoder._LazyColumns (the per-scene class-column selection of a mixed batch): nothing is computed until an entry is read, every
+    entry is computed once, slices / negative indices / iteration / zip behave like a list's."""
+    from unidet3d_amd.encoder import _LazyColumns
+    calls = []
+    cols = _LazyColumns([(lambda i=i: (calls.append(i), torch.tensor([i]))[1]) for i in range(6)])
+    part = cols[2:4]
+    assert len(cols) == 6 and len(part) == 2 and calls == []
+    assert int(part[0]) == 2 and calls == [2]
+    assert [int(t) for t in part] == [2, 3] and calls == [2, 3]
+    assert int(cols[2]) == 2 and calls == [2, 3]                      # the slice filled the parent's cache
+    assert [int(t) for t in cols] == list(range(6)) and calls == [2, 3, 0, 1, 4, 5]
+    assert int(cols[-1]) == 5 and [int(t) for t in cols[4:][::-1]] == [5, 4]
+    assert [(a, int(t)) for a, t in zip('ab', part)] == [('a', 2), ('b', 3)]
+
+
+def test_gravity_center_forms_agree_bit_for_bit():
+    """DepthInstance3DBoxes.gravity_center: the three-launch form, the cached GT rows and the reference's z + h / 2 give the same bits;
+    row slices carry the matching cached rows."""
+    from unidet3d_amd.structures import DepthInstance3DBoxes
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn(13, 7, generator=g)
+    t[:, 3:6] = t[:, 3:6].abs() + 0.1
+    b = DepthInstance3DBoxes(t, with_yaw=True, box_dim=7, origin=(0.5, 0.5, 0.5))
+    want = b.tensor[:, :3].clone()
+    want[:, 2] = b.tensor[:, 2] + b.tensor[:, 5] * 0.5
+    assert torch.equal(b.gravity_center, want)
+    rows = b.cache_gt_rows()
+    assert rows.shape == (13, 7) and torch.equal(rows[:, :3], want) and torch.equal(rows[:, 3:], b.tensor[:, 3:])
+    assert torch.equal(b.gravity_center, want)                         # now served from the cache
+    part = b[3:9]
+    assert torch.equal(part.gravity_center, want[3:9]) and torch.equal(part.gt_rows, rows[3:9])
+    assert b[torch.tensor([1, 5])].gt_rows is None and torch.equal(b[torch.tensor([1, 5])].gravity_center, want[[1, 5]])

@@ -145,48 +145,24 @@ class PredBBox(nn.Module):                    # encoder.py:82-111
 
 
 class _LazyColumns(collections.abc.Sequence):
-    """A list of tensors whose entries are made on first access (each a thunk until then); slices and ``list * n`` stay lazy."""
+    """A read-only list of tensors whose entries are computed on first access: ``thunks[i]()`` makes entry i, once.  Slices are views
+    onto the same thunks and the same cache, so ``cols[a:b]`` costs nothing until somebody reads an entry."""
 
-    def __init__(self, thunks):
-        self._t = list(thunks)
+    def __init__(self, thunks, _cache=None, _idx=None):
+        self._thunks = thunks
+        self._cache = [None] * len(thunks) if _cache is None else _cache
+        self._idx = list(range(len(thunks))) if _idx is None else _idx
 
     def __len__(self):
-        return len(self._t)
-
-    def _get(self, i):
-        v = self._t[i]
-        if callable(v) and not isinstance(v, torch.Tensor):
-            v = self._t[i] = v()
-        return v
+        return len(self._idx)
 
     def __getitem__(self, i):
         if isinstance(i, slice):
-            out = _LazyColumns([])
-            out._t = _SharedCells(self, range(len(self._t))[i])
-            return out
-        return self._get(range(len(self._t))[i])
-
-    def __iter__(self):
-        return (self._get(i) for i in range(len(self._t)))
-
-
-class _SharedCells:
-    """index view into a parent _LazyColumns: a slice evaluates (and caches) the parent's entries"""
-
-    def __init__(self, parent, idx):
-        self.parent, self.idx = parent, list(idx)
-
-    def __len__(self):
-        return len(self.idx)
-
-    def __getitem__(self, i):
-        return self.parent._get(self.idx[i])
-
-    def __setitem__(self, i, v):
-        pass            # the parent caches
-
-    def __iter__(self):
-        return (self.parent._get(j) for j in self.idx)
+            return _LazyColumns(self._thunks, self._cache, self._idx[i])
+        j = self._idx[i]
+        if self._cache[j] is None:
+            self._cache[j] = self._thunks[j]()
+        return self._cache[j]
 
 
 class _BoxDecodeFn(torch.autograd.Function):

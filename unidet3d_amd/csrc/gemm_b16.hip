@@ -203,15 +203,22 @@ constexpr int WLH = HT + 32;         // padded LDS row (halves): the four rows a
 
 template <bool A16, bool B16>
 __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_, const void* __restrict__ B_, float* __restrict__ partial,
-                                                     int colsum, int64_t M, int N, int K, int64_t rows_per_split) {
+                                                     int colsum, int64_t M, int N, int K, int64_t rows_per_split, int S) {
     __shared__ __attribute__((aligned(16))) __bf16 As[2][WKH * WLH];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][WKH * WLH];
     __shared__ float csum_s[16][HT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, i32 = lane & 31, kh = lane >> 5;
-    const int n0 = blockIdx.x * HT, k0 = blockIdx.y * HT;
-    const int64_t mlo = (int64_t)blockIdx.z * rows_per_split;
+    // 1-D grid, XCD-aware (gemm.hip gemm_tn_k): workgroup b runs on XCD b % 8, so the tiles of ONE row split are made neighbours on
+    // one XCD -- its rows of A and B come from HBM once and from that XCD's L2 for the other tiles.  (The 3-D grid of the first version
+    // spread a split's 16 tiles over all eight L2s: PMC 175 MB fetched per launch for 63 MB of bf16 operands.)
+    const int tiles_n = (N + HT - 1) / HT, tiles = tiles_n * ((K + HT - 1) / HT);
+    const int slot = blockIdx.x >> 3, tile = slot % tiles;
+    const int split = (slot / tiles) * 8 + (blockIdx.x & 7);
+    if (split >= S) return;
+    const int n0 = (tile % tiles_n) * HT, k0 = (tile / tiles_n) * HT;
+    const int64_t mlo = (int64_t)split * rows_per_split;
     const int64_t mhi = min(M, mlo + rows_per_split);
     const int rows = (int)max((int64_t)0, mhi - mlo);
     constexpr int EA = A16 ? 2 : 4, EB = B16 ? 2 : 4;
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
         __syncthreads();
     }
     const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
-    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)blockIdx.z * pstride, (int64_t)N * K * 4);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)split * pstride, (int64_t)N * K * 4);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int k = k0 + wc * 64 + b * 32 + i32;
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo, row * K * 4, 0);
             }
     }
-    if (colsum && blockIdx.y == 0) {       // column sums of A (the bias gradient): row slots per column -> one value per column, fixed order
+    if (colsum && k0 == 0) {               // column sums of A (the bias gradient): row slots per column -> one value per column, fixed order
         constexpr int SL = A16 ? 16 : 8;
         if constexpr (A16) {
 #pragma unroll
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < SL; ++r) v += csum_s[r][tid];
-            partial[(int64_t)blockIdx.z * pstride + (int64_t)N * K + n0 + tid] = v;
+            partial[(int64_t)split * pstride + (int64_t)N * K + n0 + tid] = v;
         }
     }
 }
@@ -443,12 +450,13 @@ static void launch_nt16_types(const void* A, const float* W, const float* bias, 
     }
 }
 
-// row splits: about one workgroup per CU (tools/prof_gemm16.py at M = 24 600, us for 256 | 384 | 512 | 768 workgroups, bf16 operands:
-// N, K = 256, 256: 20.1 | 23.5 | 26.5 | 33.9; 1024, 256: 31.8 | 32.3 | 33.0 | 37.0; 256, 32: 19.4 | 26.6 | 26.4 | 26.0) -- every split
-// writes an [N, K] fp32 block that the reduce reads back
+// row splits: about one workgroup per CU, two for the 16-tile products (tools/prof_gemm16.py at M = 24 600, us for 256 | 512 workgroups,
+// bf16 operands, XCD-aware grid: N, K = 256, 256: 19.5 | 24.7; 768, 256: 29.8 | 29.5; 1024, 256: 31.8 | 28.9; 256, 1024: 30.4 | 28.1;
+// 256, 32: 19.5 | 26.4) -- every split writes an [N, K] fp32 block that the reduce reads back
 static int tn16_splits(int64_t M, int N, int K) {
     const int64_t tiles = ceil_div(N, HT) * ceil_div(K, HT);
-    static const int target = [] { const char* e = getenv("U3D_TN16_WGS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+    static const int forced = [] { const char* e = getenv("U3D_TN16_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const int target = forced ? forced : (tiles >= 16 ? 512 : 256);
     int64_t s = ceil_div(target, tiles);
     const int64_t max_s = ceil_div(M, 4 * WKH);
     if (s > max_s) s = max_s;
@@ -494,12 +502,12 @@ int u3d_gemm_tn_b16(const void* A, const void* B, float* C, float* colsum_A, int
         set_error("gemm_tn_b16: M=%lld N=%d K=%d too large for 32-bit split offsets", (long long)M, N, K);
         return U3D_EUNSUPPORTED;
     }
-    const dim3 grid((unsigned)ceil_div(N, HT), (unsigned)ceil_div(K, HT), (unsigned)S);
+    const dim3 grid((unsigned)(ceil_div(S, 8) * 8 * ceil_div(N, HT) * ceil_div(K, HT)));          // whole groups of 8 splits
     const int cs = colsum_A ? 1 : 0;
-    if (a16 && b16) hipLaunchKernelGGL((gemm_tn_b16_k<true, true>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps);
-    else if (a16) hipLaunchKernelGGL((gemm_tn_b16_k<true, false>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps);
-    else if (b16) hipLaunchKernelGGL((gemm_tn_b16_k<false, true>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps);
-    else hipLaunchKernelGGL((gemm_tn_b16_k<false, false>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps);
+    if (a16 && b16) hipLaunchKernelGGL((gemm_tn_b16_k<true, true>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps, S);
+    else if (a16) hipLaunchKernelGGL((gemm_tn_b16_k<true, false>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps, S);
+    else if (b16) hipLaunchKernelGGL((gemm_tn_b16_k<false, true>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps, S);
+    else hipLaunchKernelGGL((gemm_tn_b16_k<false, false>), grid, dim3(256), 0, s, A, B, (float*)ws, cs, M, N, K, rps, S);
     const int64_t n4_main = (int64_t)N * K / 4, n4 = n4_main + (colsum_A ? N / 4 : 0);
     int64_t g = ceil_div(n4, 256);
     g = g > 1024 ? 1024 : g;

@@ -3,6 +3,8 @@
 // HBM-bound: forward reads x (+res) and writes y (+ the sum kept for backward); backward reads the sum and dy, writes
 // dx; the parameter gradients are per-workgroup partials summed in a fixed order (deterministic, no atomics).
 // One wave per row; a lane owns the float4 columns lane, lane+64, ... (C % 4 == 0, C <= 1024).
+#include <stdlib.h>
+
 #include "u3d_common.h"
 
 namespace u3d {
@@ -175,9 +177,14 @@ __global__ __launch_bounds__(1024) void layer_norm_reduce_k(const float* __restr
     }
 }
 
+// workgroups of the backward pass (each walks rows with a stride and leaves one partial dgamma / dbeta row): 512, or 1024 for the head's
+// tall input (tools/prof_ln.py, backward + reduce, us at 256 | 512 | 1024 | 2048 workgroups: M = 16 937: 23.3 | 17.9 | 18.0 | 24.2;
+// 24 600: 30.8 | 21.8 | 21.7 | 27.9; 118 559: 158.6 | 99.8 | 75.3 | 80.6)
 static int ln_blocks(int64_t M) {
+    static const int forced = [] { const char* e = getenv("U3D_LN_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const int cap = forced ? forced : (M >= 65536 ? 1024 : 512);
     const int64_t b = ceil_div(M, 4);
-    return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 }  // namespace u3d

@@ -66,20 +66,17 @@ __global__ __launch_bounds__(256) void gemm_nt_b16_k(const void* __restrict__ A_
     const int voa = (srow * K + sc8 * 8) * EA, vsa = 64 * K * EA;
     const int vob = (srow * K + sc8 * 8) * 4, vsb = 64 * K * 4;
     f32x4 ra[TA][A16 ? 1 : 2], rb[NB][2];
-    // (steps past the last one are loaded from past the end of the descriptors: zeros, no memory traffic -- and no branch around the
-    // loads: a conditional load makes the compiler copy the loop-carried load registers behind a vmcnt(0), which serialises the loop)
     const int nk = K / HK;
     auto gload = [&](int kt) {
-        const int so_a = kt < nk ? kt * (HK * EA) : 0x7ffff000, so_b = kt < nk ? kt * (HK * 4) : 0x7ffff000;
 #pragma unroll
         for (int j = 0; j < TA; ++j) {
-            ra[j][0] = bload128(rs_a, voa + j * vsa, so_a);
-            if constexpr (!A16) ra[j][1] = bload128(rs_a, voa + j * vsa + 16, so_a);
+            ra[j][0] = bload128(rs_a, voa + j * vsa, kt * (HK * EA));
+            if constexpr (!A16) ra[j][1] = bload128(rs_a, voa + j * vsa + 16, kt * (HK * EA));
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            rb[j][0] = bload128(rs_b, vob + j * vsb, so_b);
-            rb[j][1] = bload128(rs_b, vob + j * vsb + 16, so_b);
+            rb[j][0] = bload128(rs_b, vob + j * vsb, kt * (HK * 4));
+            rb[j][1] = bload128(rs_b, vob + j * vsb + 16, kt * (HK * 4));
         }
     };
     auto cvt8 = [](const f32x4& lo, const f32x4& hi) {
@@ -112,13 +109,7 @@ __global__ __launch_bounds__(256) void gemm_nt_b16_k(const void* __restrict__ A_
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    gload(0);
-    stage();
-    lstore(0);
-    gload(1);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             bf16x8 af[TA], bf[NB];
@@ -134,13 +125,34 @@ __global__ __launch_bounds__(256) void gemm_nt_b16_k(const void* __restrict__ A_
                     else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
                 }
         }
-        // (the LDS stores come BEFORE the next loads: a bf16 operand's staging registers are its load registers, and while they are
-        // live across the load the compiler gives the load new registers and copies them back behind a vmcnt wait at the loop's end)
-        stage();                                                       // step kt+1 (loaded one step ago; zeros behind the last step)
+    };
+    // The main loop has NO branch around its loads (a conditional load makes the compiler copy the loop-carried load registers behind
+    // a vmcnt(0), which serialises the loop) and never loads out of range (the raw-buffer bounds check of this hardware does not see
+    // the scalar offset, tools/buf_oob.hip): the last two steps, whose two-ahead loads do not exist, are peeled off instead.  The LDS
+    // stores come BEFORE the next loads: a bf16 operand's staging registers are its load registers, and while they are live across
+    // the load the compiler gives the load new registers and copies them back behind a vmcnt wait at the loop's end.
+    gload(0);
+    stage();
+    lstore(0);
+    if (nk > 1) gload(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        const int buf = kt & 1;
+        compute(buf);
+        stage();                                                       // step kt+1 (loaded one step ago)
         if constexpr (!(U3D_NT16_ABL & 8)) lstore(buf ^ 1);             // every wave left that buffer at the barrier of step kt-1
         if constexpr (!(U3D_NT16_ABL & 4)) gload(kt + 2);
         __syncthreads();
     }
+    if (kt + 1 < nk) {                                                 // step nk-2: stages the last step, nothing left to load
+        compute(kt & 1);
+        stage();
+        lstore((kt & 1) ^ 1);
+        __syncthreads();
+        ++kt;
+    }
+    compute(kt & 1);                                                   // step nk-1
     // ---- epilogue.  D layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     if constexpr (U3D_NT16_ABL & 1) { if (acc[0][0][0] != 12345.678f) return; }
     char* Cb = reinterpret_cast<char*>(C_) + m0 * N * EC;
@@ -237,12 +249,11 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
 #pragma unroll
     for (int c = 0; c < (A16 ? 8 : 4); ++c) cs[c] = 0.f;
     const int nt = (rows + WKH - 1) / WKH;
-    auto gload = [&](int t) {            // trips past the last one: past the end of the descriptors (zeros), no branch around the loads
-        const int so_a = t < nt ? t * (WKH * N * EA) : 0x7ffff000, so_b = t < nt ? t * (WKH * K * EB) : 0x7ffff000;
+    auto gload = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) ra[j] = bload128(rs_a, ca ? va + j * (A16 ? 16 : 8) * N * EA : va, so_a);
+        for (int j = 0; j < NLA; ++j) ra[j] = bload128(rs_a, ca ? va + j * (A16 ? 16 : 8) * N * EA : va, t * (WKH * N * EA));
 #pragma unroll
-        for (int j = 0; j < NLB; ++j) rb[j] = bload128(rs_b, cb ? vb + j * (B16 ? 16 : 8) * K * EB : vb, so_b);
+        for (int j = 0; j < NLB; ++j) rb[j] = bload128(rs_b, cb ? vb + j * (B16 ? 16 : 8) * K * EB : vb, t * (WKH * K * EB));
     };
     // staging registers (rounded where the operand is fp32): the loads run two trips ahead of their use, as in gemm_nt_b16_k
     f32x4 sa16[A16 ? NLA : 1], sb16[B16 ? NLB : 1];
@@ -298,13 +309,7 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    gload(0);
-    stage();
-    lstore(0);
-    gload(1);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r0 = h * 16 + kh * 8;
@@ -319,11 +324,31 @@ __global__ __launch_bounds__(256) void gemm_tn_b16_k(const void* __restrict__ A_
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        stage();                                           // trip t+1 (loaded one trip ago; zeros behind the last trip)
+    };
+    // main loop without a branch around its loads and without out-of-range loads; the last two trips are peeled off (gemm_nt_b16_k).
+    // (Rows past the end of the split inside a trip are past the end of the descriptors -- a VECTOR offset: zeros.)
+    gload(0);
+    stage();
+    lstore(0);
+    if (nt > 1) gload(1);
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 < nt; ++t) {
+        const int buf = t & 1;
+        compute(buf);
+        stage();                                           // trip t+1 (loaded one trip ago)
         lstore(buf ^ 1);
         gload(t + 2);
         __syncthreads();
     }
+    if (t + 1 < nt) {
+        compute(t & 1);
+        stage();
+        lstore((t & 1) ^ 1);
+        __syncthreads();
+        ++t;
+    }
+    compute(t & 1);
     const int64_t pstride = (int64_t)N * K + (colsum ? N : 0);          // a split's block: [N*K] products, then [N] column sums
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(partial + (int64_t)split * pstride, (int64_t)N * K * 4);
 #pragma unroll

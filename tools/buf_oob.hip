@@ -1,5 +1,8 @@
-// Does the raw-buffer bounds check include the scalar offset?  (It does not on gfx9-family hardware: only
-// voffset + inst_offset is compared with num_records.)   build: hipcc --offload-arch=gfx950 -O3 tools/buf_oob.hip -o tools/bin/buf_oob
+// Does the raw-buffer bounds check include the scalar offset?  Measured on MI355X (gfx950), round 6: YES -- the load with the
+// scalar offset past num_records returns 0.0 like the one with the vector offset past it ("soffset past num_records -> 0.0").
+// (An earlier version of this header claimed the opposite from the GFX9 ISA text; the kernels that bound rows through the scalar
+// offset -- gemm.hip nt_epilogue, the spconv write-outs -- rely on what the probe prints.)
+// build: hipcc --offload-arch=gfx950 -O3 tools/buf_oob.hip -o tools/bin/buf_oob
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void k(const float* src, float* out, int soff) {

@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void gemm_nt_b16_k(const void* __restrict__ A_
         }
     };
     // The main loop has NO branch around its loads (a conditional load makes the compiler copy the loop-carried load registers behind
-    // a vmcnt(0), which serialises the loop) and never loads out of range (the raw-buffer bounds check of this hardware does not see
-    // the scalar offset, tools/buf_oob.hip): the last two steps, whose two-ahead loads do not exist, are peeled off instead.  The LDS
+    // a vmcnt(0), which serialises the loop) and never loads out of range: the last two steps, whose two-ahead loads do not exist,
+    // are peeled off (measured ahead of loading "steps past the end" through an out-of-range offset by 4-8 %).  The LDS
     // stores come BEFORE the next loads: a bf16 operand's staging registers are its load registers, and while they are live across
     // the load the compiler gives the load new registers and copies them back behind a vmcnt wait at the loop's end.
     gload(0);
